@@ -1,0 +1,201 @@
+/*
+ * splash_hip.h -- C ABI of librsplash_hip.so: the MI355X (gfx950) implementation of rsplash's
+ * gridded daily water/energy balance loop.
+ *
+ * This is the drop-in boundary.  The reference exposes the path through the Rcpp module
+ * "splash_module" (src/SPLASH.cpp:12-21: class SPLASH(lat, elv) with methods spin_up, run_all,
+ * run_one_year, moist_surf, inf_GA) which R/splash.point.R:92-172 drives once per cell, and
+ * R/splash.grid.R:277-308 maps over the cells of a row block.  A per-cell call cannot feed a GPU,
+ * so the boundary is offered at three levels, all plain C (pointers + sizes, no R, no torch):
+ *
+ *   1. splash_grid_run / splash_point_run   host buffers in, host buffers out: what a `.Call`
+ *      shim behind splash.grid()/splash.point() binds (INTEGRATION.md shows the shim);
+ *   2. splash_dev_*                         device-resident stages for callers that keep the
+ *      rasters in HBM (bench.py, multi-GPU drivers): soil_hydro -> snow_threshold -> spin_up ->
+ *      run_all (+ diagnostics);
+ *   3. splash_mod_*                         one-cell mirrors of the Rcpp module's methods with
+ *      the reference's argument lists, used by the parity tests.
+ *
+ * Layouts: every raster series is time-major [nt][ncell] double (== R's [ncell x nt] column-major
+ * matrix from raster::getValues, R/splash.grid.R:278-280), cell index = row-major raster cell.
+ * Every function returns 0 on success or a negative SPLASH_E* code; when `err` is non-NULL a
+ * message is written there.  Nothing is freed or retained except what the *_create calls return.
+ * The library has no CPU fallback: without a HIP device every compute entry point fails with
+ * SPLASH_ENODEV.
+ */
+#ifndef SPLASH_HIP_H
+#define SPLASH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPLASH_ABI_VERSION 1
+
+enum {
+    SPLASH_OK = 0,
+    SPLASH_EINVAL = -1,  /* bad argument */
+    SPLASH_ENODEV = -2,  /* no HIP device / HIP runtime error */
+    SPLASH_ENOMEM = -3,  /* host or device allocation failed */
+    SPLASH_EHIP = -4     /* kernel launch / runtime failure */
+};
+
+/* rows of the per-cell parameter array cellpar[SPLASH_NPAR][ld] produced by soil_hydro:
+ * lat, elev, slop, asp-180 (R/splash.point.R:131), then soil_info[0..11] in the order of
+ * R/splash.point.R:110-114 (SAT, WP, FC, Ksat, lambda, depth, bub_press, RES, Au, Ai, ncellin,
+ * ncellout), then the R-side Wmax = theta_c*depth*1000 used by sm_lim (R/splash.point.R:102,197). */
+#define SPLASH_NPAR 17
+#define SPLASH_NSTATE 5 /* wn, snow, qin, td, nd : the carry of SPLASH::run_all, src/SPLASH.cpp:1878-1889 */
+#define SPLASH_NOUT 9   /* wn, ro, pet, aet, snow, cond, bflow, netr, sm_lim (R/splash.point.R:182,201) */
+#define SPLASH_NDIAG 6  /* precip(rain+snowfall), aet, ro, bflow, wn, snow : monthly totals over cells */
+
+int splash_hip_abi_version(void);
+int splash_hip_device_count(void);            /* 0 when no device; never fails */
+const char* splash_hip_last_error(void);      /* thread-local text of the last failure */
+
+/* ---------------------------------------------------------------- calendar ---------------- */
+/* Per-day tables shared by all cells: orbit terms (src/SOLAR.cpp:98-124, 291-374), the month
+ * factors of frain_func (R/splash.point.R:549-550) and month bookkeeping for the monthly
+ * aggregation (R/splash.point.R:208).  doy/year/month are what R passes as doys/yrs and
+ * format(time_index,"%m").  The calendar owns a device copy on the current device. */
+typedef struct splash_calendar splash_calendar;
+int splash_calendar_create(int nt, const int* doy, const int* year, const int* month,
+                           splash_calendar** out, char* err, size_t errlen);
+void splash_calendar_destroy(splash_calendar* cal);
+int splash_calendar_nt(const splash_calendar* cal);
+int splash_calendar_nmonth(const splash_calendar* cal);
+/* host copy of the orbit table, for tests: dr, sin(delta), cos(delta), each [nt] */
+int splash_calendar_orbit(const splash_calendar* cal, double* dr, double* sd, double* cd);
+
+/* ---------------------------------------------------------------- device-resident stages -- */
+/* All pointers below are DEVICE pointers on the current device; `stream` is a hipStream_t
+ * passed as void* (NULL = default stream).  Calls are asynchronous on that stream. */
+
+/* K1 soil_hydro + soil_info (R/splash.point.R:96-115, 232-416).
+ * soil [6][ncell] = sand, clay, OM, gravel, bulk density (NaN => estimated), depth;
+ * au [3][ncell] = upslope area, ncellin, ncellout, or NULL (=> 0,3,3). */
+int splash_dev_soil_hydro(size_t ncell, const double* lat, const double* elev, const double* slop,
+                          const double* asp, const double* resolution, const double* soil,
+                          const double* au, double* cellpar /*[SPLASH_NPAR][ncell]*/, void* stream);
+
+/* K2 snowfall threshold Tt = max(tc[p_snow >= 0.5]) over the whole series
+ * (R/splash.point.R:120-122); -Inf where no day qualifies.  tc is [nt][ldf]. */
+int splash_dev_snow_threshold(size_t ncell, int nt, const double* tc, size_t ldf,
+                              const double* cellpar, size_t ldp, double* Tt, void* stream);
+
+/* K4 the two spin-ups of splash.point (R/splash.point.R:141-152 -> SPLASH::spin_up,
+ * src/SPLASH.cpp:1594-1749) on the first 365 days of the calendar: spin-up #1, aridity index
+ * AI = sum(pet)/sum(P), cellout := AI (written to cellpar row 15), spin-up #2.  Writes the state
+ * handed to run_all.  passes (optional) [2][ncell] int: executed passes of each spin-up.
+ * The pass count is data dependent (2..1000 per spin-up), so the stage runs as a few phases over
+ * shrinking worklists; `work` is scratch of splash_dev_spin_up_work_size(ncell) bytes. */
+size_t splash_dev_spin_up_work_size(size_t ncell);
+int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, const double* sw_in,
+                       const double* tc, const double* pn, size_t ldf, const double* Tt,
+                       double* cellpar, size_t ldp, double* state /*[5][lds]*/, size_t lds,
+                       int* passes, void* work, void* stream);
+
+typedef struct {
+    double* out[SPLASH_NOUT]; /* each [nt_out][ldo] or NULL to skip that series */
+    size_t ldo;
+    int monthly;              /* 0: one row per day; 1: one row per calendar month
+                                 (mean of wn, snow, sm_lim; sum of the others) */
+    double* diag;             /* optional [nmonth_in_range][SPLASH_NDIAG] grid totals, or NULL */
+    double* diag_work;        /* scratch of splash_dev_diag_work_size() bytes when diag != NULL */
+} splash_dev_out;
+
+size_t splash_dev_diag_work_size(size_t ncell, int nmonth);
+
+/* K5 transient run: SPLASH::run_all (src/SPLASH.cpp:1833-1916) over days [t0, t0+nt) of the
+ * calendar for ncell cells, with the rain/snow split (K2 part 2) fused into the loads.  Forcing
+ * pointers address day t0 (row stride ldf).  state is read and overwritten (time-chunking).
+ * In monthly mode, row m of an output is month (month_id(t0+..) - month_id(t0)). */
+int splash_dev_run_all(const splash_calendar* cal, int t0, int nt, size_t ncell,
+                       const double* sw_in, const double* tc, const double* pn, size_t ldf,
+                       const double* Tt, const double* cellpar, size_t ldp, double* state,
+                       size_t lds, const splash_dev_out* out, void* stream);
+
+/* synthetic inputs on the device (generator spec: DESIGN.md "Synthetic inputs"; same
+ * counter-based splitmix64 streams as the oracle's generator).  Cells [cell0, cell0+ncell) of an
+ * H x W grid, row-major. */
+int splash_dev_synth_statics(uint64_t seed, int H, int W, int64_t cell0, size_t ncell, int terrain,
+                             double* lat, double* elev, double* slop, double* asp,
+                             double* resolution, double* soil /*[6][ncell]*/,
+                             double* au /*[3][ncell]*/, void* stream);
+int splash_dev_synth_forcing(uint64_t seed, const splash_calendar* cal, int t0, int nt,
+                             int64_t cell0, size_t ncell, const double* lat, const double* elev,
+                             double* sw_in, double* tc, double* pn, size_t ldf, void* stream);
+
+/* test hook: SOLAR+EVAP for m independent rows (src/EVAP.cpp:82-264), out [m][11] in the order
+ * of src/etr.h:44-56 (cond, eet, pet, aet, snowmelt, sublimation, econ, pw, rn_d, visc, pet_max) */
+int splash_dev_evap_batch(size_t m, const double* lat, const double* elv, const double* sw,
+                          const int* n, const int* y, const double* sw_in, const double* tc,
+                          const double* slop, const double* asp, const double* snow,
+                          const double* nd, double* out, void* stream);
+
+/* ---------------------------------------------------------------- host-buffer entry points - */
+typedef struct {
+    size_t ncell;
+    int nt;
+    const int *doy, *year, *month;           /* [nt] */
+    const double *sw_in, *tc, *pn;           /* [nt][ncell] (W m-2, deg C, mm) */
+    const double *lat, *elev, *slop, *asp;   /* [ncell] degrees / m; asp clockwise from north */
+    const double* resolution;                /* [ncell] m */
+    const double* soil;                      /* [6][ncell] */
+    const double* au;                        /* [3][ncell] or NULL */
+} splash_grid_in;
+
+typedef struct {
+    int monthly_out;    /* sim.control$monthly_out, R/splash.grid.R:28 (default TRUE there) */
+    int device;         /* HIP device ordinal */
+    size_t max_cells_per_launch; /* 0 = size blocks from free HBM */
+} splash_opts;
+
+typedef struct {
+    double* out[SPLASH_NOUT]; /* caller-allocated [nt_out][ncell], NULL to skip */
+    double* state_end;        /* optional [5][ncell] */
+    double* diag;             /* optional [nmonth][SPLASH_NDIAG] */
+    double* aux;              /* optional [4][ncell]: Tt, AI, passes1, passes2 */
+} splash_grid_out;
+
+/* splash.grid's inner computation for a block of cells (R/splash.grid.R:277-308): every cell gets
+ * what splash.point computes (R/splash.point.R:92-214).  Cells with NaN statics or NaN day-0
+ * forcing are returned as NaN (R's NA cells). */
+int splash_grid_run(const splash_grid_in* in, const splash_opts* opt, const splash_grid_out* out,
+                    char* err, size_t errlen);
+
+/* splash.point (R/splash.point.R:29-225) for one site: the same pipeline with ncell = 1.
+ * au: pointer to 1 value (scalar Au, ncellin=ncellout=3) when n_au==1, or 3 values. */
+int splash_point_run(int nt, const int* doy, const int* year, const int* month,
+                     const double* sw_in, const double* tc, const double* pn, double lat,
+                     double elev, double slop, double asp, const double* soil_data /*[6]*/,
+                     const double* au, int n_au, double resolution, int monthly_out,
+                     double* const out[SPLASH_NOUT], char* err, size_t errlen);
+
+/* ---------------------------------------------------------------- Rcpp-module mirrors ------ */
+/* One-cell GPU evaluations with the argument lists of src/SPLASH.h:85-103 (host pointers).
+ * soil_info has 12 (or 13) entries as built by R/splash.point.R:110-114. */
+int splash_mod_spin_up(double lat, double elv, int n, int y, const double* sw_in,
+                       const double* tair, const double* pn, double slop, double asp,
+                       const double* snowfall, const double* soil_info,
+                       double* sm, double* snow, double* qin, double* tdrain, double* ro,
+                       double* snwage, double* pet /* each [n] or NULL */, int* passes);
+int splash_mod_run_all(double lat, double elv, int nt, const int* doys, const int* yrs,
+                       const double* sw_in, const double* tair, const double* pn, double wn_last,
+                       double slop, double asp, double snow_last, const double* snowfall,
+                       const double* soil_info, double qin_last, double td_last, double nds_last,
+                       double* wn, double* ro, double* pet, double* aet, double* snow, double* cond,
+                       double* bflow, double* netr, double* qin_prev, double* tdrain,
+                       double* snwage /* each [nt] or NULL */);
+int splash_mod_moist_surf(double depth, double z, double bub_p, double wn, double SAT, double RES,
+                          double lambda, double* theta);
+int splash_mod_inf_GA(double bub_press, double theta_i, double Ksat, double theta_s, double lambda,
+                      double P, double tdur, double slop, double* infiltration);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1319,7 +1319,7 @@ void orc_grid_transient(int ncell, int nt, const int* doy, const int* year, cons
         for (int k = 0; k < 12; k++) si[k] = soil_info[(size_t)k * ncell + c];
         double wn = state[c], swe = state[(size_t)ncell + c], qin = state[2 * (size_t)ncell + c];
         double td = state[3 * (size_t)ncell + c], nd = state[4 * (size_t)ncell + c];
-        double asp_c = asp[c] - 180;
+        double asp_c = asp[c]; /* already asp-180 (R/splash.point.R:131) */
         orc_smr ds;
         orc_etr dv;
         for (int t = 0; t < nt; t++) {

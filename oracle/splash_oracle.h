@@ -142,7 +142,8 @@ void orc_grid(int ncell, int nt, const int* doy, const int* year, const int* mon
               const orc_opts* opt, double* const out[9], orc_cell_aux* aux /*[ncell] or NULL*/);
 
 /* transient-only variant for the CPU baseline: run_all per cell from a given state
- * (Tt given; rain/snow split done on the fly).  outputs wn,snow,ro,aet,pet [nt][ncell]. */
+ * (Tt given; rain/snow split done on the fly; asp is ALREADY asp-180).  outputs
+ * wn,snow,ro,aet,pet [nt][ncell]. */
 void orc_grid_transient(int ncell, int nt, const int* doy, const int* year, const int* month,
                         const double* sw_in, const double* tc, const double* pn,
                         const double* lat, const double* elev, const double* slop,

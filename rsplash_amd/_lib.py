@@ -1,0 +1,103 @@
+"""ctypes prototypes for include/splash_hip.h.  Fails loudly when the library is absent."""
+import ctypes as C
+import os
+
+from .build import library_path
+
+NPAR, NSTATE, NOUT, NDIAG = 17, 5, 9, 6
+OUT_NAMES = ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "sm_lim")
+DIAG_NAMES = ("precip", "aet", "ro", "bflow", "wn", "snow")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+
+class GridIn(C.Structure):
+    _fields_ = [("ncell", C.c_size_t), ("nt", C.c_int), ("doy", _ip), ("year", _ip), ("month", _ip),
+                ("sw_in", _dp), ("tc", _dp), ("pn", _dp), ("lat", _dp), ("elev", _dp),
+                ("slop", _dp), ("asp", _dp), ("resolution", _dp), ("soil", _dp), ("au", _dp)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("monthly_out", C.c_int), ("device", C.c_int), ("max_cells_per_launch", C.c_size_t)]
+
+
+class GridOut(C.Structure):
+    _fields_ = [("out", _dp * NOUT), ("state_end", _dp), ("diag", _dp), ("aux", _dp)]
+
+
+class DevOut(C.Structure):
+    _fields_ = [("out", _vp * NOUT), ("ldo", C.c_size_t), ("monthly", C.c_int), ("diag", _vp),
+                ("diag_work", _vp)]
+
+
+def _load():
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with rsplash_amd.build_library() "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(path)
+    L.splash_hip_abi_version.restype = C.c_int
+    L.splash_hip_device_count.restype = C.c_int
+    L.splash_hip_last_error.restype = C.c_char_p
+    L.splash_calendar_create.argtypes = [C.c_int, _ip, _ip, _ip, C.POINTER(_vp), C.c_char_p, C.c_size_t]
+    L.splash_calendar_destroy.argtypes = [_vp]
+    L.splash_calendar_destroy.restype = None
+    L.splash_calendar_nt.argtypes = [_vp]
+    L.splash_calendar_nmonth.argtypes = [_vp]
+    L.splash_calendar_orbit.argtypes = [_vp, _dp, _dp, _dp]
+    L.splash_dev_soil_hydro.argtypes = [C.c_size_t] + [_vp] * 8 + [_vp]
+    L.splash_dev_snow_threshold.argtypes = [C.c_size_t, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t,
+                                            _vp, _vp]
+    L.splash_dev_spin_up_work_size.restype = C.c_size_t
+    L.splash_dev_spin_up_work_size.argtypes = [C.c_size_t]
+    L.splash_dev_spin_up.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t, _vp, _vp,
+                                     C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp]
+    L.splash_dev_diag_work_size.restype = C.c_size_t
+    L.splash_dev_diag_work_size.argtypes = [C.c_size_t, C.c_int]
+    L.splash_dev_run_all.argtypes = [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, C.c_size_t,
+                                     _vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(DevOut), _vp]
+    L.splash_dev_synth_statics.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_size_t,
+                                           C.c_int] + [_vp] * 7 + [_vp]
+    L.splash_dev_synth_forcing.argtypes = [C.c_uint64, _vp, C.c_int, C.c_int, C.c_int64,
+                                           C.c_size_t, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]
+    L.splash_dev_evap_batch.argtypes = [C.c_size_t, _dp, _dp, _dp, _ip, _ip] + [_dp] * 7 + [_vp]
+    L.splash_grid_run.argtypes = [C.POINTER(GridIn), C.POINTER(Opts), C.POINTER(GridOut),
+                                  C.c_char_p, C.c_size_t]
+    L.splash_point_run.argtypes = [C.c_int, _ip, _ip, _ip, _dp, _dp, _dp] + [C.c_double] * 4 + \
+        [_dp, _dp, C.c_int, C.c_double, C.c_int, C.POINTER(_dp), C.c_char_p, C.c_size_t]
+    L.splash_mod_spin_up.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, _dp, _dp, _dp,
+                                     C.c_double, C.c_double, _dp, _dp] + [_dp] * 7 + [_ip]
+    L.splash_mod_run_all.argtypes = [C.c_double, C.c_double, C.c_int, _ip, _ip, _dp, _dp, _dp,
+                                     C.c_double, C.c_double, C.c_double, C.c_double, _dp, _dp,
+                                     C.c_double, C.c_double, C.c_double] + [_dp] * 11
+    L.splash_mod_moist_surf.argtypes = [C.c_double] * 7 + [_dp]
+    L.splash_mod_inf_GA.argtypes = [C.c_double] * 8 + [_dp]
+    return L
+
+
+lib = _load()
+
+# every symbol include/splash_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = (
+    "splash_hip_abi_version", "splash_hip_device_count", "splash_hip_last_error",
+    "splash_calendar_create", "splash_calendar_destroy", "splash_calendar_nt",
+    "splash_calendar_nmonth", "splash_calendar_orbit", "splash_dev_soil_hydro",
+    "splash_dev_snow_threshold", "splash_dev_spin_up_work_size", "splash_dev_spin_up",
+    "splash_dev_diag_work_size",
+    "splash_dev_run_all", "splash_dev_synth_statics", "splash_dev_synth_forcing",
+    "splash_dev_evap_batch", "splash_grid_run", "splash_point_run", "splash_mod_spin_up",
+    "splash_mod_run_all", "splash_mod_moist_surf", "splash_mod_inf_GA",
+)
+
+
+class SplashError(RuntimeError):
+    pass
+
+
+def check(rc, where=""):
+    if rc != 0:
+        msg = lib.splash_hip_last_error()
+        raise SplashError(f"{where} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,324 @@
+"""Host-side mirror of the reference's interface for the gridded SPLASH path.
+
+  splash_point(...)  <->  R/splash.point.R:29   (same argument names / meaning / outputs)
+  splash_grid(...)   <->  R/splash.grid.R:28    (arrays instead of Raster* objects)
+  SPLASH(lat, elv)   <->  Rcpp module "splash_module", src/SPLASH.cpp:12-21
+  Calendar, dev_*    <->  the device-resident stages of include/splash_hip.h (torch tensors or
+                          raw device pointers; used by bench.py and multi-GPU drivers)
+
+Everything computes through librsplash_hip.so; there is no numerical fallback here.
+"""
+import ctypes as C
+import datetime as _dt
+
+import numpy as np
+
+from . import _lib
+from ._lib import DIAG_NAMES, NDIAG, NOUT, NPAR, NSTATE, OUT_NAMES, SplashError, check, lib
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+def device_count():
+    return lib.splash_hip_device_count()
+
+
+def time_fields(time_index):
+    """doy / year / month vectors (what R derives with format(time_index, '%j' / '%Y' / '%m'),
+    R/splash.point.R:57-59, 547)."""
+    t = np.asarray(time_index)
+    if t.dtype.kind == "M":
+        days = t.astype("datetime64[D]")
+        years = days.astype("datetime64[Y]")
+        months = days.astype("datetime64[M]")
+        year = years.astype(int) + 1970
+        month = months.astype(int) % 12 + 1
+        doy = (days - years.astype("datetime64[D]")).astype(int) + 1
+    else:
+        dates = [d if isinstance(d, _dt.date) else _dt.date.fromisoformat(str(d)) for d in t]
+        year = np.array([d.year for d in dates])
+        month = np.array([d.month for d in dates])
+        doy = np.array([d.timetuple().tm_yday for d in dates])
+    return doy.astype(np.int32), year.astype(np.int32), month.astype(np.int32)
+
+
+def month_ids(year, month):
+    """running month number (groups of format(time_index,'%Y-%m'), R/splash.point.R:208)."""
+    key = np.asarray(year).astype(np.int64) * 12 + np.asarray(month)
+    chg = np.r_[0, (key[1:] != key[:-1]).astype(np.int64)]
+    return np.cumsum(chg).astype(np.int32)
+
+
+# ---------------------------------------------------------------------------- splash.point
+def splash_point(sw_in, tc, pn, lat, elev, slop=0.0, asp=0.0, soil_data=None, Au=0.0,
+                 resolution=250.0, time_index=None, monthly_out=False):
+    """R/splash.point.R:29.  Daily series in, dict of the 9 reference outputs out
+    (wn, ro, pet, aet, snow, cond, bflow, netr, sm_lim).  `time_index`: dates of the series.
+    Monthly inputs (R/splash.point.R:66-86) are not supported: their disaggregation draws from
+    an unseeded RNG in the reference."""
+    if time_index is None:
+        raise ValueError("time_index is required (dates of the daily series)")
+    if soil_data is None or len(soil_data) != 6:
+        raise ValueError("soil_data = c(sand, clay, OM, gravel, bulk density (may be NaN), depth)")
+    doy, year, month = time_fields(time_index)
+    nt = len(doy)
+    f = [_d(x) for x in (sw_in, tc, pn)]
+    if any(len(x[0]) != nt for x in f):
+        raise ValueError("sw_in, tc, pn and time_index must have the same length")
+    sd, sdp = _d(soil_data)
+    au = np.atleast_1d(np.asarray(Au, dtype=np.float64))
+    aua, aup = _d(au)
+    nm = int(month_ids(year, month)[-1]) + 1
+    nt_out = nm if monthly_out else nt
+    out = np.empty((NOUT, nt_out))
+    ptrs = (_dp * NOUT)(*[out[k].ctypes.data_as(_dp) for k in range(NOUT)])
+    err = C.create_string_buffer(512)
+    ia = [_i(x) for x in (doy, year, month)]
+    rc = lib.splash_point_run(nt, ia[0][1], ia[1][1], ia[2][1], f[0][1], f[1][1], f[2][1],
+                              float(lat), float(elev), float(slop), float(asp), sdp, aup, len(au),
+                              float(resolution), int(bool(monthly_out)), ptrs, err, 512)
+    if rc:
+        raise SplashError(f"splash_point_run failed ({rc}): {err.value.decode()}")
+    return {k: out[i] for i, k in enumerate(OUT_NAMES)}
+
+
+# ---------------------------------------------------------------------------- splash.grid
+def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=250.0,
+                time_index=None, sim_control=None, outputs=OUT_NAMES, device=0,
+                max_cells_per_launch=0, want_aux=False, want_diag=False):
+    """R/splash.grid.R:28 on arrays.  sw_in/tc/pn: [nt, ncell] (or [nt, H, W]) daily rasters;
+    elev/lat/slop/asp: [ncell]; soil: [6, ncell]; Au: [3, ncell] (area, ncellin, ncellout) or
+    None.  The static rasters the reference derives with raster/GDAL/TauDEM (lat, slope, aspect,
+    upslope area, resolution: R/splash.grid.R:76-110) are inputs here.  sim_control =
+    dict(monthly_out=True) mirrors sim.control (monthly is the reference's default).
+    Returns dict of [nt_out, ...] arrays named as R/splash.grid.R:449 (netr is 'netrad' there)."""
+    if time_index is None:
+        raise ValueError("time_index is required")
+    monthly = True if sim_control is None else bool(sim_control.get("monthly_out", True))
+    sw = np.asarray(sw_in, dtype=np.float64)
+    shp = sw.shape[1:]
+    nt = sw.shape[0]
+    ncell = int(np.prod(shp))
+    doy, year, month = time_fields(time_index)
+    if len(doy) != nt:
+        raise ValueError("time_index length differs from the rasters' time dimension")
+
+    def flat(a, lead):
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float64)).reshape(lead + (ncell,))
+        return a, a.ctypes.data_as(_dp)
+
+    f = [flat(x, (nt,)) for x in (sw, tc, pn)]
+    st = [flat(np.broadcast_to(np.asarray(x, dtype=np.float64), shp) if np.ndim(x) == 0 else x, ())
+          for x in (lat, elev, slop, asp, resolution)]
+    so = flat(soil, (6,))
+    au = flat(Au, (3,)) if Au is not None else None
+    ia = [_i(x) for x in (doy, year, month)]
+    gin = _lib.GridIn(ncell, nt, ia[0][1], ia[1][1], ia[2][1], f[0][1], f[1][1], f[2][1],
+                      st[0][1], st[1][1], st[2][1], st[3][1], st[4][1], so[1],
+                      au[1] if au else None)
+    nm = int(month_ids(year, month)[-1]) + 1
+    nt_out = nm if monthly else nt
+    res = {k: np.empty((nt_out,) + shp) for k in outputs}
+    gout = _lib.GridOut()
+    for i, k in enumerate(OUT_NAMES):
+        gout.out[i] = res[k].ctypes.data_as(_dp) if k in res else None
+    state_end = np.empty((NSTATE,) + shp)
+    gout.state_end = state_end.ctypes.data_as(_dp)
+    aux = diag = None
+    if want_aux:
+        aux = np.empty((4,) + shp)
+        gout.aux = aux.ctypes.data_as(_dp)
+    if want_diag:
+        diag = np.empty((nm, NDIAG))
+        gout.diag = diag.ctypes.data_as(_dp)
+    opt = _lib.Opts(int(monthly), int(device), int(max_cells_per_launch))
+    err = C.create_string_buffer(512)
+    rc = lib.splash_grid_run(C.byref(gin), C.byref(opt), C.byref(gout), err, 512)
+    if rc:
+        raise SplashError(f"splash_grid_run failed ({rc}): {err.value.decode()}")
+    res["state_end"] = state_end
+    if want_aux:
+        res["aux"] = dict(Tt=aux[0], AI=aux[1], passes1=aux[2], passes2=aux[3])
+    if want_diag:
+        res["diag"] = {k: diag[:, i] for i, k in enumerate(DIAG_NAMES)}
+    return res
+
+
+# ---------------------------------------------------------------------------- Rcpp module mirror
+class SPLASH:
+    """Mirror of the Rcpp class exposed by src/SPLASH.cpp:12-21 (`new(SPLASH, lat, elev)`)."""
+
+    def __init__(self, lat, elv):
+        self.lat, self.elv = float(lat), float(elv)
+
+    def spin_up(self, n, y, sw_in, tair, pn, slop, asp, snowfall, soil_info):
+        """src/SPLASH.cpp:1594 -> dict(sm, snow, qin, tdrain, ro, snwage, pet) (+ 'passes')."""
+        a = [_d(x) for x in (sw_in, tair, pn, snowfall, soil_info)]
+        names = ("sm", "snow", "qin", "tdrain", "ro", "snwage", "pet")
+        out = {k: np.empty(n) for k in names}
+        passes = C.c_int(0)
+        check(lib.splash_mod_spin_up(self.lat, self.elv, int(n), int(y), a[0][1], a[1][1], a[2][1],
+                                     float(slop), float(asp), a[3][1], a[4][1],
+                                     *[out[k].ctypes.data_as(_dp) for k in names],
+                                     C.byref(passes)), "splash_mod_spin_up")
+        out["passes"] = passes.value
+        return out
+
+    def run_all(self, doys, yrs, sw_in, tair, pn, wn_last, slop, asp, snow_last, snowfall,
+                soil_info, qin_last, td_last, nds_last):
+        """src/SPLASH.cpp:1833 -> dict of the 11 series of :1913-1915."""
+        nt = len(doys)
+        d, dp_ = _i(doys)
+        y, yp = _i(yrs)
+        a = [_d(x) for x in (sw_in, tair, pn, snowfall, soil_info)]
+        names = ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "qin_prev", "tdrain",
+                 "snwage")
+        out = {k: np.empty(nt) for k in names}
+        check(lib.splash_mod_run_all(self.lat, self.elv, nt, dp_, yp, a[0][1], a[1][1], a[2][1],
+                                     float(wn_last), float(slop), float(asp), float(snow_last),
+                                     a[3][1], a[4][1], float(qin_last), float(td_last),
+                                     float(nds_last),
+                                     *[out[k].ctypes.data_as(_dp) for k in names]),
+              "splash_mod_run_all")
+        return out
+
+    @staticmethod
+    def moist_surf(depth, z, bub_p, wn, SAT, RES, lam):
+        """src/SPLASH.cpp:1921"""
+        v = C.c_double()
+        check(lib.splash_mod_moist_surf(depth, z, bub_p, wn, SAT, RES, lam, C.byref(v)),
+              "splash_mod_moist_surf")
+        return v.value
+
+    @staticmethod
+    def inf_GA(bub_press, theta_i, Ksat, theta_s, lam, P, tdur, slop):
+        """src/SPLASH.cpp:1963"""
+        v = C.c_double()
+        check(lib.splash_mod_inf_GA(bub_press, theta_i, Ksat, theta_s, lam, P, tdur, slop,
+                                    C.byref(v)), "splash_mod_inf_GA")
+        return v.value
+
+
+def evap_batch(lat, elv, sw, n, y, sw_in, tc, slop, asp, snow, nd):
+    """test hook: SOLAR+EVAP rows on the GPU -> [m, 11] (order of src/etr.h:44-56)."""
+    m = len(lat)
+    out = np.empty((m, 11))
+    f = [_d(x) for x in (lat, elv, sw)]
+    i = [_i(x) for x in (n, y)]
+    g = [_d(x) for x in (sw_in, tc, slop, asp, snow, nd)]
+    check(lib.splash_dev_evap_batch(m, f[0][1], f[1][1], f[2][1], i[0][1], i[1][1],
+                                    *[x[1] for x in g], out.ctypes.data_as(_dp), None),
+          "splash_dev_evap_batch")
+    return out
+
+
+# ---------------------------------------------------------------------------- device-resident API
+def _ptr(x):
+    """device pointer of a torch tensor (or an int / None)."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()
+
+
+class Calendar:
+    """Per-day tables on the current device (splash_calendar_create)."""
+
+    def __init__(self, doy, year, month):
+        ia = [_i(x) for x in (doy, year, month)]
+        self.nt = len(ia[0][0])
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = lib.splash_calendar_create(self.nt, ia[0][1], ia[1][1], ia[2][1], C.byref(h), err, 512)
+        if rc:
+            raise SplashError(f"splash_calendar_create failed ({rc}): {err.value.decode()}")
+        self.h = h
+        self.nmonth = lib.splash_calendar_nmonth(h)
+        self.month_id = month_ids(year, month)
+
+    @classmethod
+    def from_dates(cls, time_index):
+        return cls(*time_fields(time_index))
+
+    def orbit(self):
+        dr, sd, cd = (np.empty(self.nt) for _ in range(3))
+        check(lib.splash_calendar_orbit(self.h, *[x.ctypes.data_as(_dp) for x in (dr, sd, cd)]))
+        return dr, sd, cd
+
+    def close(self):
+        if self.h:
+            lib.splash_calendar_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def dev_soil_hydro(ncell, lat, elev, slop, asp, resolution, soil, au, cellpar, stream=None):
+    check(lib.splash_dev_soil_hydro(ncell, _ptr(lat), _ptr(elev), _ptr(slop), _ptr(asp),
+                                    _ptr(resolution), _ptr(soil), _ptr(au), _ptr(cellpar), stream),
+          "splash_dev_soil_hydro")
+
+
+def dev_snow_threshold(ncell, nt, tc, ldf, cellpar, ldp, Tt, stream=None):
+    check(lib.splash_dev_snow_threshold(ncell, nt, _ptr(tc), ldf, _ptr(cellpar), ldp, _ptr(Tt),
+                                        stream), "splash_dev_snow_threshold")
+
+
+def spin_up_work_size(ncell):
+    return lib.splash_dev_spin_up_work_size(ncell)
+
+
+def dev_spin_up(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, work, passes=None,
+                stream=None):
+    """work: device scratch of spin_up_work_size(ncell) bytes"""
+    check(lib.splash_dev_spin_up(cal.h, ncell, _ptr(sw_in), _ptr(tc), _ptr(pn), ldf, _ptr(Tt),
+                                 _ptr(cellpar), ldp, _ptr(state), lds, _ptr(passes), _ptr(work),
+                                 stream), "splash_dev_spin_up")
+
+
+def diag_work_size(ncell, nmonth):
+    return lib.splash_dev_diag_work_size(ncell, nmonth)
+
+
+def dev_run_all(cal, t0, nt, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, out_ptrs,
+                ldo, monthly=False, diag=None, diag_work=None, stream=None):
+    """out_ptrs: dict name -> tensor/pointer for the series to store (others are skipped)."""
+    o = _lib.DevOut()
+    for i, k in enumerate(OUT_NAMES):
+        o.out[i] = _ptr(out_ptrs.get(k)) if out_ptrs else None
+    o.ldo = ldo
+    o.monthly = int(bool(monthly))
+    o.diag = _ptr(diag)
+    o.diag_work = _ptr(diag_work)
+    check(lib.splash_dev_run_all(cal.h, t0, nt, ncell, _ptr(sw_in), _ptr(tc), _ptr(pn), ldf,
+                                 _ptr(Tt), _ptr(cellpar), ldp, _ptr(state), lds, C.byref(o),
+                                 stream), "splash_dev_run_all")
+
+
+def dev_synth_statics(seed, H, W, cell0, ncell, terrain, lat, elev, slop, asp, resolution, soil,
+                      au, stream=None):
+    check(lib.splash_dev_synth_statics(seed, H, W, cell0, ncell, int(terrain), _ptr(lat),
+                                       _ptr(elev), _ptr(slop), _ptr(asp), _ptr(resolution),
+                                       _ptr(soil), _ptr(au), stream), "splash_dev_synth_statics")
+
+
+def dev_synth_forcing(seed, cal, t0, nt, cell0, ncell, lat, elev, sw_in, tc, pn, ldf, stream=None):
+    check(lib.splash_dev_synth_forcing(seed, cal.h, t0, nt, cell0, ncell, _ptr(lat), _ptr(elev),
+                                       _ptr(sw_in), _ptr(tc), _ptr(pn), ldf, stream),
+          "splash_dev_synth_forcing")

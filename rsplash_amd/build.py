@@ -1,0 +1,21 @@
+"""In-tree build of librsplash_hip.so (hipcc --offload-arch=gfx950)."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def library_path():
+    return os.path.join(_HERE, "librsplash_hip.so")
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source of the package for gfx950; returns the .so path."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    if not os.path.exists(library_path()):
+        raise RuntimeError("librsplash_hip.so was not produced by " + " ".join(cmd))
+    return library_path()

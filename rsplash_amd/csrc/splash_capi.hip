@@ -1,0 +1,841 @@
+// splash_capi.hip -- the C ABI of librsplash_hip.so (include/splash_hip.h) and the host-side
+// pipeline that stands where R/splash.point.R:92-214 and R/splash.grid.R:277-308 stand in the
+// reference: calendar tables, stage sequencing, NA-cell masking, blocking over HBM capacity.
+// There is no CPU compute path in this file: every entry point that produces results launches the
+// HIP kernels, and fails with SPLASH_ENODEV when no device is present.
+#include "../../include/splash_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "splash_kernels.hpp"
+
+using namespace splash;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+static int fail(int code, char* err, size_t errlen, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    if (err && errlen) {
+        snprintf(err, errlen, "%s", buf);
+    }
+    return code;
+}
+
+#define HIP_TRY(expr, err, errlen)                                                          \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return fail(e__ == hipErrorOutOfMemory ? SPLASH_ENOMEM                          \
+                        : (e__ == hipErrorNoDevice || e__ == hipErrorInvalidDevice)         \
+                            ? SPLASH_ENODEV                                                 \
+                            : SPLASH_EHIP,                                                  \
+                        err, errlen, "%s: %s", #expr, hipGetErrorString(e__));              \
+    } while (0)
+
+extern "C" int splash_hip_abi_version(void) { return SPLASH_ABI_VERSION; }
+
+extern "C" int splash_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char* splash_hip_last_error(void) { return g_err.c_str(); }
+
+static int need_device(char* err, size_t errlen)
+{
+    if (splash_hip_device_count() <= 0)
+        return fail(SPLASH_ENODEV, err, errlen,
+                    "no HIP device available: librsplash_hip has no CPU fallback");
+    return 0;
+}
+
+// ------------------------------------------------------------------ calendar
+// Orbit of one calendar day: the day-static part of SOLAR::calculate_daily_fluxes
+// (src/SOLAR.cpp:98-124 with berger_tls :291-350 and julian_day :352-374), evaluated on the host
+// with libm once per day instead of once per cell-day.
+namespace {
+
+const double PI_ = 3.141592653589793;
+const double PIR = PI_ / 180.0;
+const double K_E = 0.0167, K_EPS = 23.44, K_OMEGA = 283.0; // Berger (1978), src/global.cpp:80-82
+
+// kept out of line so sin/cos pairs are evaluated by sin() and cos(), like the reference
+__attribute__((noinline)) double sind(double x) { return std::sin(x * PIR); }
+__attribute__((noinline)) double cosd(double x) { return std::cos(x * PIR); }
+
+int julian_day(int y, int m, int i)
+{
+    if (m <= 2) {
+        y -= 1;
+        m += 12;
+    }
+    int a = y / 100;
+    int b = 2 - a + a / 4;
+    float jd = (int)(365.25 * (y + 4716)) + (int)(30.6001 * (m + 1)) + i + b - 1524.5; // float, :371
+    return (int)jd;
+}
+
+void orbit_day(int n, int y, double& dr, double& sd, double& cd)
+{
+    volatile double e = K_E; // keep libm calls at run time (the reference's constants are extern)
+    const int kN = (y == 0) ? 365 : julian_day(y + 1, 1, 1) - julian_day(y, 1, 1);
+    const double xee = std::pow(e, 2.0), xec = std::pow(e, 3.0);
+    const double xse = std::sqrt(1.0 - xee);
+    double xlam = (e / 2.0 + xec / 8.0) * (1.0 + xse) * sind(K_OMEGA);
+    xlam -= xee / 4.0 * (0.5 + xse) * sind(2.0 * K_OMEGA);
+    xlam += xec / 8.0 * (1.0 / 3.0 + xse) * sind(3.0 * K_OMEGA);
+    xlam *= 2.0;
+    xlam /= PIR;
+    const double dlamm = xlam + (n - 80.0) * (360.0 / kN);
+    const double ranm = (dlamm - K_OMEGA) * PIR;
+    double ranv = ranm;
+    ranv += (2.0 * e - xec / 4.0) * std::sin(ranm);
+    ranv += 5.0 / 4.0 * xee * std::sin(2.0 * ranm);
+    ranv += 13.0 / 12.0 * xec * std::sin(3.0 * ranm);
+    const double anv = ranv / PIR;
+    double tls = anv + K_OMEGA;
+    if (tls < 0) {
+        tls += 360.0;
+    } else if (tls > 360) {
+        tls -= 360.0;
+    }
+    double nu = tls - K_OMEGA;
+    if (nu < 0) nu += 360.0;
+    const double rho = (1.0 - xee) / (1.0 + cosd(nu) * e);
+    const double inv = 1.0 / rho; // pow(rho,-1.0)
+    dr = inv * inv;               // pow(dr, 2.0)
+    volatile double eps = K_EPS;
+    double delta = std::asin(sind(tls) * sind(eps)) / PIR;
+    sd = sind(delta);
+    cd = cosd(delta);
+}
+
+} // namespace
+
+struct splash_calendar {
+    int nt = 0, nmonth = 0, device = 0;
+    std::vector<DayRec> host;
+    DayRec* dev = nullptr;
+};
+
+extern "C" int splash_calendar_create(int nt, const int* doy, const int* year, const int* month,
+                                      splash_calendar** out, char* err, size_t errlen)
+{
+    if (!out || nt <= 0 || !doy || !year || !month)
+        return fail(SPLASH_EINVAL, err, errlen, "calendar: nt must be > 0 and doy/year/month given");
+    if (int rc = need_device(err, errlen)) return rc;
+    auto* cal = new splash_calendar;
+    cal->nt = nt;
+    cal->host.resize(nt);
+    int mid = 0;
+    for (int t = 0; t < nt; t++) {
+        if (month[t] < 1 || month[t] > 12 || doy[t] < 1 || doy[t] > 366) {
+            delete cal;
+            return fail(SPLASH_EINVAL, err, errlen, "calendar: bad doy/month at day %d", t);
+        }
+        if (t > 0 && (month[t] != month[t - 1] || year[t] != year[t - 1])) mid++;
+        DayRec& d = cal->host[t];
+        orbit_day(doy[t], year[t], d.dr, d.sd, d.cd);
+        const int m = month[t];
+        d.ttm_s = sind((m + 2) / 1.91);                      // R/splash.point.R:549
+        d.trm14 = 1.4 * (13.3 * (0.55 + sind(m + 4)) * 0.6); // :550, :553
+        d.month_id = mid;
+        d.doy = doy[t];
+        d.flags = 0;
+        d.mdays = 0;
+    }
+    cal->nmonth = mid + 1;
+    std::vector<int> cnt(cal->nmonth, 0);
+    for (int t = 0; t < nt; t++) cnt[cal->host[t].month_id]++;
+    for (int t = 0; t < nt; t++) {
+        DayRec& d = cal->host[t];
+        d.mdays = cnt[d.month_id];
+        if (t == nt - 1 || cal->host[t + 1].month_id != d.month_id) d.flags |= 1;
+    }
+    (void)hipGetDevice(&cal->device);
+    hipError_t e = hipMalloc((void**)&cal->dev, sizeof(DayRec) * (size_t)nt);
+    if (e == hipSuccess)
+        e = hipMemcpy(cal->dev, cal->host.data(), sizeof(DayRec) * (size_t)nt, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (cal->dev) (void)hipFree(cal->dev);
+        delete cal;
+        return fail(SPLASH_EHIP, err, errlen, "calendar upload: %s", hipGetErrorString(e));
+    }
+    *out = cal;
+    return SPLASH_OK;
+}
+
+extern "C" void splash_calendar_destroy(splash_calendar* cal)
+{
+    if (!cal) return;
+    if (cal->dev) (void)hipFree(cal->dev);
+    delete cal;
+}
+
+extern "C" int splash_calendar_nt(const splash_calendar* cal) { return cal ? cal->nt : 0; }
+extern "C" int splash_calendar_nmonth(const splash_calendar* cal) { return cal ? cal->nmonth : 0; }
+
+extern "C" int splash_calendar_orbit(const splash_calendar* cal, double* dr, double* sd, double* cd)
+{
+    if (!cal) return fail(SPLASH_EINVAL, nullptr, 0, "calendar is NULL");
+    for (int t = 0; t < cal->nt; t++) {
+        if (dr) dr[t] = cal->host[t].dr;
+        if (sd) sd[t] = cal->host[t].sd;
+        if (cd) cd[t] = cal->host[t].cd;
+    }
+    return SPLASH_OK;
+}
+
+// ------------------------------------------------------------------ device-resident stages
+#define REQ(cond, msg)                                                   \
+    do {                                                                 \
+        if (!(cond)) return fail(SPLASH_EINVAL, nullptr, 0, "%s", msg);  \
+    } while (0)
+
+extern "C" int splash_dev_soil_hydro(size_t ncell, const double* lat, const double* elev,
+                                     const double* slop, const double* asp,
+                                     const double* resolution, const double* soil, const double* au,
+                                     double* cellpar, void* stream)
+{
+    REQ(lat && elev && slop && asp && resolution && soil && cellpar, "soil_hydro: NULL argument");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    HIP_TRY(launch_soil_hydro(ncell, lat, elev, slop, asp, resolution, soil, au, cellpar,
+                              (hipStream_t)stream), nullptr, 0);
+    return SPLASH_OK;
+}
+
+extern "C" int splash_dev_snow_threshold(size_t ncell, int nt, const double* tc, size_t ldf,
+                                         const double* cellpar, size_t ldp, double* Tt, void* stream)
+{
+    REQ(tc && cellpar && Tt && nt > 0, "snow_threshold: NULL argument or nt <= 0");
+    REQ(ldf >= ncell && ldp >= ncell, "snow_threshold: leading dimension smaller than ncell");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    HIP_TRY(launch_snow_threshold(ncell, nt, tc, ldf, cellpar, ldp, Tt, (hipStream_t)stream),
+            nullptr, 0);
+    return SPLASH_OK;
+}
+
+// workspace of splash_dev_spin_up: two worklists, job records, aridity index, phase counters
+static size_t spin_work_layout(size_t ncell, size_t* o_wl_b, size_t* o_meta, size_t* o_ai,
+                               size_t* o_cnt)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    take(ncell * 4); // wl_a at 0
+    size_t wl_b = take(ncell * 4), meta = take(ncell * 4), ai = take(ncell * 8), cnt = take(64);
+    if (o_wl_b) *o_wl_b = wl_b;
+    if (o_meta) *o_meta = meta;
+    if (o_ai) *o_ai = ai;
+    if (o_cnt) *o_cnt = cnt;
+    return off;
+}
+
+extern "C" size_t splash_dev_spin_up_work_size(size_t ncell)
+{
+    return spin_work_layout(ncell, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, const double* sw_in,
+                                  const double* tc, const double* pn, size_t ldf, const double* Tt,
+                                  double* cellpar, size_t ldp, double* state, size_t lds,
+                                  int* passes, void* work, void* stream)
+{
+    REQ(cal && sw_in && tc && pn && Tt && cellpar && state && work, "spin_up: NULL argument");
+    REQ(cal->nt >= 365, "spin_up: needs at least 365 days (R/splash.point.R:141-144)");
+    REQ(ldf >= ncell && ldp >= ncell && lds >= ncell, "spin_up: leading dimension < ncell");
+    REQ(ncell < 0xFFFFFFFFull, "spin_up: more than 2^32-1 cells in one call");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    if (ncell == 0) return SPLASH_OK;
+    hipStream_t s = (hipStream_t)stream;
+    size_t o_wl_b, o_meta, o_ai, o_cnt;
+    spin_work_layout(ncell, &o_wl_b, &o_meta, &o_ai, &o_cnt);
+    char* w = (char*)work;
+    uint32_t* wl[2] = {(uint32_t*)w, (uint32_t*)(w + o_wl_b)};
+    uint32_t* cnt = (uint32_t*)(w + o_cnt);
+    HIP_TRY(hipMemsetAsync(cnt, 0, 64, s), nullptr, 0);
+    SpinPhaseArgs a{};
+    a.days = cal->dev;
+    a.n = 365;
+    a.ncell = ncell;
+    a.sw = sw_in;
+    a.tc = tc;
+    a.pn = pn;
+    a.ldf = ldf;
+    a.Tt = Tt;
+    a.par = cellpar;
+    a.ldp = ldp;
+    a.state = state;
+    a.lds = lds;
+    a.passes = passes;
+    a.meta = (int*)(w + o_meta);
+    a.ai = (double*)(w + o_ai);
+    // pass budgets per phase; the last one covers the 2 x 1000-pass worst case (src/SPLASH.cpp:1697)
+    static const int budget[] = {8, 16, 64, 2100};
+    for (int ph = 0; ph < 4; ph++) {
+        a.fresh = (ph == 0);
+        a.budget = budget[ph];
+        a.wl_in = ph == 0 ? nullptr : wl[(ph - 1) & 1];
+        a.n_in = ph == 0 ? nullptr : cnt + (ph - 1);
+        a.wl_out = wl[ph & 1];
+        a.n_out = cnt + ph;
+        HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+    }
+    return SPLASH_OK;
+}
+
+extern "C" size_t splash_dev_diag_work_size(size_t ncell, int nmonth)
+{
+    return run_all_blocks(ncell) * (size_t)std::max(nmonth, 0) * SPLASH_NDIAG_K * sizeof(double);
+}
+
+extern "C" int splash_dev_run_all(const splash_calendar* cal, int t0, int nt, size_t ncell,
+                                  const double* sw_in, const double* tc, const double* pn,
+                                  size_t ldf, const double* Tt, const double* cellpar, size_t ldp,
+                                  double* state, size_t lds, const splash_dev_out* out, void* stream)
+{
+    REQ(cal && sw_in && tc && pn && Tt && cellpar && state && out, "run_all: NULL argument");
+    REQ(t0 >= 0 && nt >= 0 && t0 + nt <= cal->nt, "run_all: day range outside the calendar");
+    REQ(ldf >= ncell && ldp >= ncell && lds >= ncell && out->ldo >= ncell,
+        "run_all: leading dimension < ncell");
+    REQ(!out->diag || out->diag_work, "run_all: diag requested without diag_work");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    if (nt == 0 || ncell == 0) return SPLASH_OK;
+    RunArgs a{};
+    a.days = cal->dev + t0;
+    a.nt = nt;
+    a.ncell = ncell;
+    a.sw = sw_in;
+    a.tc = tc;
+    a.pn = pn;
+    a.snowfall = nullptr;
+    a.ldf = ldf;
+    a.Tt = Tt;
+    a.par = cellpar;
+    a.ldp = ldp;
+    a.state = state;
+    a.lds = lds;
+    for (int k = 0; k < SPLASH_NOUT; k++) a.out[k] = out->out[k];
+    a.ldo = out->ldo;
+    a.monthly = out->monthly;
+    a.month0 = cal->host[t0].month_id;
+    a.head_partial = (t0 > 0 && cal->host[t0 - 1].month_id == a.month0) ? 1 : 0;
+    a.nmonth = cal->host[t0 + nt - 1].month_id - a.month0 + 1;
+    a.diag_part = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (out->diag) {
+        a.diag_part = out->diag_work;
+        HIP_TRY(hipMemsetAsync(out->diag_work, 0, splash_dev_diag_work_size(ncell, a.nmonth), s),
+                nullptr, 0);
+    }
+    HIP_TRY(launch_run_all(a, s), nullptr, 0);
+    if (out->diag)
+        HIP_TRY(launch_diag_reduce(a.diag_part, run_all_blocks(ncell), a.nmonth, out->diag, s),
+                nullptr, 0);
+    return SPLASH_OK;
+}
+
+extern "C" int splash_dev_synth_statics(uint64_t seed, int H, int W, int64_t cell0, size_t ncell,
+                                        int terrain, double* lat, double* elev, double* slop,
+                                        double* asp, double* resolution, double* soil, double* au,
+                                        void* stream)
+{
+    REQ(lat && elev && slop && asp && resolution && soil && au && H > 0 && W > 0,
+        "synth_statics: NULL argument");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    HIP_TRY(launch_synth_statics(seed, H, W, cell0, ncell, terrain, lat, elev, slop, asp,
+                                 resolution, soil, au, (hipStream_t)stream), nullptr, 0);
+    return SPLASH_OK;
+}
+
+extern "C" int splash_dev_synth_forcing(uint64_t seed, const splash_calendar* cal, int t0, int nt,
+                                        int64_t cell0, size_t ncell, const double* lat,
+                                        const double* elev, double* sw_in, double* tc, double* pn,
+                                        size_t ldf, void* stream)
+{
+    REQ(cal && lat && elev && sw_in && tc && pn, "synth_forcing: NULL argument");
+    REQ(t0 >= 0 && nt >= 0 && t0 + nt <= cal->nt, "synth_forcing: day range outside the calendar");
+    REQ(ldf >= ncell, "synth_forcing: leading dimension < ncell");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    HIP_TRY(launch_synth_forcing(seed, cal->dev + t0, t0, nt, cell0, ncell, lat, elev, sw_in, tc,
+                                 pn, ldf, (hipStream_t)stream), nullptr, 0);
+    return SPLASH_OK;
+}
+
+// ------------------------------------------------------------------ small RAII helpers
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T>
+    T* as() const
+    {
+        return (T*)p;
+    }
+};
+
+inline bool isnan_d(double x) { return x != x; }
+
+} // namespace
+
+// test hook: SOLAR+EVAP rows (host pointers)
+extern "C" int splash_dev_evap_batch(size_t m, const double* lat, const double* elv,
+                                     const double* sw, const int* n, const int* y,
+                                     const double* sw_in, const double* tc, const double* slop,
+                                     const double* asp, const double* snow, const double* nd,
+                                     double* out, void* stream)
+{
+    (void)stream;
+    REQ(lat && elv && sw && n && y && sw_in && tc && slop && asp && snow && nd && out,
+        "evap_batch: NULL argument");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    if (m == 0) return SPLASH_OK;
+    std::vector<double> orb(3 * m);
+    for (size_t i = 0; i < m; i++) orbit_day(n[i], y[i], orb[i], orb[m + i], orb[2 * m + i]);
+    const double* hin[9] = {lat, elv, sw, sw_in, tc, slop, asp, snow, nd};
+    DevBuf buf[9], dorb, dout;
+    for (int k = 0; k < 9; k++) {
+        HIP_TRY(buf[k].alloc(m * 8), nullptr, 0);
+        HIP_TRY(hipMemcpy(buf[k].p, hin[k], m * 8, hipMemcpyHostToDevice), nullptr, 0);
+    }
+    HIP_TRY(dorb.alloc(3 * m * 8), nullptr, 0);
+    HIP_TRY(hipMemcpy(dorb.p, orb.data(), 3 * m * 8, hipMemcpyHostToDevice), nullptr, 0);
+    HIP_TRY(dout.alloc(11 * m * 8), nullptr, 0);
+    const double* o = dorb.as<double>();
+    HIP_TRY(launch_evap_batch(m, buf[0].as<double>(), buf[1].as<double>(), buf[2].as<double>(), o,
+                              o + m, o + 2 * m, buf[3].as<double>(), buf[4].as<double>(),
+                              buf[5].as<double>(), buf[6].as<double>(), buf[7].as<double>(),
+                              buf[8].as<double>(), dout.as<double>(), nullptr), nullptr, 0);
+    HIP_TRY(hipMemcpy(out, dout.p, 11 * m * 8, hipMemcpyDeviceToHost), nullptr, 0);
+    return SPLASH_OK;
+}
+
+// ------------------------------------------------------------------ splash.grid / splash.point
+extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
+                               const splash_grid_out* out, char* err, size_t errlen)
+{
+    if (!in || !out) return fail(SPLASH_EINVAL, err, errlen, "grid_run: NULL in/out");
+    if (!in->doy || !in->year || !in->month || !in->sw_in || !in->tc || !in->pn || !in->lat ||
+        !in->elev || !in->slop || !in->asp || !in->resolution || !in->soil)
+        return fail(SPLASH_EINVAL, err, errlen, "grid_run: NULL input array");
+    if (in->nt < 365)
+        return fail(SPLASH_EINVAL, err, errlen,
+                    "grid_run: %d days given, the spin-up needs the first 365 "
+                    "(R/splash.point.R:141-144)", in->nt);
+    if (int rc = need_device(err, errlen)) return rc;
+    const int device = opt ? opt->device : 0;
+    const int monthly = opt ? opt->monthly_out : 0;
+    HIP_TRY(hipSetDevice(device), err, errlen);
+
+    const size_t N = in->ncell;
+    const int nt = in->nt;
+    splash_calendar* cal = nullptr;
+    if (int rc = splash_calendar_create(nt, in->doy, in->year, in->month, &cal, err, errlen)) return rc;
+    struct CalGuard {
+        splash_calendar* c;
+        ~CalGuard() { splash_calendar_destroy(c); }
+    } cg{cal};
+    const int nmonth = cal->nmonth;
+    const int nt_out = monthly ? nmonth : nt;
+    const double NaN = std::numeric_limits<double>::quiet_NaN();
+
+    // NA cells (R: every comparison false, all outputs NA): mask them out, emit NaN
+    std::vector<size_t> idx;
+    idx.reserve(N);
+    for (size_t c = 0; c < N; c++) {
+        bool bad = isnan_d(in->lat[c]) || isnan_d(in->elev[c]) || isnan_d(in->slop[c]) ||
+                   isnan_d(in->asp[c]) || isnan_d(in->resolution[c]) || isnan_d(in->sw_in[c]) ||
+                   isnan_d(in->tc[c]) || isnan_d(in->pn[c]);
+        for (int k = 0; k < 6 && !bad; k++)
+            if (k != 4 && isnan_d(in->soil[(size_t)k * N + c])) bad = true; // bd NA is legal
+        if (in->au)
+            for (int k = 0; k < 3 && !bad; k++)
+                if (isnan_d(in->au[(size_t)k * N + c])) bad = true;
+        if (!bad) idx.push_back(c);
+    }
+    const size_t nv = idx.size();
+    const bool dense = (nv == N);
+    if (!dense) {
+        for (int k = 0; k < SPLASH_NOUT; k++)
+            if (out->out[k]) std::fill(out->out[k], out->out[k] + (size_t)nt_out * N, NaN);
+        if (out->state_end) std::fill(out->state_end, out->state_end + 5 * N, NaN);
+        if (out->aux) std::fill(out->aux, out->aux + 4 * N, NaN);
+    }
+    if (out->diag) std::fill(out->diag, out->diag + (size_t)nmonth * SPLASH_NDIAG, 0.0);
+    if (nv == 0) return SPLASH_OK;
+
+    int n_out = 0;
+    for (int k = 0; k < SPLASH_NOUT; k++) n_out += out->out[k] ? 1 : 0;
+
+    // cells per launch from free HBM
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b), err, errlen);
+    const size_t per_cell = (size_t)nt * 3 * 8 + (size_t)nt_out * n_out * 8 +
+                            (SPLASH_NPAR + SPLASH_NSTATE + 6 + 5 + 3 + 1 + 4 + 4) * 8 + 64;
+    size_t nb_max = (size_t)((double)free_b * 0.85) / per_cell;
+    if (opt && opt->max_cells_per_launch) nb_max = std::min(nb_max, opt->max_cells_per_launch);
+    if (nb_max == 0) return fail(SPLASH_ENOMEM, err, errlen, "grid_run: not enough device memory");
+    nb_max = std::min(nb_max, nv);
+    if (nb_max > 256) nb_max -= nb_max % 256;
+
+    DevBuf d_force, d_out, d_par, d_state, d_stat, d_tt, d_pass, d_diag, d_dwork, d_swork;
+    HIP_TRY(d_force.alloc((size_t)nt * 3 * nb_max * 8), err, errlen);
+    HIP_TRY(d_out.alloc((size_t)nt_out * std::max(n_out, 1) * nb_max * 8), err, errlen);
+    HIP_TRY(d_par.alloc((size_t)SPLASH_NPAR * nb_max * 8), err, errlen);
+    HIP_TRY(d_state.alloc((size_t)SPLASH_NSTATE * nb_max * 8), err, errlen);
+    HIP_TRY(d_stat.alloc((size_t)(5 + 6 + 3) * nb_max * 8), err, errlen);
+    HIP_TRY(d_tt.alloc(nb_max * 8), err, errlen);
+    HIP_TRY(d_pass.alloc(2 * nb_max * sizeof(int)), err, errlen);
+    HIP_TRY(d_swork.alloc(splash_dev_spin_up_work_size(nb_max)), err, errlen);
+    if (out->diag) {
+        HIP_TRY(d_diag.alloc((size_t)nmonth * SPLASH_NDIAG * 8), err, errlen);
+        HIP_TRY(hipMemset(d_diag.p, 0, (size_t)nmonth * SPLASH_NDIAG * 8), err, errlen);
+        HIP_TRY(d_dwork.alloc(splash_dev_diag_work_size(nb_max, nmonth)), err, errlen);
+    }
+    std::vector<double> stage; // host gather/scatter buffer for masked grids
+    std::vector<double> hstat((size_t)(5 + 6 + 3) * nb_max), hsmall(5 * nb_max);
+    std::vector<int> hpass(2 * nb_max);
+    if (!dense) stage.resize((size_t)std::max(nt, nt_out) * nb_max);
+
+    hipStream_t s = nullptr;
+    for (size_t b0 = 0; b0 < nv; b0 += nb_max) {
+        const size_t nb = std::min(nb_max, nv - b0);
+        double* F = d_force.as<double>();
+        double* dsw = F;
+        double* dtc = F + (size_t)nt * nb;
+        double* dpn = F + (size_t)2 * nt * nb;
+        const double* hsrc[3] = {in->sw_in, in->tc, in->pn};
+        double* ddst[3] = {dsw, dtc, dpn};
+        for (int v = 0; v < 3; v++) {
+            if (dense) {
+                HIP_TRY(hipMemcpy2D(ddst[v], nb * 8, hsrc[v] + b0, N * 8, nb * 8, (size_t)nt,
+                                    hipMemcpyHostToDevice), err, errlen);
+            } else {
+                for (int t = 0; t < nt; t++)
+                    for (size_t j = 0; j < nb; j++)
+                        stage[(size_t)t * nb + j] = hsrc[v][(size_t)t * N + idx[b0 + j]];
+                HIP_TRY(hipMemcpy(ddst[v], stage.data(), (size_t)nt * nb * 8, hipMemcpyHostToDevice),
+                        err, errlen);
+            }
+        }
+        // statics: lat, elev, slop, asp, resolution, soil[6], au[3]
+        const double* st1[5] = {in->lat, in->elev, in->slop, in->asp, in->resolution};
+        for (int k = 0; k < 5; k++)
+            for (size_t j = 0; j < nb; j++) hstat[(size_t)k * nb + j] = st1[k][idx[b0 + j]];
+        for (int k = 0; k < 6; k++)
+            for (size_t j = 0; j < nb; j++)
+                hstat[(size_t)(5 + k) * nb + j] = in->soil[(size_t)k * N + idx[b0 + j]];
+        if (in->au)
+            for (int k = 0; k < 3; k++)
+                for (size_t j = 0; j < nb; j++)
+                    hstat[(size_t)(11 + k) * nb + j] = in->au[(size_t)k * N + idx[b0 + j]];
+        double* S = d_stat.as<double>();
+        HIP_TRY(hipMemcpy(S, hstat.data(), (size_t)14 * nb * 8, hipMemcpyHostToDevice), err, errlen);
+
+        double* par = d_par.as<double>();
+        double* state = d_state.as<double>();
+        double* Tt = d_tt.as<double>();
+        int rc;
+        rc = splash_dev_soil_hydro(nb, S, S + nb, S + 2 * nb, S + 3 * nb, S + 4 * nb, S + 5 * nb,
+                                   in->au ? S + 11 * nb : nullptr, par, s);
+        if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
+        rc = splash_dev_snow_threshold(nb, nt, dtc, nb, par, nb, Tt, s);
+        if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
+        rc = splash_dev_spin_up(cal, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb,
+                                d_pass.as<int>(), d_swork.p, s);
+        if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
+        splash_dev_out dout{};
+        int q = 0;
+        for (int k = 0; k < SPLASH_NOUT; k++)
+            dout.out[k] = out->out[k] ? d_out.as<double>() + (size_t)(q++) * nt_out * nb : nullptr;
+        dout.ldo = nb;
+        dout.monthly = monthly;
+        dout.diag = out->diag ? d_diag.as<double>() : nullptr;
+        dout.diag_work = out->diag ? d_dwork.as<double>() : nullptr;
+        rc = splash_dev_run_all(cal, 0, nt, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, &dout, s);
+        if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
+        HIP_TRY(hipStreamSynchronize(s), err, errlen);
+
+        for (int k = 0; k < SPLASH_NOUT; k++) {
+            if (!out->out[k]) continue;
+            if (dense) {
+                HIP_TRY(hipMemcpy2D(out->out[k] + b0, N * 8, dout.out[k], nb * 8, nb * 8,
+                                    (size_t)nt_out, hipMemcpyDeviceToHost), err, errlen);
+            } else {
+                HIP_TRY(hipMemcpy(stage.data(), dout.out[k], (size_t)nt_out * nb * 8,
+                                  hipMemcpyDeviceToHost), err, errlen);
+                for (int t = 0; t < nt_out; t++)
+                    for (size_t j = 0; j < nb; j++)
+                        out->out[k][(size_t)t * N + idx[b0 + j]] = stage[(size_t)t * nb + j];
+            }
+        }
+        if (out->state_end) {
+            HIP_TRY(hipMemcpy(hsmall.data(), state, 5 * nb * 8, hipMemcpyDeviceToHost), err, errlen);
+            for (int k = 0; k < 5; k++)
+                for (size_t j = 0; j < nb; j++)
+                    out->state_end[(size_t)k * N + idx[b0 + j]] = hsmall[(size_t)k * nb + j];
+        }
+        if (out->aux) {
+            HIP_TRY(hipMemcpy(hsmall.data(), Tt, nb * 8, hipMemcpyDeviceToHost), err, errlen);
+            HIP_TRY(hipMemcpy(hsmall.data() + nb, par + (size_t)15 * nb, nb * 8,
+                              hipMemcpyDeviceToHost), err, errlen);
+            HIP_TRY(hipMemcpy(hpass.data(), d_pass.p, 2 * nb * sizeof(int), hipMemcpyDeviceToHost),
+                    err, errlen);
+            for (size_t j = 0; j < nb; j++) {
+                out->aux[idx[b0 + j]] = hsmall[j];
+                out->aux[N + idx[b0 + j]] = hsmall[nb + j];
+                out->aux[2 * N + idx[b0 + j]] = hpass[j];
+                out->aux[3 * N + idx[b0 + j]] = hpass[nb + j];
+            }
+        }
+    }
+    if (out->diag)
+        HIP_TRY(hipMemcpy(out->diag, d_diag.p, (size_t)nmonth * SPLASH_NDIAG * 8,
+                          hipMemcpyDeviceToHost), err, errlen);
+    return SPLASH_OK;
+}
+
+extern "C" int splash_point_run(int nt, const int* doy, const int* year, const int* month,
+                                const double* sw_in, const double* tc, const double* pn, double lat,
+                                double elev, double slop, double asp, const double* soil_data,
+                                const double* au, int n_au, double resolution, int monthly_out,
+                                double* const outp[SPLASH_NOUT], char* err, size_t errlen)
+{
+    if (!soil_data || !outp) return fail(SPLASH_EINVAL, err, errlen, "point_run: NULL argument");
+    if (n_au != 0 && n_au != 1 && n_au != 3)
+        return fail(SPLASH_EINVAL, err, errlen, "point_run: Au must have 1 or 3 values");
+    // length(Au)==1 => ncellin = ncellout = 3 (R/splash.point.R:106-110)
+    double au3[3] = {0.0, 3.0, 3.0};
+    if (au && n_au >= 1) au3[0] = au[0];
+    if (au && n_au == 3) {
+        au3[1] = au[1];
+        au3[2] = au[2];
+    }
+    splash_grid_in in{};
+    in.ncell = 1;
+    in.nt = nt;
+    in.doy = doy;
+    in.year = year;
+    in.month = month;
+    in.sw_in = sw_in;
+    in.tc = tc;
+    in.pn = pn;
+    in.lat = &lat;
+    in.elev = &elev;
+    in.slop = &slop;
+    in.asp = &asp;
+    in.resolution = &resolution;
+    in.soil = soil_data;
+    in.au = au3;
+    splash_opts opt{};
+    opt.monthly_out = monthly_out;
+    splash_grid_out o{};
+    for (int k = 0; k < SPLASH_NOUT; k++) o.out[k] = outp[k];
+    return splash_grid_run(&in, &opt, &o, err, errlen);
+}
+
+// ------------------------------------------------------------------ Rcpp-module mirrors
+namespace {
+
+// cellpar of one cell from the module's arguments (soil_info as R/splash.point.R:110-114 builds it;
+// asp arrives already shifted by -180, R/splash.point.R:131)
+void par_from_soil_info(double lat, double elv, double slop, double asp, const double* si,
+                        double* par)
+{
+    par[P_LAT] = lat;
+    par[P_ELV] = elv;
+    par[P_SLOP] = slop;
+    par[P_ASP] = asp;
+    for (int k = 0; k < 12; k++) par[P_SAT + k] = si[k];
+    par[P_WMAXR] = std::numeric_limits<double>::quiet_NaN(); // sm_lim is not a module output
+}
+
+struct Upload {
+    DevBuf b;
+    int put(const void* h, size_t bytes)
+    {
+        if (b.alloc(bytes) != hipSuccess) return SPLASH_ENOMEM;
+        if (hipMemcpy(b.p, h, bytes, hipMemcpyHostToDevice) != hipSuccess) return SPLASH_EHIP;
+        return 0;
+    }
+};
+
+} // namespace
+
+// SPLASH::spin_up (src/SPLASH.cpp:1594-1749; R call at R/splash.point.R:148,152)
+extern "C" int splash_mod_spin_up(double lat, double elv, int n, int y, const double* sw_in,
+                                  const double* tair, const double* pn, double slop, double asp,
+                                  const double* snowfall, const double* soil_info, double* sm,
+                                  double* snow, double* qin, double* tdrain, double* ro,
+                                  double* snwage, double* pet, int* passes)
+{
+    REQ(n > 0 && sw_in && tair && pn && snowfall && soil_info, "mod_spin_up: bad argument");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    std::vector<DayRec> days(n);
+    for (int i = 0; i < n; i++) {
+        DayRec& d = days[i];
+        orbit_day(i + 1, y, d.dr, d.sd, d.cd); // quick_run((i+1), y, ...) :1658
+        d.ttm_s = 0.0;
+        d.trm14 = 1.0;
+        d.month_id = 0;
+        d.mdays = n;
+        d.flags = (i == n - 1);
+        d.doy = i + 1;
+    }
+    double par[SPLASH_NPAR];
+    par_from_soil_info(lat, elv, slop, asp, soil_info, par);
+    Upload ud, up, usw, utc, upn, usf;
+    int rc = 0;
+    if ((rc = ud.put(days.data(), sizeof(DayRec) * n)) || (rc = up.put(par, sizeof par)) ||
+        (rc = usw.put(sw_in, 8 * (size_t)n)) || (rc = utc.put(tair, 8 * (size_t)n)) ||
+        (rc = upn.put(pn, 8 * (size_t)n)) || (rc = usf.put(snowfall, 8 * (size_t)n)))
+        return fail(rc, nullptr, 0, "mod_spin_up: upload failed");
+    DevBuf dser, dptr, dstate, dpass;
+    HIP_TRY(dser.alloc(7 * 8 * (size_t)n), nullptr, 0);
+    HIP_TRY(hipMemset(dser.p, 0, 7 * 8 * (size_t)n), nullptr, 0);
+    double* hptr[7];
+    for (int k = 0; k < 7; k++) hptr[k] = dser.as<double>() + (size_t)k * n;
+    HIP_TRY(dptr.alloc(sizeof hptr), nullptr, 0);
+    HIP_TRY(hipMemcpy(dptr.p, hptr, sizeof hptr, hipMemcpyHostToDevice), nullptr, 0);
+    HIP_TRY(dstate.alloc(5 * 8), nullptr, 0);
+    HIP_TRY(dpass.alloc(2 * sizeof(int)), nullptr, 0);
+    SpinArgs a{};
+    a.days = ud.b.as<DayRec>();
+    a.n = n;
+    a.ncell = 1;
+    a.sw = usw.b.as<double>();
+    a.tc = utc.b.as<double>();
+    a.pn = upn.b.as<double>();
+    a.ldf = 1;
+    a.Tt = nullptr;
+    a.par = up.b.as<double>();
+    a.ldp = 1;
+    a.state = dstate.as<double>();
+    a.lds = 1;
+    a.passes = dpass.as<int>();
+    HIP_TRY(launch_spin_up_mod(a, dptr.as<double*>(), 1, usf.b.as<double>(), nullptr), nullptr, 0);
+    HIP_TRY(hipDeviceSynchronize(), nullptr, 0);
+    double* dst[7] = {sm, snow, qin, tdrain, ro, snwage, pet}; // names of :1748
+    for (int k = 0; k < 7; k++)
+        if (dst[k])
+            HIP_TRY(hipMemcpy(dst[k], hptr[k], 8 * (size_t)n, hipMemcpyDeviceToHost), nullptr, 0);
+    if (passes) HIP_TRY(hipMemcpy(passes, dpass.p, sizeof(int), hipMemcpyDeviceToHost), nullptr, 0);
+    return SPLASH_OK;
+}
+
+// SPLASH::run_all (src/SPLASH.cpp:1833-1916; R call at R/splash.point.R:158-172)
+extern "C" int splash_mod_run_all(double lat, double elv, int nt, const int* doys, const int* yrs,
+                                  const double* sw_in, const double* tair, const double* pn,
+                                  double wn_last, double slop, double asp, double snow_last,
+                                  const double* snowfall, const double* soil_info, double qin_last,
+                                  double td_last, double nds_last, double* wn, double* ro,
+                                  double* pet, double* aet, double* snow, double* cond,
+                                  double* bflow, double* netr, double* qin_prev, double* tdrain,
+                                  double* snwage)
+{
+    REQ(nt > 0 && doys && yrs && sw_in && tair && pn && snowfall && soil_info,
+        "mod_run_all: bad argument");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    std::vector<DayRec> days(nt);
+    for (int i = 0; i < nt; i++) {
+        DayRec& d = days[i];
+        orbit_day(doys[i], yrs[i], d.dr, d.sd, d.cd);
+        d.ttm_s = 0.0;
+        d.trm14 = 1.0;
+        d.month_id = 0;
+        d.mdays = nt;
+        d.flags = (i == nt - 1);
+        d.doy = doys[i];
+    }
+    double par[SPLASH_NPAR];
+    par_from_soil_info(lat, elv, slop, asp, soil_info, par);
+    const double st0[5] = {wn_last, snow_last, qin_last, td_last, nds_last};
+    Upload ud, up, usw, utc, upn, usf, ust;
+    int rc = 0;
+    if ((rc = ud.put(days.data(), sizeof(DayRec) * nt)) || (rc = up.put(par, sizeof par)) ||
+        (rc = usw.put(sw_in, 8 * (size_t)nt)) || (rc = utc.put(tair, 8 * (size_t)nt)) ||
+        (rc = upn.put(pn, 8 * (size_t)nt)) || (rc = usf.put(snowfall, 8 * (size_t)nt)) ||
+        (rc = ust.put(st0, sizeof st0)))
+        return fail(rc, nullptr, 0, "mod_run_all: upload failed");
+    DevBuf dser;
+    HIP_TRY(dser.alloc(11 * 8 * (size_t)nt), nullptr, 0);
+    RunArgs a{};
+    a.days = ud.b.as<DayRec>();
+    a.nt = nt;
+    a.ncell = 1;
+    a.sw = usw.b.as<double>();
+    a.tc = utc.b.as<double>();
+    a.pn = upn.b.as<double>();
+    a.snowfall = usf.b.as<double>();
+    a.ldf = 1;
+    a.Tt = nullptr;
+    a.par = up.b.as<double>();
+    a.ldp = 1;
+    a.state = ust.b.as<double>();
+    a.lds = 1;
+    for (int k = 0; k < 8; k++) a.out[k] = dser.as<double>() + (size_t)k * nt;
+    a.out[8] = nullptr;
+    for (int k = 0; k < 3; k++) a.extra[k] = dser.as<double>() + (size_t)(8 + k) * nt;
+    a.ldo = 1;
+    HIP_TRY(launch_run_all_mod(a, nullptr), nullptr, 0);
+    HIP_TRY(hipDeviceSynchronize(), nullptr, 0);
+    double* dst[11] = {wn, ro, pet, aet, snow, cond, bflow, netr, qin_prev, tdrain, snwage};
+    for (int k = 0; k < 11; k++)
+        if (dst[k])
+            HIP_TRY(hipMemcpy(dst[k], dser.as<double>() + (size_t)k * nt, 8 * (size_t)nt,
+                              hipMemcpyDeviceToHost), nullptr, 0);
+    return SPLASH_OK;
+}
+
+extern "C" int splash_mod_moist_surf(double depth, double z, double bub_p, double wn, double SAT,
+                                     double RES, double lambda, double* theta)
+{
+    REQ(theta, "mod_moist_surf: NULL result");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    DevBuf d;
+    HIP_TRY(d.alloc(8), nullptr, 0);
+    HIP_TRY(launch_moist_surf(depth, z, bub_p, wn, SAT, RES, lambda, d.as<double>(), nullptr),
+            nullptr, 0);
+    HIP_TRY(hipMemcpy(theta, d.p, 8, hipMemcpyDeviceToHost), nullptr, 0);
+    return SPLASH_OK;
+}
+
+extern "C" int splash_mod_inf_GA(double bub_press, double theta_i, double Ksat, double theta_s,
+                                 double lambda, double P, double tdur, double slop,
+                                 double* infiltration)
+{
+    REQ(infiltration, "mod_inf_GA: NULL result");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    DevBuf d;
+    HIP_TRY(d.alloc(8), nullptr, 0);
+    HIP_TRY(launch_inf_GA(bub_press, theta_i, Ksat, theta_s, lambda, P, tdur, slop, d.as<double>(),
+                          nullptr), nullptr, 0);
+    HIP_TRY(hipMemcpy(infiltration, d.p, 8, hipMemcpyDeviceToHost), nullptr, 0);
+    return SPLASH_OK;
+}

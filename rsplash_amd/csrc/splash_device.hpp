@@ -1,0 +1,774 @@
+// splash_device.hpp -- per-cell per-day SPLASH v2.0 flux integrator as gfx950 device functions.
+//
+// One wavefront lane owns one grid cell and carries its five state scalars (wn, snow, qin, td, nd)
+// in registers through the day loop.  Everything that depends only on the cell (soil hydraulics,
+// terrain trigonometry, pressure, ...) is computed once per kernel in cell_setup(); everything that
+// depends only on the calendar day (orbit) comes from a per-day table read with scalar loads.
+//
+// Reference being replaced (file:line relative to the rsplash tree):
+//   SOLAR::calculate_daily_fluxes  src/SOLAR.cpp:77-267
+//   EVAP::calculate_daily_fluxes   src/EVAP.cpp:82-264   (+ water properties :291-515)
+//   SPLASH::run_one_day/quick_run  src/SPLASH.cpp:920-1588 / 150-918
+//   SPLASH::moist_surf / inf_GA    src/SPLASH.cpp:1921-1961 / 1963-2023
+//   soil_hydro, snowfall split     R/splash.point.R:232-416, 120-128, 521-578
+//
+// Numerics: FP64 throughout, except water viscosity which the reference computes in `float`
+// (src/EVAP.cpp:405-462); that routine is emulated operation by operation (contraction off,
+// glibc's expf algorithm) because Dunne runoff amplifies a 1-ulp(float) viscosity change to ~1e-5.
+// NaN-as-control-flow and std::max/min argument-order semantics of the reference are kept.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "splash_kernels.hpp"
+
+namespace splash {
+
+// ---- src/global.cpp:49-83 ------------------------------------------------------------------
+constexpr double kA = 91.86328;
+constexpr double kAlbSw = 0.30;
+constexpr double kB = 0.2012435;
+constexpr double kC = 0.25;
+constexpr double kD = 0.50;
+constexpr double kKfus = 334000.0;
+constexpr double kG = 9.80665;
+constexpr double kGsc = 1360.8;
+constexpr double kL = 0.0065;
+constexpr double kMa = 0.028963;
+constexpr double kMv = 0.01802;
+constexpr double kPo = 101325.0;
+constexpr double kR = 8.31447;
+constexpr double kTo = 288.15;
+constexpr double kPI = 3.141592653589793;
+constexpr double kPir = kPI / 180.0;
+constexpr double kFluidity = 35187037.0;
+
+// std::max / std::min as the reference uses them: max(a,b) = (a<b)?b:a, min(a,b) = (b<a)?b:a
+#define SPL_MAX(a, b) (((a) < (b)) ? (b) : (a))
+#define SPL_MIN(a, b) (((b) < (a)) ? (b) : (a))
+
+struct State {
+    double wn, snow, qin, td, nd;
+};
+
+struct DayConst { // per-calendar-day terms (host table): orbit, src/SOLAR.cpp:98-124, and the
+                  // month-dependent factors of frain_func, R/splash.point.R:549-550
+    double dr, sd, cd;  // distance factor, sin(delta), cos(delta)
+    double ttm_s;       // dsin((m+2)/1.91)
+    double trm14;       // 1.4 * (13.3*(0.55+dsin(m+4))*0.6)
+};
+
+struct DayOut {
+    double ro, pet, aet, cond, bflow, netr;
+};
+
+// Cell-static terms hoisted out of the day loop (the reference recomputes all of them per day).
+struct CellConst {
+    // SOLAR (src/SOLAR.cpp:129-131, 170)
+    double ka, kb, kc;      // a = sd*ka, b = cd*kb, c = cd*kc
+    double tau_o;
+    // EVAP (src/EVAP.cpp:110)
+    double patm;
+    float patm_f;
+    // SPLASH soil column
+    double SAT, RES, Au, Ai;
+    double d1000;           // depth*1000
+    double depth;
+    double theta_s, theta_r, dtheta; // dtheta = theta_s - theta_r
+    double inv_lambda, e3l1;        // 1/lambda, 3*lambda+1
+    double lambda;
+    double bub;
+    double Wmax, wm_th;     // src/SPLASH.cpp:1029 and Wmax/(depth*1000)
+    double int_perm;        // Ksat/fluidity
+    double tan_slop, inv_cos2; // tan(slop), 1/cos^2(slop)
+    double h_f;             // Green-Ampt wetting-front suction (src/SPLASH.cpp:1987)
+    double kun_exp;         // 3 + 2/lambda
+    double so_cellout;      // sid_oct*cellout
+    double tu_fac;          // (24*cellout*sid_oct)/(1000*Ai)
+    double tu_coef;         // bub/(3*lambda+1)
+    double kb_coef;         // log(Kb) = Ksat_visc*kb_coef   (src/SPLASH.cpp:1291-1326)
+    double qt_coef;         // Qt = Ksat_visc*qt_coef*hyd_grad_out (src/SPLASH.cpp:1333-1360)
+    bool deep;              // depth >= 2.0
+};
+
+// ---- small helpers -------------------------------------------------------------------------
+__device__ __forceinline__ double dsin_deg(double x) { return sin(x * kPir); }
+
+// src/EVAP.cpp:338-389 (Chen et al. 1977).  Contraction is off so that the value later rounded
+// to float inside the viscosity routine is the same double the reference rounds.
+__device__ __forceinline__ double density_h2o(double tc, double p)
+{
+#pragma clang fp contract(off)
+    // products are evaluated left to right exactly as written in the reference
+    // (c*tc*tc*... == (((c*tc)*tc)*...)), not as c*(tc^k)
+    double po = 0.99983952;
+    po += (6.788260e-5) * tc;
+    po += -(9.08659e-6) * tc * tc;
+    po += (1.022130e-7) * tc * tc * tc;
+    po += -(1.35439e-9) * tc * tc * tc * tc;
+    po += (1.471150e-11) * tc * tc * tc * tc * tc;
+    po += -(1.11663e-13) * tc * tc * tc * tc * tc * tc;
+    po += (5.044070e-16) * tc * tc * tc * tc * tc * tc * tc;
+    po += -(1.00659e-18) * tc * tc * tc * tc * tc * tc * tc * tc;
+
+    double ko = 19652.17;
+    ko += 148.1830 * tc;
+    ko += -2.29995 * tc * tc;
+    ko += 0.01281 * tc * tc * tc;
+    ko += -(4.91564e-5) * tc * tc * tc * tc;
+    ko += (1.035530e-7) * tc * tc * tc * tc * tc;
+
+    double ca = 3.26138;
+    ca += (5.223e-4) * tc;
+    ca += (1.324e-4) * tc * tc;
+    ca += -(7.655e-7) * tc * tc * tc;
+    ca += (8.584e-10) * tc * tc * tc * tc;
+
+    double cb = (7.2061e-5);
+    cb += -(5.8948e-6) * tc;
+    cb += (8.69900e-8) * tc * tc;
+    cb += -(1.0100e-9) * tc * tc * tc;
+    cb += (4.3220e-12) * tc * tc * tc * tc;
+
+    double pbar = (1.0e-5) * p;
+    double num = (ko + ca * pbar + cb * (pbar * pbar));
+    double pw = num / (num - pbar);
+    pw *= (1.0e3) * po;
+    return pw;
+}
+
+// glibc 2.35 expf (sysdeps/ieee754/flt-32/e_expf.c: N=32 table of 2^(i/32), cubic in double).
+// std::exp(float) in the reference resolves to this routine; it is NOT correctly rounded
+// (0.06 % of arguments differ from (float)exp((double)x)), so the algorithm itself is restated.
+// The table is 2^(i/32) correctly rounded to double, minus (i << 47).
+__device__ const uint64_t kExp2fTab[32] = {
+    0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,
+    0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,
+    0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,
+    0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,
+    0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
+    0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,
+    0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
+    0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL};
+
+__device__ __forceinline__ float expf_glibc(float x)
+{
+    constexpr double N = 32.0;
+    constexpr double InvLn2N = 0x1.71547652b82fep+0 * N;
+    constexpr double Shift = 0x1.8p+52;
+    constexpr double C0 = 0x1.c6af84b912394p-5 / N / N / N;
+    constexpr double C1 = 0x1.ebfce50fac4f3p-3 / N / N;
+    constexpr double C2 = 0x1.62e42ff0c52d6p-1 / N;
+    double xd = (double)x;
+    // |x| >= 88: overflow/underflow paths of the original are unreachable for viscosity
+    // arguments (0 <= x < 8); handled generically for completeness.
+    if (!(fabsf(x) < 88.0f)) {
+        if (x != x) return x;
+        if (x > 0.0f) return x > 88.72283f ? __builtin_inff() : (float)exp(xd);
+        return x < -103.97208f ? 0.0f : (float)exp(xd);
+    }
+    double z = InvLn2N * xd;
+    double kd = z + Shift;
+    uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= Shift;
+    double r = z - kd;
+    uint64_t t = kExp2fTab[ki & 31];
+    t += ki << 47;
+    double s = __longlong_as_double((long long)t);
+    double zz = C0 * r + C1;
+    double r2 = r * r;
+    double y = C2 * r + 1.0;
+    y = zz * r2 + y;
+    y = y * s;
+    return (float)y;
+}
+
+// src/EVAP.cpp:405-462 -- Huber et al. (2009) viscosity in the reference's float/double mix.
+// Every rounding point of the C++ original is kept: a `float` variable is a rounding to float;
+// an expression containing a double literal is evaluated in double.
+__device__ __forceinline__ float viscosity_h2o(float tc, float p)
+{
+#pragma clang fp contract(off)
+    const float tk_ast = 647.096f;
+    const float rho_ast = 322.0f;
+    const float mu_ast = 1e-6f;
+
+    float rho = (float)density_h2o((double)tc, (double)p);            // :413
+    float tbar = (float)(((double)tc + 273.15) / (double)tk_ast);      // :416
+    float tbarx = (float)sqrt((double)tbar);                           // :417 pow(tbar,0.5)
+    float tbar2 = tbar * tbar;                                         // :418
+    float tbar3 = tbar * tbar * tbar;                                  // :419
+    float rbar = rho / rho_ast;                                        // :420
+
+    float mu0 = (float)(1.67752 + 2.20462 / (double)tbar + 0.6366564 / (double)tbar2 -
+                        0.241605 / (double)tbar3);                     // :423
+    mu0 = (float)(1e2 * (double)tbarx / (double)mu0);                  // :424
+
+    // Table 3 of Huber et al. (:427-435); the literals are rounded to float as in the
+    // reference's `float h_array[7][6]`.  Zero entries add exactly 0 and are skipped.
+    float ctbar = (float)((1.0 / (double)tbar) - 1.0);                 // :439
+    double cd_ = (double)ctbar;
+    double rb = (double)rbar - 1.0;                                    // pow(rbar - 1.0, j) base
+    double rb2 = rb * rb, rb3 = rb2 * rb, rb4 = rb3 * rb, rb5 = rb4 * rb, rb6 = rb5 * rb;
+    double ct2 = cd_ * cd_, ct3 = ct2 * cd_, ct4 = ct3 * cd_, ct5 = ct4 * cd_;
+
+#define H(v) ((double)(float)(v))
+#define ACC(c2, h, pw_) c2 = (float)((double)(c2) + H(h) * (pw_))
+    float mu1 = 0.0f, c2;
+    // i = 0: coef1 = pow(ctbar,0) = 1
+    c2 = 0.0f;
+    ACC(c2, 0.520094, 1.0); ACC(c2, 0.222531, rb); ACC(c2, -0.281378, rb2);
+    ACC(c2, 0.161913, rb3); ACC(c2, -0.0325372, rb4);
+    mu1 = mu1 + 1.0f * c2;
+    // i = 1
+    c2 = 0.0f;
+    ACC(c2, 0.0850895, 1.0); ACC(c2, 0.999115, rb); ACC(c2, -0.906851, rb2);
+    ACC(c2, 0.257399, rb3);
+    mu1 = mu1 + (float)cd_ * c2;
+    // i = 2
+    c2 = 0.0f;
+    ACC(c2, -1.08374, 1.0); ACC(c2, 1.88797, rb); ACC(c2, -0.772479, rb2);
+    mu1 = mu1 + (float)ct2 * c2;
+    // i = 3
+    c2 = 0.0f;
+    ACC(c2, -0.289555, 1.0); ACC(c2, 1.26613, rb); ACC(c2, -0.489837, rb2);
+    ACC(c2, 0.0698452, rb4); ACC(c2, -0.00435673, rb6);
+    mu1 = mu1 + (float)ct3 * c2;
+    // i = 4
+    c2 = 0.0f;
+    ACC(c2, -0.257040, rb2); ACC(c2, 0.00872102, rb5);
+    mu1 = mu1 + (float)ct4 * c2;
+    // i = 5
+    c2 = 0.0f;
+    ACC(c2, 0.120573, rb); ACC(c2, -0.000593264, rb6);
+    mu1 = mu1 + (float)ct5 * c2;
+#undef ACC
+#undef H
+
+    mu1 = expf_glibc(rbar * mu1);                                      // :451
+    float mu_bar = mu0 * mu1;                                          // :456
+    float mu = mu_bar * mu_ast;                                        // :459
+    return mu;
+}
+
+// src/EVAP.cpp:491-515
+__device__ __forceinline__ double specific_heat(double tc)
+{
+    double cp;
+    if (tc < 0) {
+        cp = 1004.5714270;
+    } else if (tc > 100) {
+        cp = 2031.2260590;
+    } else {
+        double t2 = tc * tc, t3 = t2 * tc, t4 = t3 * tc, t5 = t4 * tc;
+        cp = 1.0045714270;
+        cp += (2.050632750e-3) * tc;
+        cp += -(1.631537093e-4) * t2;
+        cp += (6.212300300e-6) * t3;
+        cp += -(8.830478888e-8) * t4;
+        cp += (5.071307038e-10) * t5;
+        cp *= (1.0e3);
+    }
+    return cp;
+}
+
+// ---- cell setup ----------------------------------------------------------------------------
+// Loads one cell's raw parameters (cellpar rows) and derives the day-loop constants.
+// cellout is passed separately because splash.point overwrites it with the aridity index
+// between the two spin-ups (R/splash.point.R:150).
+__device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, size_t ld,
+                                  size_t cell, double cellout)
+{
+    const double lat = par[P_LAT * ld + cell], elv = par[P_ELV * ld + cell];
+    const double slop = par[P_SLOP * ld + cell], asp = par[P_ASP * ld + cell];
+    const double SAT = par[P_SAT * ld + cell], WP = par[P_WP * ld + cell];
+    const double FC = par[P_FC * ld + cell], Ksat = par[P_KSAT * ld + cell];
+    const double lambda = par[P_LAMBDA * ld + cell], depth = par[P_DEPTH * ld + cell];
+    const double bub = par[P_BUB * ld + cell], RES = par[P_RES * ld + cell];
+    const double Au = par[P_AU * ld + cell], Ai = par[P_AI * ld + cell];
+    const double cellin = par[P_CELLIN * ld + cell];
+
+    // SOLAR terrain terms, src/SOLAR.cpp:129-131
+    double sl = sin(lat * kPir), cl = cos(lat * kPir);
+    double ss = sin(slop * kPir), cs = cos(slop * kPir);
+    double sa = sin(asp * kPir), ca = cos(asp * kPir);
+    c.ka = cl * ss * ca - sl * cs;
+    c.kb = cl * cs + sl * ss * ca;
+    c.kc = ss * sa;
+    c.tau_o = (kC + kD) * (1.0 + (2.67e-5) * elv); // :170
+
+    // EVAP::elv2pres, src/EVAP.cpp:319-336
+    {
+        double ep = (kG * kMa) / (kR * kL);
+        double pa = (1.0 - elv * kL / kTo);
+        c.patm = pow(pa, ep) * kPo;
+        c.patm_f = (float)c.patm;
+    }
+
+    c.SAT = SAT;
+    c.RES = RES;
+    c.Au = Au;
+    c.Ai = Ai;
+    c.depth = depth;
+    c.d1000 = depth * 1000.0;
+    c.lambda = lambda;
+    c.bub = bub;
+    c.deep = (depth >= 2.0);
+
+    // src/SPLASH.cpp:971-993
+    const double KG_o = 1000.0 / (997 * kG);
+    c.theta_s = SAT / c.d1000;
+    c.theta_r = RES / c.d1000;
+    c.dtheta = c.theta_s - c.theta_r;
+    const double theta_fc = FC / c.d1000;
+    const double theta_wp = WP / c.d1000;
+    const double theta_q0 = theta_wp + 0.001;
+    const double sid_oct = sqrt(Ai / (2.0 * (1 + sqrt(2.0))));
+    c.inv_lambda = 1 / lambda;
+    c.e3l1 = 3.0 * lambda + 1.0;
+    c.kun_exp = 3.0 + (2.0 / lambda);
+
+    // src/SPLASH.cpp:1027-1029
+    const double coeff_A = exp(log(33.0) + (1.0 / lambda) * log(theta_fc));
+    c.Wmax = pow((coeff_A * KG_o / (depth)), (1.0 / ((1 / lambda) + 1.0))) * (c.d1000);
+    c.wm_th = c.Wmax / c.d1000;
+
+    c.int_perm = Ksat / kFluidity; // :1260
+    c.tan_slop = tan(slop * kPir); // :1278
+    c.inv_cos2 = 1.0 / (cs * cs);  // :2011
+    c.h_f = ((2 + 3 * lambda) / (1 + 3 * lambda)) * (bub / 2); // :1987
+    c.tu_coef = bub / c.e3l1;
+    c.so_cellout = sid_oct * cellout;
+    c.tu_fac = ((24.0 * cellout * sid_oct) / (1000.0 * Ai));
+
+    // Recession constant: log(Kb) = Ksat_visc * kb_coef, src/SPLASH.cpp:1291-1326
+    {
+        double psi_q0 = bub / pow(((theta_q0 - c.theta_r) / c.dtheta), c.inv_lambda);
+        double wtd_q0 = ((bub - psi_q0) / 1000.0);
+        if (wtd_q0 < 0.0 || isnan(wtd_q0)) {
+            wtd_q0 = 0.0;
+        } else if (wtd_q0 > depth) {
+            wtd_q0 = depth;
+        }
+        double tq0 = c.tu_coef * (pow((bub / psi_q0), c.e3l1) -
+                                  pow((bub / (psi_q0 + (wtd_q0 * 1000.0))), c.e3l1));
+        double q_q0 = tq0 * c.tan_slop * ((24.0 * sid_oct * cellout) / (1.0e6));
+        double acs_qs = depth * sid_oct * cellout;
+        double q_qs = c.tan_slop * 24.0 * acs_qs / 1000.0;
+        c.kb_coef = (q_q0 - q_qs) / ((SAT - WP) * (Ai / 1000.0));
+    }
+    // Drainage at Wmax: Qt = Ksat_visc*qt_coef*hyd_grad_out, src/SPLASH.cpp:1333-1360
+    {
+        double th = c.wm_th;
+        double psi_m = bub / pow(((th - c.theta_r) / c.dtheta), c.inv_lambda);
+        double wtd = ((bub - psi_m) / 1000.0);
+        if (wtd < 0.0 || isnan(wtd)) {
+            wtd = 0.01;
+        } else if (wtd > depth) {
+            wtd = depth;
+        }
+        double acs = (depth - wtd) * cellin * sid_oct;
+        double to_uns = c.tu_coef * (pow((bub / psi_m), c.e3l1) -
+                                     pow((bub / (psi_m + (wtd * 1000.0))), c.e3l1));
+        double qo_uns = to_uns * ((24.0 * cellin * sid_oct) / (1.0e6));
+        double qo_sat = 24.0 * acs / 1000.0;
+        c.qt_coef = qo_sat + qo_uns;
+    }
+}
+
+// ---- SOLAR + EVAP ---------------------------------------------------------------------------
+struct Etr { // src/etr.h:44-56 (fields the water balance needs)
+    double cond, pet, aet, snowmelt, sublimation, pw, rn_d, visc, econ, pet_max;
+};
+
+// src/SOLAR.cpp:77-267 + src/EVAP.cpp:82-264 for one cell-day.
+// sw is the supply fraction (src/SPLASH.cpp:1042-1048), snow already includes today's snowfall.
+__device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, double sw,
+                                         double sw_in, double tc, double snow, double nd, Etr& o)
+{
+    // ----- SOLAR
+    double sw_s = sw > 1.0 ? 1.0 : sw; // :92
+    double a = d.sd * c.ka, b = d.cd * c.kb, cc = d.cd * c.kc;
+    double b2c2 = b * b + cc * cc;
+    double dd = b2c2 - a * a;
+    double sinfirst;
+    if (dd < 0) {
+        sinfirst = (a * cc) / b2c2;
+    } else {
+        sinfirst = (a * cc + b * sqrt(dd)) / b2c2;
+    }
+    double ru = -1 * a + cc * sinfirst;
+    double rv = b;
+
+    double ruv = ru / rv;
+    double hs; // degrees, :149-159
+    if (ruv >= 1.0) {
+        hs = 180.0;
+    } else if (ruv <= -1.0) {
+        hs = 0.0;
+    } else {
+        hs = acos(-1.0 * ruv) / kPir;
+    }
+    double sin_hs = dsin_deg(hs);
+    double geo = (ru * hs * kPir + rv * sin_hs);
+    double ra_d = (86400.0 / kPI) * d.dr * kGsc * geo; // :164-165
+
+    double r_in = 86400 * sw_in;
+    double tau; // :174-178
+    if (isnan(ra_d) || r_in == 0 || ra_d < r_in) {
+        tau = c.tau_o;
+    } else {
+        tau = r_in / ra_d;
+    }
+    double sf = pow(((tau - c.tau_o * 0.1898) / (c.tau_o * (1 - 0.1898))), (1 / 0.7410)); // :197
+    if (isnan(sf)) {
+        sf = 0.0;
+    } else if (sf > 1.0) {
+        sf = 1.0;
+    }
+    double rnl = (0.0883289 + (1.0 - kB) * sf) * (kA + 1.95974 * tc); // :203
+
+    double max_alb_snw = (1.0 - 0.443700) + (0.443700 * exp(-0.895189 * nd)); // :208
+    double sfc = snow / (140.0 + snow);
+    double alb_v = kAlbSw - 0.17 * sw_s;
+    double alb = alb_v * (1.0 - sfc) + sfc * max_alb_snw;
+    double rw; // :220-224
+    if ((sw_in == 0.0) || (hs == 0.0)) {
+        rw = (1.0 - alb) * tau * d.dr * kGsc;
+    } else {
+        rw = (1.0 - alb) * (r_in) / ((86400.0 / kPI) * geo);
+    }
+
+    double xn = (rnl - rw * ru) / (rw * rv);
+    double hn; // :231-240
+    if (xn >= 1.0) {
+        hn = 0;
+    } else if (xn <= -1.0) {
+        hn = 180.0;
+    } else {
+        hn = acos(xn) / kPir;
+    }
+    double sin_hn = dsin_deg(hn);
+    double rn_d = (kPir * hn * (rw * ru - rnl) + rw * rv * sin_hn) * (86400.0 / kPI); // :245-246
+    double rnn_d = rw * rv * (sin_hs - sin_hn);                                        // :252-255
+    rnn_d += rw * ru * (hs - hn) * kPir;
+    rnn_d -= rnl * (kPI - hn * kPir);
+    rnn_d *= (86400.0 / kPI);
+
+    // ----- EVAP
+    double tw = tc < 0.0 ? 0.0 : tc; // :100-105
+    double s; // sat_slope :299-301
+    {
+        double q = tc + 237.3;
+        s = exp((tc * 17.269) / q) / (q * q) * ((17.269) * (237.3) * (610.78));
+    }
+    double lv; // enthalpy_vap :313-315
+    {
+        double q = (tc + 273.15) / (tc + 273.15 - 33.91);
+        lv = q * q * 1.91846e6;
+    }
+    double pw = density_h2o(tc, c.patm);                        // :113
+    double g = (kMa * specific_heat(tc) * c.patm) / (kMv * lv); // psychro :486
+    double econ = s / (lv * pw * (s + g));                      // :117
+    float visc_f = viscosity_h2o((float)tw, c.patm_f);          // :120
+    double cn = (1.0e3) * econ * fabs(rnn_d) * 0.1;             // :124
+    double eet_d = (1.0e3) * (s / (lv * pw * (s + 0.24 * g))) * rn_d; // :129
+    double rx = (3.6e6) * econ;                                 // :145
+    double pet_max = rx * ((rw * (ru + rv)) - rnl);             // :148
+
+    double B_r = g / (sw * s); // :157-166 (uses the UNclamped sw argument)
+    double EF = 1 / (B_r + 1.0);
+    double sup = pet_max * EF;
+    if (sup < 0.0 || isnan(sup)) {
+        sup = 0.0;
+    }
+    double cos_hi = sup / (rw * rv * rx) + rnl / (rw * rv) - ru / rv; // :208
+    double hi;
+    if (cos_hi >= 1.0) {
+        hi = 0.0;
+    } else if (cos_hi <= -1.0) {
+        hi = 180.0;
+    } else {
+        hi = acos(cos_hi) / kPir;
+    }
+    double snowmelt; // :233-237
+    if (tc >= 3.0) {
+        double m = (rn_d / (pw * kKfus)) * 1000.0;
+        snowmelt = SPL_MIN(snow, m);
+    } else {
+        snowmelt = 0.0;
+    }
+    double melt_enrg = (snowmelt / 1000) * pw * kKfus; // :241-249
+    double AE = rn_d - melt_enrg;
+    double sub_c = (AE * econ) * 1000.0;
+    double sublimation = SPL_MIN(snowmelt, sub_c);
+    melt_enrg += ((sublimation / 1000.0) / econ);
+
+    double aet_d = sup * hi * kPir; // :254-263
+    aet_d += rx * rw * rv * (sin_hn - dsin_deg(hi));
+    aet_d += (rx * rw * ru - rx * rnl) * (hn - hi) * kPir;
+    aet_d *= (24.0 / kPI);
+    aet_d -= (melt_enrg * econ * 1000.0);
+    if (aet_d < 0.0) {
+        aet_d = 0.0;
+    }
+
+    o.cond = cn;
+    o.pet = eet_d; // pet_d = eet_d, :140
+    o.aet = aet_d;
+    o.snowmelt = snowmelt;
+    o.sublimation = sublimation;
+    o.pw = pw;
+    o.rn_d = rn_d;
+    o.visc = (double)visc_f;
+    o.econ = econ;
+    o.pet_max = pet_max;
+}
+
+// ---- SPLASH helpers ---------------------------------------------------------------------------
+// src/SPLASH.cpp:1921-1961 with z = 10 cm (call at :1265)
+__device__ __forceinline__ double moist_surf(const CellConst& c, double wn)
+{
+    const double z = 10.0;
+    double bubbling_pr = c.bub / 10;
+    double theta_mean = (wn) / (c.d1000);
+    double water_pot_BC = bubbling_pr / pow(((theta_mean - c.theta_r) / c.dtheta), c.inv_lambda);
+    double total_head_BC = water_pot_BC + z;
+    double theta_BC = c.dtheta * pow((total_head_BC / bubbling_pr), (-1 * c.lambda)) + c.theta_r;
+    if (theta_mean < c.theta_r) {
+        theta_BC = c.theta_r;
+    } else if (isnan(theta_BC)) {
+        theta_BC = c.theta_s;
+    }
+    return theta_BC;
+}
+
+// src/SPLASH.cpp:1963-2023 with tdur = 6 h (call at :1268)
+__device__ __forceinline__ double inf_GA(const CellConst& c, double theta_i, double Ksat,
+                                         double P)
+{
+    const double tdur = 6.0;
+    double r = P / tdur;
+    double delta_head = c.h_f;
+    double delta_theta = (c.theta_s - theta_i);
+    double I = 0.0;
+    if (r <= Ksat) {
+        I = P;
+    } else {
+        if (delta_theta <= 0.0) {
+            I = Ksat * tdur;
+        } else {
+            double tp = (Ksat * delta_theta * -1.0 * delta_head) / (r * (r - Ksat));
+            if (tp <= 0.0 || isnan(tp)) {
+                tp = 0.01;
+            }
+            double tp_s = tp * c.inv_cos2;
+            I = r * tp_s + (Ksat * (tdur - tp_s) -
+                            (delta_head * delta_theta *
+                             log(1 - (r * tp_s / (delta_head * delta_theta)))));
+        }
+    }
+    if (I > P) {
+        I = P;
+    }
+    return I;
+}
+
+// Transmittance of the column at water content sm (src/SPLASH.cpp:1406-1431 and 1511-1536):
+// returns T_uns already scaled to flux density [mm/day] and guarded, and Acs_out via reference.
+__device__ __forceinline__ double transmittance_uns(const CellConst& c, double Ksat_visc,
+                                                    double sm, double& Acs_out)
+{
+    double theta_i = (sm) / (c.d1000);
+    double psi_m = c.bub / pow(((theta_i - c.theta_r) / c.dtheta), c.inv_lambda);
+    double wtd = ((c.bub - psi_m) / 1000.0);
+    if (wtd < 0.0 || isnan(wtd)) {
+        wtd = 0.01;
+    } else if (wtd > c.depth) {
+        wtd = c.depth;
+    }
+    Acs_out = (c.depth - wtd) * c.so_cellout;
+    double T_uns = (Ksat_visc * c.tu_coef) * (pow((c.bub / psi_m), c.e3l1) -
+                                              pow((c.bub / (psi_m + (wtd * 1000.0))), c.e3l1));
+    T_uns *= c.tu_fac;
+    if (T_uns < 0.0 || isnan(T_uns)) {
+        T_uns = 0.0;
+    }
+    return T_uns;
+}
+
+// ---- the day step: src/SPLASH.cpp:920-1588 (== quick_run :150-918) ----------------------------
+__device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, double sw_in,
+                                         double tc, double pn, double snowfall, State& st,
+                                         DayOut& o)
+{
+    const double wn = st.wn;
+    double snow = st.snow, qin = st.qin, td = st.td, nd = st.nd;
+
+    // :984-990 clamp of the start-of-day volumetric content
+    double theta_i = (wn) / (c.d1000);
+    if (theta_i >= c.theta_s) {
+        theta_i = c.theta_s - 0.001;
+    } else if (theta_i <= c.theta_r) {
+        theta_i = c.theta_r + 0.001;
+    }
+    // :1042-1048
+    double sw = ((wn - c.RES) / (c.Wmax - c.RES));
+    if (sw < 0.0 || isnan(sw)) {
+        sw = 0.0;
+    } else if (sw > 1.0) {
+        sw = 1.0;
+    }
+    // :1225-1231
+    if (snowfall > 0.0) {
+        nd = 0.0;
+    } else {
+        nd += 1.0;
+    }
+    snow += snowfall;
+
+    Etr ev;
+    evap_day(c, d, sw, sw_in, tc, snow, nd, ev); // :1235
+    snow -= ev.snowmelt;                          // :1240
+    double snowmelt = ev.snowmelt - ev.sublimation; // :1243
+
+    // :1260-1272
+    double Ksat_visc = c.int_perm * ((ev.pw * kG) / ev.visc) * 3.6;
+    double inflow = pn + ev.cond + snowmelt;
+    double surf_moist = moist_surf(c, wn);
+    double theta_m = SPL_MAX(c.wm_th, theta_i);
+    double infi = inf_GA(c, surf_moist, Ksat_visc, inflow);
+    double ro_h_arg = inflow - infi;
+    double ro_h = SPL_MAX(ro_h_arg, 0.0);
+    double R = infi - ev.aet;
+
+    // :1275-1284
+    double hyd_grad_z = (infi / (Ksat_visc * 24)) - 1.0;
+    double hyd_grad_out = sqrt(hyd_grad_z * hyd_grad_z + c.tan_slop * c.tan_slop);
+
+    // :1291-1326 (cell-static part folded into kb_coef); Kb and log(Kb) keep the reference's
+    // exp-then-log rounding
+    double Kb = exp(Ksat_visc * c.kb_coef);
+    // :1360
+    double Qt = (Ksat_visc * c.qt_coef) * hyd_grad_out;
+
+    // :1365-1372
+    double q_in_o = 0.0;
+    if ((td <= 0.0) || (qin <= 0.0)) {
+        q_in_o = 0.0;
+    } else {
+        q_in_o = qin * Kb;
+    }
+    // :1377-1397
+    double sm = wn + q_in_o + R;
+    double ro_d = 0.0;
+    if (sm > c.SAT) {
+        ro_d = (sm - c.SAT);
+        sm = c.SAT;
+        if (R > 0) {
+            R -= ro_d;
+        }
+    } else if (sm < c.RES) {
+        sm = c.RES;
+        ro_d = 0.0;
+    }
+
+    // :1406-1457 transmittance after recharge
+    double Acs_out;
+    double T_uns = transmittance_uns(c, Ksat_visc, sm, Acs_out);
+    double T_sat;
+    if (c.deep) { // depth >= 2.0: vertical drainage corrections :1433-1450
+        double Kunsat = Ksat_visc * pow((theta_m / c.theta_s), c.kun_exp); // :1275
+        T_uns += Kunsat * 24.0;
+        T_sat = Ksat_visc * 24.0 * ((Acs_out + c.Ai) / c.Ai);
+    } else {
+        T_sat = Ksat_visc * 24.0 * (Acs_out / c.Ai);
+    }
+    double T = (T_sat + T_uns) * hyd_grad_out;
+    double Q = (T * c.Ai) / 1000;
+
+    // :1465-1483
+    double t_drain = 0.0;
+    double q_in_f = 0.0;
+    td -= 1.0;
+    if ((R > 0.0) && (sm > c.Wmax)) {
+        double lkb = log(Kb);
+        t_drain = -1.0 * log(1.0 - (lkb * (c.Au * R / Q))) / lkb;
+        q_in_f = (Qt - c.Au * R * lkb) / c.Ai;
+    }
+    if (q_in_f < 0.0 || isnan(q_in_f)) {
+        q_in_f = 0.0;
+    }
+    double td_arg = (td + t_drain) / 2;
+    double tdrain_out = SPL_MAX(td_arg, 0.0);
+
+    // :1488-1506
+    sm += (q_in_f);
+    if (sm > c.SAT) {
+        ro_d += (sm - c.SAT);
+        sm = c.SAT;
+    } else if (sm < c.RES) {
+        sm = c.RES;
+    }
+    double ro = ro_d + ro_h;
+
+    // :1511-1547 transmittance after upslope inflow (no vertical-drainage correction here)
+    double Acs2;
+    double T_uns2 = transmittance_uns(c, Ksat_visc, sm, Acs2);
+    double T2 = (Ksat_visc * 24.0 * (Acs2 / c.Ai) + T_uns2) * hyd_grad_out;
+
+    // :1552-1567
+    sm -= (T2);
+    if (sm > c.SAT) {
+        sm = c.SAT;
+    } else if (sm < c.RES) {
+        sm = c.RES;
+    }
+    // :1574
+    double mx = SPL_MAX(q_in_o, q_in_f);
+    double qin_nday = SPL_MAX(mx, 0.0);
+
+    st.wn = sm;
+    st.snow = snow;
+    st.qin = qin_nday;
+    st.td = tdrain_out;
+    st.nd = nd;
+    o.ro = ro;
+    o.pet = ev.pet;
+    o.aet = ev.aet;
+    o.cond = ev.cond;
+    o.bflow = T2;
+    o.netr = ev.rn_d / 1e6; // src/SPLASH.cpp:1907
+}
+
+// ---- rain / snow split: R/splash.point.R:120-128, 521-578 -------------------------------------
+// snow_term = elev*0.0004596581 + |lat|*0.0110592101 (cell-static part of snowfall_prob, :576)
+__device__ __forceinline__ double snowfall_prob(double tc, double snow_term)
+{
+    return 1 / (1 + exp(-0.4710405934 + 1.0473543991 * tc - snow_term));
+}
+
+__device__ __forceinline__ void rain_snow_split(const DayConst& d, double tc, double pn, double Tt,
+                                                double snow_term, double& rain, double& snowfall)
+{
+    double p = snowfall_prob(tc, snow_term);
+    double f_rain = 1.0;
+    if (p >= 0.5) {
+        double Ttm = Tt + (Tt * d.ttm_s);
+        double x = ((tc - Ttm) / d.trm14);
+        double x2 = x * x, x3 = x2 * x;
+        double fr;
+        if (tc <= Ttm) {
+            fr = 5 * x3 + 6.76 * x2 + 3.19 * x + 0.5;
+        } else {
+            fr = 5 * x3 - 6.76 * x2 + 3.19 * x + 0.5;
+        }
+        if (fr < 0) fr = 0;
+        if (fr > 1) fr = 1;
+        f_rain = fr;
+    }
+    snowfall = pn * (1 - f_rain);
+    rain = pn * f_rain;
+}
+
+} // namespace splash

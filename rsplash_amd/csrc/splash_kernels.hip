@@ -1,0 +1,813 @@
+// splash_kernels.hip -- gfx950 kernels of the gridded SPLASH loop and their launchers.
+//
+// Launch shape everywhere: one lane = one grid cell, 256-lane workgroups (4 wavefronts), grid =
+// ceil(ncell/256).  Rasters are time-major [nt][ld] so that the 64 lanes of a wavefront read 512
+// contiguous bytes per series per day; the per-day table is read through scalar loads (uniform
+// index).  Lanes past ncell stay alive (clamped index, masked stores) so wave-level votes and
+// reductions always see full waves.
+#include "splash_kernels.hpp"
+
+#include "splash_device.hpp"
+
+namespace splash {
+
+static constexpr int kBlock = 256;
+
+// ================================================================ K1 soil_hydro ===============
+// R/splash.point.R:232-416 (soil_hydro) + :96-115 (soil_info) + :131 (asp-180)
+__global__ __launch_bounds__(kBlock) void k_soil_hydro(
+    size_t ncell, const double* __restrict__ lat, const double* __restrict__ elev,
+    const double* __restrict__ slop, const double* __restrict__ asp,
+    const double* __restrict__ resolution, const double* __restrict__ soil,
+    const double* __restrict__ au, double* __restrict__ par)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= ncell) return;
+    const double sand = soil[i], clay = soil[ncell + i], OM = soil[2 * ncell + i];
+    double fgravel = soil[3 * ncell + i], bd = soil[4 * ncell + i];
+    const double depth_m = soil[5 * ncell + i];
+
+    double fsand = sand / 100, fclay = clay / 100, fOM = OM / 100; // :261-264
+    fgravel = fgravel / 100;
+    const double depth30 = 30; // :268
+    double dp = 1 / ((fOM / 1.3) + ((1 - fOM) / 2.65));
+    if (isnan(bd)) { // :276
+        bd = (1.5 + (dp - 1.5 - 1.10 * (1 - fclay)) * (1 - exp(-0.022 * depth30))) /
+             (1 + 6.27 * fOM);
+    }
+    if (bd < 0.81) bd = 0.81; // :280
+    double sat = 1 - (bd / dp); // :285
+    double sq_clay = sqrt(fclay); // fclay^0.5
+    double fc = (sat / bd) * (0.4760944 + (0.9402962 - 0.4760944) * sq_clay) *
+                exp(-1 * (0.05472678 * fsand - 0.01 * fOM) / (sat / bd)); // :287
+    double wp_Ball = fc * (0.2018522 + (0.7809203 - 0.2018522) * sq_clay);    // :289
+    double wp = -2.464e-05 * sand + 3.650e-03 * clay + 8.680e-03 * OM + 9.393e-03 * bd; // :294
+    if (!isnan(wp) && wp >= fc) wp = wp_Ball;                                           // :295
+    double coef_B = (log(1500.0) - log(33.0)) / (log(fc) - log(wp)); // :319
+    double coef_A = exp(log(33.0) + coef_B * log(fc));               // :320
+    double coeff_c = 1000.0 / (997 * 9.80665);                       // :326
+    double theta_c = pow((coeff_c * coef_A / 2.0), (1 / (1 + coef_B))); // :327
+    double theta_r = (0.0285 + 0.00336 * (clay)) * bd;                  // :340
+    if (!isnan(theta_r) && theta_r > wp) theta_r = wp;                  // :341
+    sat = sat * (1 - fgravel); // :351-353
+    fc = fc * (1 - fgravel);
+    wp = wp * (1 - fgravel);
+    double coef_lambda = 1 / coef_B;
+    double ksat = 857.48454 / (1 + exp(-2.70927 * fsand + 3.62264 * bd + 7.33398 * fclay +
+                                       -8.11795 * (sat - fc) + 18.75552 * fOM +
+                                       1.03319 * coef_lambda)); // :355-363
+    double m33i = 0.278 * fsand + 0.034 * fclay + 0.022 * fOM - 0.018 * (fsand * fOM) -
+                  0.027 * (fclay * fOM) - 0.584 * (fsand * fclay) + 0.078; // :369
+    double m33 = m33i + (0.636 * m33i - 0.107);                            // :370
+    double bub_init = -21.6 * fsand - 27.93 * fclay - 81.97 * m33 + 71.12 * (fsand * m33) +
+                      8.29 * (fclay * m33) + 14.05 * (fsand * fclay) + 27.16; // :371
+    double bubbling_p = bub_init + (0.02 * (bub_init * bub_init) - 0.113 * bub_init - 0.7); // :372
+    bubbling_p = bubbling_p * -101.97162129779;                                             // :374
+    if (!isnan(bubbling_p) && bubbling_p > 0) bubbling_p = coef_A * -101.97162129779;        // :379
+    double RESv = theta_r * (1 - fgravel); // :410
+
+    double res = resolution[i];
+    par[P_LAT * ncell + i] = lat[i];
+    par[P_ELV * ncell + i] = elev[i];
+    par[P_SLOP * ncell + i] = slop[i];
+    par[P_ASP * ncell + i] = asp[i] - 180; // R/splash.point.R:131
+    par[P_SAT * ncell + i] = sat * depth_m * 1000; // :98-101
+    par[P_WP * ncell + i] = wp * depth_m * 1000;
+    par[P_FC * ncell + i] = fc * depth_m * 1000;
+    par[P_KSAT * ncell + i] = ksat;
+    par[P_LAMBDA * ncell + i] = 1 / coef_B; // :104
+    par[P_DEPTH * ncell + i] = depth_m;
+    par[P_BUB * ncell + i] = bubbling_p;
+    par[P_RES * ncell + i] = RESv * depth_m * 1000;
+    par[P_AU * ncell + i] = au ? au[i] : 0.0;
+    par[P_AI * ncell + i] = res * res; // resolution^2
+    par[P_CELLIN * ncell + i] = au ? au[ncell + i] : 3.0;
+    par[P_CELLOUT * ncell + i] = au ? au[2 * ncell + i] : 3.0;
+    par[P_WMAXR * ncell + i] = theta_c * depth_m * 1000; // :102
+}
+
+// ================================================================ K2 snow threshold ===========
+// Tt = max(tc[p_snow >= 0.5]) over the whole series, R/splash.point.R:120-122
+__global__ __launch_bounds__(kBlock) void k_snow_threshold(size_t ncell, int nt,
+                                                          const double* __restrict__ tc,
+                                                          size_t ldf,
+                                                          const double* __restrict__ par,
+                                                          size_t ldp, double* __restrict__ Tt)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= ncell) return;
+    double snow_term = par[P_ELV * ldp + i] * 0.0004596581 + fabs(par[P_LAT * ldp + i]) * 0.0110592101;
+    double best = -__builtin_inf();
+#pragma unroll 4
+    for (int t = 0; t < nt; t++) {
+        double v = __builtin_nontemporal_load(&tc[(size_t)t * ldf + i]);
+        double p = snowfall_prob(v, snow_term);
+        if (p >= 0.5 && v > best) best = v;
+    }
+    Tt[i] = best;
+}
+
+// ================================================================ forcing access ==============
+struct Forcing {
+    const double *sw, *tc, *pn, *snowfall; // snowfall != NULL => explicit rain/snow series
+    size_t ld;
+    double Tt, snow_term;
+    size_t cell;
+    __device__ __forceinline__ void raw(int t, double& a, double& b, double& c_) const
+    {
+        size_t k = (size_t)t * ld + cell;
+        a = sw[k];
+        b = tc[k];
+        c_ = pn[k];
+    }
+    __device__ __forceinline__ void split(const DayRec& d, int t, double tcv, double pnv,
+                                          double& rain, double& snowf) const
+    {
+        if (snowfall) {
+            rain = pnv;
+            snowf = snowfall[(size_t)t * ld + cell];
+        } else {
+            DayConst dc{d.dr, d.sd, d.cd, d.ttm_s, d.trm14};
+            rain_snow_split(dc, tcv, pnv, Tt, snow_term, rain, snowf);
+        }
+    }
+};
+
+__device__ __forceinline__ DayConst day_const(const DayRec& d)
+{
+    return DayConst{d.dr, d.sd, d.cd, d.ttm_s, d.trm14};
+}
+
+// ================================================================ K4 spin-up ===================
+// SPLASH::spin_up, src/SPLASH.cpp:1594-1749, for one lane.  The "extra" day-1 step that closes
+// each pass (:1674, :1729) is the same evaluation as day 1 of the following pass, so it is
+// computed once and reused.  Lanes whose loop has ended keep stepping (the wavefront runs until
+// its slowest lane converges) but no longer update their results.
+// series: optional per-day outputs of the LAST executed pass (module mirror), [7][n][ld].
+template <bool SERIES>
+__device__ __forceinline__ int spin_up_lane(const CellConst& c, const DayRec* __restrict__ days,
+                                            int n, const Forcing& f, bool valid, State& final_st,
+                                            double& pet_sum, double& p_sum,
+                                            double* const* series, size_t sld)
+{
+    State e{c.RES, 0.0, 0.0, 0.0, 0.0}; // wn_vec(n,RES) etc. read at [n-1] on day 1, :1633-1648
+    DayOut o;
+    double sw0, tc0, pn0, rain0, snf0;
+    f.raw(0, sw0, tc0, pn0);
+    f.split(days[0], 0, tc0, pn0, rain0, snf0);
+    day_step(c, day_const(days[0]), sw0, tc0, rain0, snf0, e, o);
+    pet_sum = o.pet;
+    p_sum = rain0 + snf0;
+    int count = 1;
+    bool active = valid;
+    bool first = true;
+    final_st = e;
+    for (;;) {
+        State cur = e;
+        const double start_sm = e.wn;
+        double ro0 = o.ro, pet0 = o.pet;
+        if (SERIES && active) {
+            series[0][f.cell] = e.wn;
+            series[1][f.cell] = e.snow;
+            series[2][f.cell] = e.qin;
+            series[3][f.cell] = e.td;
+            series[4][f.cell] = ro0;
+            series[5][f.cell] = e.nd;
+            if (first) series[6][f.cell] = pet0;
+        }
+        double swv, tcv, pnv;
+        f.raw(1, swv, tcv, pnv);
+        for (int i = 1; i < n; i++) {
+            double swn = swv, tcn = tcv, pnn = pnv;
+            if (i + 1 < n) f.raw(i + 1, swn, tcn, pnn); // prefetch next day
+            double rain, snf;
+            f.split(days[i], i, tcv, pnv, rain, snf);
+            day_step(c, day_const(days[i]), swv, tcv, rain, snf, cur, o);
+            if (first) { // pet_vec is only filled in the first pass, :1667 vs :1718-1723
+                pet_sum += o.pet;
+                p_sum += rain + snf;
+            }
+            if (SERIES && active) {
+                size_t k = (size_t)i * sld + f.cell;
+                series[0][k] = cur.wn;
+                series[1][k] = cur.snow;
+                series[2][k] = cur.qin;
+                series[3][k] = cur.td;
+                series[4][k] = o.ro;
+                series[5][k] = cur.nd;
+                if (first) series[6][k] = o.pet;
+            }
+            swv = swn;
+            tcv = tcn;
+            pnv = pnn;
+        }
+        State nxt = cur;
+        day_step(c, day_const(days[0]), sw0, tc0, rain0, snf0, nxt, o); // :1674 / :1729
+        double diff_sm = nxt.wn - start_sm;                              // :1678-1688
+        if (diff_sm < 0) diff_sm = start_sm - nxt.wn;
+        if (active) final_st = cur;
+        bool cont = active && (diff_sm > 1.0) && (count < 1000); // :1697
+        active = cont;
+        if (!__any(active)) break;
+        if (active) count++;
+        e = nxt;
+        first = false;
+    }
+    return count;
+}
+
+// Grid spin-up: both spin-ups of splash.point (R/splash.point.R:141-152) as a resumable per-cell
+// job.  The number of passes is data dependent (2..1000, src/SPLASH.cpp:1697): most cells need
+// 2-5, a few per thousand never meet the 1 mm criterion and run all 1000.  A wavefront costs as
+// much as its slowest lane, so the work is done in phases: every phase gives each job a pass
+// budget, finished cells write their state, unfinished ones park their job (stage, pass count,
+// day-1 state) and append their cell id to a worklist; the next phase runs on the compacted
+// list, so the long-running cells end up packed into few dense waves.
+//   job stage 1: spin-up #1 (cellout as given); its first pass also yields the aridity index
+//   job stage 2: spin-up #2 with cellout := AI (R/splash.point.R:150)
+__global__ __launch_bounds__(kBlock) void k_spin_phase(SpinPhaseArgs a)
+{
+    const size_t nin = a.n_in ? (size_t)*a.n_in : a.ncell;
+    if ((size_t)blockIdx.x * kBlock >= nin) return; // whole workgroup past the list
+    const size_t slot = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = slot < nin;
+    const size_t sl = valid ? slot : nin - 1;
+    const size_t ci = a.wl_in ? (size_t)a.wl_in[sl] : sl;
+
+    Forcing f{a.sw, a.tc, a.pn, nullptr, a.ldf, a.Tt[ci],
+              a.par[P_ELV * a.ldp + ci] * 0.0004596581 + fabs(a.par[P_LAT * a.ldp + ci]) * 0.0110592101,
+              ci};
+    const DayRec d0 = a.days[0];
+    double sw0, tc0, pn0, rain0, snf0;
+    f.raw(0, sw0, tc0, pn0);
+    f.split(d0, 0, tc0, pn0, rain0, snf0);
+
+    int stage, count;
+    State e;
+    CellConst c;
+    DayOut o;
+    double pet_sum = 0.0, p_sum = 0.0;
+    if (a.fresh) {
+        stage = 1;
+        count = 1;
+        cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci]);
+        e = State{c.RES, 0.0, 0.0, 0.0, 0.0}; // wn_vec(n,RES), others 0, read at [n-1] (:1633-1648)
+        day_step(c, day_const(d0), sw0, tc0, rain0, snf0, e, o);
+        pet_sum = o.pet;
+        p_sum = rain0 + snf0;
+    } else {
+        const int m = a.meta[ci];
+        stage = m >> 16;
+        count = m & 0xFFFF;
+        cell_setup(c, a.par, a.ldp, ci, stage == 1 ? a.par[P_CELLOUT * a.ldp + ci] : a.ai[ci]);
+        e = State{a.state[ci], a.state[a.lds + ci], a.state[2 * a.lds + ci],
+                  a.state[3 * a.lds + ci], a.state[4 * a.lds + ci]};
+    }
+    bool done = !valid;
+    for (int it = 0; it < a.budget; it++) {
+        const bool acc = a.fresh && it == 0; // first pass of spin-up #1 (uniform)
+        State cur = e;
+        double swv, tcv, pnv;
+        f.raw(1, swv, tcv, pnv);
+        for (int i = 1; i < a.n; i++) {
+            double swn = swv, tcn = tcv, pnn = pnv;
+            if (i + 1 < a.n) f.raw(i + 1, swn, tcn, pnn);
+            const DayRec d = a.days[i];
+            double rain, snf;
+            f.split(d, i, tcv, pnv, rain, snf);
+            day_step(c, day_const(d), swv, tcv, rain, snf, cur, o);
+            if (acc) { // pet_vec is only filled in the first pass (:1667), Pinit = rain + snow
+                pet_sum += o.pet;
+                p_sum += rain + snf;
+            }
+            swv = swn;
+            tcv = tcn;
+            pnv = pnn;
+        }
+        State nxt = cur; // the closing day-1 step (:1674/:1729) == day 1 of the next pass
+        day_step(c, day_const(d0), sw0, tc0, rain0, snf0, nxt, o);
+        double diff_sm = nxt.wn - e.wn; // end_sm - start_sm, :1678-1688
+        if (diff_sm < 0) diff_sm = e.wn - nxt.wn;
+        if (!done) {
+            if (acc) a.ai[ci] = pet_sum / p_sum; // R/splash.point.R:150
+            const bool cont = (diff_sm > 1.0) && (count < 1000); // :1697
+            if (cont) {
+                e = nxt;
+                count++;
+            } else if (stage == 1) {
+                if (a.passes) a.passes[ci] = count;
+                const double AI = a.ai[ci];
+                a.par[P_CELLOUT * a.ldp + ci] = AI; // soil_info[12] <- AI (1-based): ncellout
+                cell_setup(c, a.par, a.ldp, ci, AI);
+                stage = 2;
+                count = 1;
+                e = State{c.RES, 0.0, 0.0, 0.0, 0.0};
+                day_step(c, day_const(d0), sw0, tc0, rain0, snf0, e, o);
+            } else {
+                a.state[ci] = cur.wn; // initial$sm[365] etc., R/splash.point.R:164-172
+                a.state[a.lds + ci] = cur.snow;
+                a.state[2 * a.lds + ci] = cur.qin;
+                a.state[3 * a.lds + ci] = cur.td;
+                a.state[4 * a.lds + ci] = cur.nd;
+                if (a.passes) a.passes[a.ncell + ci] = count;
+                done = true;
+            }
+        }
+        if (__all(done)) break;
+    }
+    if (!done) { // park the job and queue the cell for the next phase
+        a.state[ci] = e.wn;
+        a.state[a.lds + ci] = e.snow;
+        a.state[2 * a.lds + ci] = e.qin;
+        a.state[3 * a.lds + ci] = e.td;
+        a.state[4 * a.lds + ci] = e.nd;
+        a.meta[ci] = (stage << 16) | count;
+        const uint32_t k = atomicAdd(a.n_out, 1u);
+        a.wl_out[k] = (uint32_t)ci;
+    }
+}
+
+// module mirror: one spin-up with explicit snowfall and soil_info-derived cellpar, series out
+__global__ __launch_bounds__(64) void k_spin_up_mod(SpinArgs a, double* const* series, size_t sld,
+                                                   const double* snowfall)
+{
+    size_t cell = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const bool valid = cell < a.ncell;
+    const size_t ci = valid ? cell : a.ncell - 1;
+    Forcing f{a.sw, a.tc, a.pn, snowfall, a.ldf, 0.0, 0.0, ci};
+    CellConst c;
+    cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci]);
+    State st;
+    double pet_sum, p_sum;
+    int p1 = spin_up_lane<true>(c, a.days, a.n, f, valid, st, pet_sum, p_sum, series, sld);
+    if (valid && a.passes) a.passes[ci] = p1;
+}
+
+// ================================================================ K5 run_all ===================
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// SPLASH::run_all, src/SPLASH.cpp:1833-1916 (+ sm_lim and monthly aggregation of
+// R/splash.point.R:197-214, + monthly grid totals for the water-balance diagnostics).
+template <bool MONTHLY, bool DIAG>
+__global__ __launch_bounds__(kBlock) void k_run_all(RunArgs a)
+{
+    __shared__ double red[DIAG ? 4 * SPLASH_NDIAG_K : 1];
+    size_t cell = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = cell < a.ncell;
+    const size_t ci = valid ? cell : a.ncell - 1;
+    Forcing f{a.sw, a.tc, a.pn, a.snowfall, a.ldf, a.Tt ? a.Tt[ci] : 0.0,
+              a.par[P_ELV * a.ldp + ci] * 0.0004596581 + fabs(a.par[P_LAT * a.ldp + ci]) * 0.0110592101,
+              ci};
+    CellConst c;
+    cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci]);
+    const double wmax_r = a.par[P_WMAXR * a.ldp + ci];
+    const double lim_den = wmax_r - c.RES;
+    State st{a.state[ci], a.state[a.lds + ci], a.state[2 * a.lds + ci], a.state[3 * a.lds + ci],
+             a.state[4 * a.lds + ci]};
+
+    double acc[9]; // monthly accumulators in output order
+    double dg[4];  // monthly flux totals: precip, aet, ro, bflow
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) dg[k] = 0.0;
+
+    double swv, tcv, pnv;
+    f.raw(0, swv, tcv, pnv);
+    for (int t = 0; t < a.nt; t++) {
+        const DayRec d = a.days[t];
+        double swn = swv, tcn = tcv, pnn = pnv;
+        if (t + 1 < a.nt) f.raw(t + 1, swn, tcn, pnn); // next day's forcing in flight
+        double rain, snf;
+        f.split(d, t, tcv, pnv, rain, snf);
+        DayOut o;
+        day_step(c, day_const(d), swv, tcv, rain, snf, st, o);
+
+        double lim = (st.wn - c.RES) / lim_den; // R/splash.point.R:197-200
+        if (lim < 0) lim = 0.0;
+        if (lim > 1) lim = 1.0;
+        const double v[9] = {st.wn, o.ro, o.pet, o.aet, st.snow, o.cond, o.bflow, o.netr, lim};
+
+        if (!MONTHLY) {
+            size_t k = (size_t)t * a.ldo + ci;
+#pragma unroll
+            for (int q = 0; q < 9; q++)
+                if (a.out[q] && valid) __builtin_nontemporal_store(v[q], &a.out[q][k]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 9; q++) acc[q] += v[q];
+        }
+        if (DIAG) {
+            dg[0] += rain + snf;
+            dg[1] += o.aet;
+            dg[2] += o.ro;
+            dg[3] += o.bflow;
+        }
+        const bool month_end = (d.flags & 1) != 0;
+        if (month_end || t == a.nt - 1) {
+            const int m = d.month_id - a.month0;
+            if (MONTHLY) {
+                // mean of storages (wn, snow, sm_lim), sum of fluxes (R/splash.point.R:210-211);
+                // a month split over two calls is completed by adding to the stored partial
+                const bool partial_head = (m == 0) && a.head_partial;
+                const double inv_n = 1.0 / (double)d.mdays;
+                size_t k = (size_t)m * a.ldo + ci;
+#pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    if (a.out[q] && valid) {
+                        double x = (q == 0 || q == 4 || q == 8) ? acc[q] * inv_n : acc[q];
+                        if (partial_head) x += a.out[q][k];
+                        a.out[q][k] = x;
+                    }
+                    acc[q] = 0.0;
+                }
+            }
+            if (DIAG) {
+                double w[SPLASH_NDIAG_K] = {dg[0], dg[1], dg[2], dg[3],
+                                            month_end ? st.wn : 0.0, month_end ? st.snow : 0.0};
+                const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+                for (int q = 0; q < SPLASH_NDIAG_K; q++) {
+                    double s = wave_sum(valid ? w[q] : 0.0);
+                    if (lane == 0) red[wave * SPLASH_NDIAG_K + q] = s;
+                }
+                __syncthreads();
+                if (threadIdx.x < SPLASH_NDIAG_K) {
+                    double s = red[threadIdx.x] + red[SPLASH_NDIAG_K + threadIdx.x] +
+                               red[2 * SPLASH_NDIAG_K + threadIdx.x] +
+                               red[3 * SPLASH_NDIAG_K + threadIdx.x];
+                    a.diag_part[((size_t)blockIdx.x * a.nmonth + m) * SPLASH_NDIAG_K + threadIdx.x] += s;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; q++) dg[q] = 0.0;
+            }
+        }
+        swv = swn;
+        tcv = tcn;
+        pnv = pnn;
+    }
+    if (valid) {
+        a.state[ci] = st.wn;
+        a.state[a.lds + ci] = st.snow;
+        a.state[2 * a.lds + ci] = st.qin;
+        a.state[3 * a.lds + ci] = st.td;
+        a.state[4 * a.lds + ci] = st.nd;
+    }
+}
+
+// module mirror of run_all: daily series of all 11 outputs for a handful of cells
+__global__ __launch_bounds__(64) void k_run_all_mod(RunArgs a)
+{
+    size_t cell = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (cell >= a.ncell) return;
+    Forcing f{a.sw, a.tc, a.pn, a.snowfall, a.ldf, 0.0, 0.0, cell};
+    CellConst c;
+    cell_setup(c, a.par, a.ldp, cell, a.par[P_CELLOUT * a.ldp + cell]);
+    State st{a.state[cell], a.state[a.lds + cell], a.state[2 * a.lds + cell],
+             a.state[3 * a.lds + cell], a.state[4 * a.lds + cell]};
+    for (int t = 0; t < a.nt; t++) {
+        const DayRec d = a.days[t];
+        double swv, tcv, pnv, rain, snf;
+        f.raw(t, swv, tcv, pnv);
+        f.split(d, t, tcv, pnv, rain, snf);
+        DayOut o;
+        day_step(c, day_const(d), swv, tcv, rain, snf, st, o);
+        size_t k = (size_t)t * a.ldo + cell;
+        const double v[8] = {st.wn, o.ro, o.pet, o.aet, st.snow, o.cond, o.bflow, o.netr};
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (a.out[q]) a.out[q][k] = v[q];
+        if (a.extra[0]) a.extra[0][k] = st.qin;
+        if (a.extra[1]) a.extra[1][k] = st.td;
+        if (a.extra[2]) a.extra[2][k] = st.nd;
+    }
+}
+
+// fixed-order reduction of the per-workgroup diagnostic partials: diag[m][k] += sum_b part[b][m][k]
+__global__ void k_diag_reduce(const double* __restrict__ part, size_t nblocks, int nmonth,
+                              double* __restrict__ diag)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nmonth * SPLASH_NDIAG_K) return;
+    double s = 0.0;
+    for (size_t b = 0; b < nblocks; b++) s += part[b * (size_t)nmonth * SPLASH_NDIAG_K + e];
+    diag[e] += s;
+}
+
+// ================================================================ test hooks ===================
+// SOLAR+EVAP for independent rows (src/EVAP.cpp:82-264)
+__global__ __launch_bounds__(kBlock) void k_evap_batch(size_t m, const double* lat,
+                                                      const double* elv, const double* sw,
+                                                      const double* dr, const double* sd,
+                                                      const double* cd, const double* sw_in,
+                                                      const double* tc, const double* slop,
+                                                      const double* asp, const double* snow,
+                                                      const double* nd, double* out)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    CellConst c;
+    double sl = sin(lat[i] * kPir), cl = cos(lat[i] * kPir);
+    double ss = sin(slop[i] * kPir), cs = cos(slop[i] * kPir);
+    double sa = sin(asp[i] * kPir), ca = cos(asp[i] * kPir);
+    c.ka = cl * ss * ca - sl * cs;
+    c.kb = cl * cs + sl * ss * ca;
+    c.kc = ss * sa;
+    c.tau_o = (kC + kD) * (1.0 + (2.67e-5) * elv[i]);
+    double ep = (kG * kMa) / (kR * kL);
+    c.patm = pow((1.0 - elv[i] * kL / kTo), ep) * kPo;
+    c.patm_f = (float)c.patm;
+    DayConst d{dr[i], sd[i], cd[i], 0.0, 1.0};
+    Etr e;
+    evap_day(c, d, sw[i], sw_in[i], tc[i], snow[i], nd[i], e);
+    double* o = out + i * 11;
+    o[0] = e.cond;
+    o[1] = e.pet; // eet == pet (src/EVAP.cpp:140)
+    o[2] = e.pet;
+    o[3] = e.aet;
+    o[4] = e.snowmelt;
+    o[5] = e.sublimation;
+    o[6] = e.econ;
+    o[7] = e.pw;
+    o[8] = e.rn_d;
+    o[9] = e.visc;
+    o[10] = e.pet_max;
+}
+
+// general-argument forms of the two exported helper methods (src/SPLASH.cpp:1921-1961, 1963-2023)
+__global__ void k_moist_surf(double depth, double z, double bub_p, double wn, double SAT,
+                             double RES, double lambda, double* out)
+{
+    double theta_r = RES / (depth * 1000.0);
+    double theta_s = SAT / (depth * 1000.0);
+    double bubbling_pr = bub_p / 10;
+    double theta_mean = (wn) / (depth * 1000.0);
+    double water_pot_BC =
+        bubbling_pr / pow((((theta_mean - theta_r) / (theta_s - theta_r))), (1 / lambda));
+    double total_head_BC = water_pot_BC + z;
+    double theta_BC =
+        (theta_s - theta_r) * pow((total_head_BC / bubbling_pr), (-1 * lambda)) + theta_r;
+    if (theta_mean < theta_r) {
+        theta_BC = theta_r;
+    } else if (isnan(theta_BC)) {
+        theta_BC = theta_s;
+    }
+    *out = theta_BC;
+}
+
+__global__ void k_inf_GA(double bub_press, double theta_i, double Ksat, double theta_s,
+                         double lambda, double P, double tdur, double slop, double* out)
+{
+    double r = P / tdur;
+    double h_f = ((2 + 3 * lambda) / (1 + 3 * lambda)) * (bub_press / 2);
+    double delta_head = h_f;
+    double delta_theta = (theta_s - theta_i);
+    double I = 0.0;
+    if (r <= Ksat) {
+        I = P;
+    } else {
+        if (delta_theta <= 0.0) {
+            I = Ksat * tdur;
+        } else {
+            double tp = (Ksat * delta_theta * -1.0 * delta_head) / (r * (r - Ksat));
+            if (tp <= 0.0 || isnan(tp)) tp = 0.01;
+            double cs = cos(slop * kPir);
+            double tp_s = tp / (cs * cs);
+            I = r * tp_s + (Ksat * (tdur - tp_s) -
+                            (delta_head * delta_theta *
+                             log(1 - (r * tp_s / (delta_head * delta_theta)))));
+        }
+    }
+    if (I > P) I = P;
+    *out = I;
+}
+
+// ================================================================ synthetic inputs =============
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double synth_u(uint64_t seed, uint64_t stream, uint64_t cell,
+                                          uint64_t day)
+{
+    uint64_t h = mix64(mix64(mix64(seed ^ stream) ^ cell) ^ day);
+    return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+enum { ST_ELEV = 1, ST_SLOP, ST_ASP, ST_AU, ST_NIN, ST_SAND, ST_CLAY, ST_OM, ST_GRAVEL, ST_BD,
+       ST_DEPTH, ST_DEPTH2, ST_TC = 20, ST_SW, ST_ROCC, ST_RAMT };
+
+__global__ __launch_bounds__(kBlock) void k_synth_statics(uint64_t seed, int H, int W,
+                                                         int64_t cell0, size_t ncell, int terrain,
+                                                         double* lat, double* elev, double* slop,
+                                                         double* asp, double* resolution,
+                                                         double* soil, double* au)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= ncell) return;
+    uint64_t c = (uint64_t)(cell0 + (int64_t)i);
+    int64_t r = (cell0 + (int64_t)i) / W;
+    lat[i] = 60.0 - 120.0 * ((double)r + 0.5) / (double)H;
+    resolution[i] = 250.0;
+    const double Ai = 62500.0;
+    if (terrain) {
+        elev[i] = 200.0 + 2800.0 * synth_u(seed, ST_ELEV, c, 0);
+        double u = synth_u(seed, ST_SLOP, c, 0);
+        slop[i] = 30.0 * u * u;
+        asp[i] = 360.0 * synth_u(seed, ST_ASP, c, 0);
+        au[i] = Ai * exp2(12.0 * synth_u(seed, ST_AU, c, 0));
+        au[ncell + i] = 1.0 + floor(3.0 * synth_u(seed, ST_NIN, c, 0));
+        au[2 * ncell + i] = 3.0;
+    } else {
+        elev[i] = 500.0;
+        slop[i] = 0.0;
+        asp[i] = 0.0;
+        au[i] = 0.0;
+        au[ncell + i] = 3.0;
+        au[2 * ncell + i] = 3.0;
+    }
+    double sand = 15.0 + 55.0 * synth_u(seed, ST_SAND, c, 0);
+    double cmax = 95.0 - sand;
+    if (cmax > 60.0) cmax = 60.0;
+    double clay = 8.0 + (cmax - 8.0) * synth_u(seed, ST_CLAY, c, 0);
+    double depth = 0.6 + 1.4 * synth_u(seed, ST_DEPTH, c, 0);
+    if (synth_u(seed, ST_DEPTH2, c, 0) < 0.1) depth = 2.0;
+    soil[i] = sand;
+    soil[ncell + i] = clay;
+    soil[2 * ncell + i] = 0.3 + 7.7 * synth_u(seed, ST_OM, c, 0);
+    soil[3 * ncell + i] = 40.0 * synth_u(seed, ST_GRAVEL, c, 0);
+    soil[4 * ncell + i] = 0.9 + 0.7 * synth_u(seed, ST_BD, c, 0);
+    soil[5 * ncell + i] = depth;
+}
+
+__global__ __launch_bounds__(kBlock) void k_synth_forcing(uint64_t seed,
+                                                         const DayRec* __restrict__ days, int t0,
+                                                         int nt, int64_t cell0, size_t ncell,
+                                                         const double* __restrict__ lat,
+                                                         const double* __restrict__ elev,
+                                                         double* sw_in, double* tc, double* pn,
+                                                         size_t ldf)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= ncell) return;
+    const double TWO_PI = 6.283185307179586;
+    const uint64_t c = (uint64_t)(cell0 + (int64_t)i);
+    const double la = lat[i], el = elev[i];
+    const double base = 25.0 * cos(la * kPir) - 5.0;
+    const double amp = (5.0 + 0.25 * fabs(la));
+    const double shift = 15.0 + (la < 0.0 ? 182.0 : 0.0);
+    for (int t = blockIdx.y; t < nt; t += gridDim.y) {
+        const uint64_t day = (uint64_t)(t0 + t);
+        const double n = (double)days[t].doy;
+        size_t k = (size_t)t * ldf + i;
+        double v = base - amp * cos(TWO_PI * (n - shift) / 365.0) - 0.0065 * el +
+                   3.0 * (synth_u(seed, ST_TC, c, day) - 0.5) * 2.0;
+        tc[k] = (double)(float)v;
+        double decl = 23.44 * sin(TWO_PI * (n - 80.0) / 365.0);
+        double s = 180.0 * cos((la - decl) * kPir) * (0.55 + 0.45 * synth_u(seed, ST_SW, c, day)) +
+                   10.0;
+        if (s < 5.0) s = 5.0;
+        if (s > 420.0) s = 420.0;
+        sw_in[k] = (double)(float)s;
+        double p = 0.0;
+        if (synth_u(seed, ST_ROCC, c, day) < 0.3)
+            p = -6.0 * log(1.0 - synth_u(seed, ST_RAMT, c, day));
+        pn[k] = (double)(float)p;
+    }
+}
+
+// ================================================================ launchers ===================
+static inline unsigned nblk(size_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+hipError_t launch_soil_hydro(size_t ncell, const double* lat, const double* elev,
+                             const double* slop, const double* asp, const double* resolution,
+                             const double* soil, const double* au, double* par, hipStream_t s)
+{
+    if (ncell == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_soil_hydro, dim3(nblk(ncell, kBlock)), dim3(kBlock), 0, s, ncell, lat,
+                       elev, slop, asp, resolution, soil, au, par);
+    return hipGetLastError();
+}
+
+hipError_t launch_snow_threshold(size_t ncell, int nt, const double* tc, size_t ldf,
+                                 const double* par, size_t ldp, double* Tt, hipStream_t s)
+{
+    if (ncell == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_snow_threshold, dim3(nblk(ncell, kBlock)), dim3(kBlock), 0, s, ncell, nt,
+                       tc, ldf, par, ldp, Tt);
+    return hipGetLastError();
+}
+
+hipError_t launch_spin_phase(const SpinPhaseArgs& a, hipStream_t s)
+{
+    if (a.ncell == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_spin_phase, dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_spin_up_mod(const SpinArgs& a, double* const* series_dev, size_t sld,
+                              const double* snowfall, hipStream_t s)
+{
+    if (a.ncell == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_spin_up_mod, dim3(nblk(a.ncell, 64)), dim3(64), 0, s, a, series_dev, sld,
+                       snowfall);
+    return hipGetLastError();
+}
+
+hipError_t launch_run_all(const RunArgs& a, hipStream_t s)
+{
+    if (a.ncell == 0 || a.nt == 0) return hipSuccess;
+    dim3 g(nblk(a.ncell, kBlock)), b(kBlock);
+    const bool diag = a.diag_part != nullptr;
+    if (a.monthly) {
+        if (diag)
+            hipLaunchKernelGGL((k_run_all<true, true>), g, b, 0, s, a);
+        else
+            hipLaunchKernelGGL((k_run_all<true, false>), g, b, 0, s, a);
+    } else {
+        if (diag)
+            hipLaunchKernelGGL((k_run_all<false, true>), g, b, 0, s, a);
+        else
+            hipLaunchKernelGGL((k_run_all<false, false>), g, b, 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_run_all_mod(const RunArgs& a, hipStream_t s)
+{
+    if (a.ncell == 0 || a.nt == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_run_all_mod, dim3(nblk(a.ncell, 64)), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_diag_reduce(const double* part, size_t nblocks, int nmonth, double* diag,
+                              hipStream_t s)
+{
+    int e = nmonth * SPLASH_NDIAG_K;
+    if (e == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_diag_reduce, dim3((e + 63) / 64), dim3(64), 0, s, part, nblocks, nmonth,
+                       diag);
+    return hipGetLastError();
+}
+
+size_t run_all_blocks(size_t ncell) { return nblk(ncell, kBlock); }
+
+hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, const double* sw,
+                             const double* dr, const double* sd, const double* cd,
+                             const double* sw_in, const double* tc, const double* slop,
+                             const double* asp, const double* snow, const double* nd, double* out,
+                             hipStream_t s)
+{
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_evap_batch, dim3(nblk(m, kBlock)), dim3(kBlock), 0, s, m, lat, elv, sw, dr,
+                       sd, cd, sw_in, tc, slop, asp, snow, nd, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_moist_surf(double depth, double z, double bub_p, double wn, double SAT,
+                             double RES, double lambda, double* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_moist_surf, dim3(1), dim3(1), 0, s, depth, z, bub_p, wn, SAT, RES, lambda,
+                       out);
+    return hipGetLastError();
+}
+
+hipError_t launch_inf_GA(double bub_press, double theta_i, double Ksat, double theta_s,
+                         double lambda, double P, double tdur, double slop, double* out,
+                         hipStream_t s)
+{
+    hipLaunchKernelGGL(k_inf_GA, dim3(1), dim3(1), 0, s, bub_press, theta_i, Ksat, theta_s, lambda,
+                       P, tdur, slop, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_statics(uint64_t seed, int H, int W, int64_t cell0, size_t ncell,
+                                int terrain, double* lat, double* elev, double* slop, double* asp,
+                                double* resolution, double* soil, double* au, hipStream_t s)
+{
+    if (ncell == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_synth_statics, dim3(nblk(ncell, kBlock)), dim3(kBlock), 0, s, seed, H, W,
+                       cell0, ncell, terrain, lat, elev, slop, asp, resolution, soil, au);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_forcing(uint64_t seed, const DayRec* days, int t0, int nt, int64_t cell0,
+                                size_t ncell, const double* lat, const double* elev, double* sw_in,
+                                double* tc, double* pn, size_t ldf, hipStream_t s)
+{
+    if (ncell == 0 || nt == 0) return hipSuccess;
+    unsigned gy = nt < 64 ? (unsigned)nt : 64u;
+    hipLaunchKernelGGL(k_synth_forcing, dim3(nblk(ncell, kBlock), gy), dim3(kBlock), 0, s, seed,
+                       days, t0, nt, cell0, ncell, lat, elev, sw_in, tc, pn, ldf);
+    return hipGetLastError();
+}
+
+} // namespace splash

@@ -1,0 +1,117 @@
+// splash_kernels.hpp -- argument blocks and launcher prototypes shared by the kernels
+// (splash_kernels.hip) and the C ABI (splash_capi.hip).  Internal; not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace splash {
+
+#define SPLASH_NDIAG_K 6
+
+// rows of the cell-parameter array cellpar[SPLASH_NPAR][ncell] (see include/splash_hip.h)
+enum {
+    P_LAT = 0, P_ELV, P_SLOP, P_ASP /* already asp-180 */,
+    P_SAT, P_WP, P_FC, P_KSAT, P_LAMBDA, P_DEPTH, P_BUB, P_RES, P_AU, P_AI, P_CELLIN, P_CELLOUT,
+    P_WMAXR, P_NPAR
+};
+
+// one calendar day of the shared per-day table (uniform index => scalar loads)
+struct DayRec {
+    double dr, sd, cd;   // orbit: distance factor, sin/cos of declination (src/SOLAR.cpp:114-124)
+    double ttm_s, trm14; // month factors of frain_func (R/splash.point.R:549-550)
+    int month_id;        // running month number since the first day of the calendar
+    int mdays;           // days of that month present in the calendar
+    int flags;           // bit0: last calendar day of its month
+    int doy;             // day of year (synthetic generator)
+};
+
+struct SpinArgs {
+    const DayRec* days; // first 365 days
+    int n;
+    size_t ncell;
+    const double *sw, *tc, *pn;
+    size_t ldf;
+    const double* Tt;
+    double* par;
+    size_t ldp;
+    double* state;
+    size_t lds;
+    int* passes;
+};
+
+// one phase of the grid spin-up (see k_spin_phase)
+struct SpinPhaseArgs {
+    const DayRec* days; // first 365 days
+    int n;
+    size_t ncell;
+    const double *sw, *tc, *pn;
+    size_t ldf;
+    const double* Tt;
+    double* par;
+    size_t ldp;
+    double* state; // final state, and parking space of unfinished jobs
+    size_t lds;
+    int* passes;            // optional [2][ncell]
+    const uint32_t* wl_in;  // cell ids of this phase (NULL: all cells, phase 0)
+    const uint32_t* n_in;   // device-side length of wl_in (NULL: ncell)
+    uint32_t* wl_out;       // cells that need another phase
+    uint32_t* n_out;
+    int* meta;              // [ncell] (stage << 16) | pass count of parked jobs
+    double* ai;             // [ncell] aridity index
+    int budget;             // passes per job in this phase
+    int fresh;              // phase 0
+};
+
+struct RunArgs {
+    const DayRec* days; // day t0 onwards
+    int nt;
+    size_t ncell;
+    const double *sw, *tc, *pn, *snowfall; // snowfall != NULL: explicit split (module mirror)
+    size_t ldf;
+    const double* Tt;
+    const double* par;
+    size_t ldp;
+    double* state;
+    size_t lds;
+    double* out[9];
+    double* extra[3]; // module mirror only: qin_prev, tdrain, snwage
+    size_t ldo;
+    int monthly;
+    int month0;       // month_id of day t0
+    int head_partial; // month0 began before t0 (add to the stored partial)
+    double* diag_part;
+    int nmonth;
+};
+
+hipError_t launch_soil_hydro(size_t ncell, const double* lat, const double* elev,
+                             const double* slop, const double* asp, const double* resolution,
+                             const double* soil, const double* au, double* par, hipStream_t s);
+hipError_t launch_snow_threshold(size_t ncell, int nt, const double* tc, size_t ldf,
+                                 const double* par, size_t ldp, double* Tt, hipStream_t s);
+hipError_t launch_spin_phase(const SpinPhaseArgs& a, hipStream_t s);
+hipError_t launch_spin_up_mod(const SpinArgs& a, double* const* series_dev, size_t sld,
+                              const double* snowfall, hipStream_t s);
+hipError_t launch_run_all(const RunArgs& a, hipStream_t s);
+hipError_t launch_run_all_mod(const RunArgs& a, hipStream_t s);
+hipError_t launch_diag_reduce(const double* part, size_t nblocks, int nmonth, double* diag,
+                              hipStream_t s);
+size_t run_all_blocks(size_t ncell);
+hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, const double* sw,
+                             const double* dr, const double* sd, const double* cd,
+                             const double* sw_in, const double* tc, const double* slop,
+                             const double* asp, const double* snow, const double* nd, double* out,
+                             hipStream_t s);
+hipError_t launch_moist_surf(double depth, double z, double bub_p, double wn, double SAT,
+                             double RES, double lambda, double* out, hipStream_t s);
+hipError_t launch_inf_GA(double bub_press, double theta_i, double Ksat, double theta_s,
+                         double lambda, double P, double tdur, double slop, double* out,
+                         hipStream_t s);
+hipError_t launch_synth_statics(uint64_t seed, int H, int W, int64_t cell0, size_t ncell,
+                                int terrain, double* lat, double* elev, double* slop, double* asp,
+                                double* resolution, double* soil, double* au, hipStream_t s);
+hipError_t launch_synth_forcing(uint64_t seed, const DayRec* days, int t0, int nt, int64_t cell0,
+                                size_t ncell, const double* lat, const double* elev, double* sw_in,
+                                double* tc, double* pn, size_t ldf, hipStream_t s);
+
+} // namespace splash

@@ -1,0 +1,64 @@
+import csv
+import datetime
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle.binding import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def bourne():
+    """the reference's bundled example site (data/Bourne.RData -> tests/golden, README.md:28-61)"""
+    rows = list(csv.DictReader(open(os.path.join(GOLD, "bourne_forcing.csv"))))
+    site = json.load(open(os.path.join(GOLD, "bourne_site.json")))
+    dates = [datetime.date.fromisoformat(r["date"]) for r in rows]
+    d = dict(
+        dates=np.array(dates, dtype="datetime64[D]"),
+        doy=np.array([x.timetuple().tm_yday for x in dates], np.int32),
+        year=np.array([x.year for x in dates], np.int32),
+        month=np.array([x.month for x in dates], np.int32),
+        P=np.array([float(r["P"]) for r in rows]),
+        Ta=np.array([float(r["Ta"]) for r in rows]),
+        sw_in=np.array([float(r["sw_in"]) for r in rows]),
+        soil=np.array([np.nan if v is None else v for v in site["soil"]]),
+        site=site,
+    )
+    d["month_id"] = ((d["year"] - d["year"][0]) * 12 + d["month"] - 1).astype(np.int32)
+    d["nmonth"] = int(d["month_id"][-1]) + 1
+    return d
+
+
+@pytest.fixture(scope="session")
+def kat():
+    return dict(np.load(os.path.join(GOLD, "ref_evap_kat.npz")))
+
+
+def rel_err(x, ref, floor=1e-9):
+    """max relative error where |ref| > floor, max abs error elsewhere"""
+    x, ref = np.asarray(x, float), np.asarray(ref, float)
+    assert x.shape == ref.shape
+    nanx, nanr = np.isnan(x), np.isnan(ref)
+    assert (nanx == nanr).all(), f"NaN pattern differs: {nanx.sum()} vs {nanr.sum()}"
+    ok = ~nanr
+    big = ok & (np.abs(ref) > floor)
+    rel = float(np.max(np.abs(x[big] - ref[big]) / np.abs(ref[big]))) if big.any() else 0.0
+    small = ok & ~big
+    ab = float(np.max(np.abs(x[small] - ref[small]))) if small.any() else 0.0
+    return rel, ab

@@ -1,0 +1,331 @@
+"""GPU suite: the HIP path, called through the C ABI, against the oracle on identical inputs.
+
+Tolerance (BASELINE.json north_star): wn, snow, ro, aet, pet within 1e-5 relative of the
+reference.  Relative error is taken where |ref| > 1e-9 mm; below that the absolute error must be
+< 1e-12 (exact-zero reference entries stay zero).  Index-like quantities (spin-up pass counts,
+snow age, NaN patterns, viscosity float bit patterns) must match exactly.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5     # north_star tolerance
+ATOL0 = 1e-12   # for |ref| <= 1e-9
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available(), "GPU suite needs a GPU"
+    import rsplash_amd
+    rsplash_amd.build_library()
+    from rsplash_amd import api as a
+    assert a.device_count() >= 1
+    return a
+
+
+def close(x, ref, name="", rtol=RTOL):
+    rel, ab = rel_err(x, ref)
+    assert rel <= rtol and ab <= ATOL0, f"{name}: rel {rel:.3e} abs-at-zero {ab:.3e}"
+    return rel
+
+
+# ---------------------------------------------------------------- SOLAR + EVAP vs the REAL reference
+def test_evap_vs_reference_kat(api, kat):
+    k = kat
+    out = api.evap_batch(k["lat"], k["elv"], k["sw"], k["n"], k["y"], k["sw_in"], k["tc"],
+                         k["slop"], k["asp"], k["snow"], k["nd"])
+    ref = k["evap"]
+    # viscosity (float emulation): identical bit patterns
+    v = out[:, 9].astype(np.float32).view(np.uint32)
+    vr = ref[:, 9].astype(np.float32).view(np.uint32)
+    assert (v == vr).mean() == 1.0, f"viscosity bit mismatches: {(v != vr).sum()} of {len(v)}"
+    assert np.array_equal(out[:, 9], ref[:, 9])
+    for j, name in enumerate(("cond", "eet", "pet", "aet", "snowmelt", "sublimation", "econ", "pw",
+                              "rn_d", "visc", "pet_max")):
+        scale = np.maximum(np.abs(ref[:, j]), 1e-6 * np.abs(ref[:, j]).max())
+        err = np.max(np.abs(out[:, j] - ref[:, j]) / scale)
+        assert err < 1e-9, f"{name}: {err:.3e}"
+
+
+def test_viscosity_bits_dense_sweep(api, oracle):
+    """all daily temperatures the forcing can take, several pressures: float bit patterns"""
+    tc = np.tile(np.linspace(-35, 48, 60000).astype(np.float32).astype(np.float64), 3)
+    elv = np.repeat([0.0, 1783.08, 4500.0], 60000)
+    m = len(tc)
+    z = np.zeros(m)
+    n = np.full(m, 100, np.int32)
+    y = np.full(m, 2001, np.int32)
+    args = (np.full(m, 40.0), elv, np.full(m, 0.5), n, y, np.full(m, 150.0), tc, z, z, z, z)
+    out = api.evap_batch(*args)
+    ref = oracle.evap_batch(*args)
+    bad = out[:, 9] != ref[:, 9]
+    assert bad.sum() == 0, f"{bad.sum()} viscosity mismatches of {m}"
+
+
+# ---------------------------------------------------------------- module mirrors
+def test_moist_surf_and_inf_GA(api, oracle):
+    rng = np.random.default_rng(3)
+    L = oracle.lib
+    for _ in range(200):
+        depth = rng.uniform(0.6, 2.0)
+        SAT, RES = rng.uniform(200, 600), rng.uniform(10, 60)
+        wn = rng.choice([RES, SAT, rng.uniform(RES, SAT), RES - 1.0])
+        lam, bub = rng.uniform(0.1, 0.6), -rng.uniform(100, 3000)
+        a = api.SPLASH.moist_surf(depth, 10.0, bub, wn, SAT, RES, lam)
+        b = L.orc_moist_surf(depth, 10.0, bub, wn, SAT, RES, lam)
+        assert a == pytest.approx(b, rel=1e-12)
+        th_s = SAT / (depth * 1000)
+        th_i = rng.choice([th_s, th_s * rng.uniform(0.1, 0.99), th_s + 0.01])
+        Ks = rng.uniform(0.05, 40)
+        P = rng.choice([0.0, rng.uniform(0, 5), rng.uniform(5, 300)])
+        slop = rng.choice([0.0, rng.uniform(0, 60)])
+        a = api.SPLASH.inf_GA(bub, th_i, Ks, th_s, lam, P, 6.0, slop)
+        b = L.orc_inf_GA(bub, th_i, Ks, th_s, lam, P, 6.0, slop)
+        assert a == pytest.approx(b, rel=1e-11, abs=1e-300)
+
+
+def _bourne_prelude(oracle, b):
+    s = b["site"]
+    si, wmax_r = oracle.soil_info(b["soil"], [s["Aups_250m"], 3, 3], s["resolution"])
+    Tt, rain, snowf = oracle.snow_partition(b["Ta"], b["P"], b["month"], s["latitude"], s["elev_m"])
+    return si, rain, snowf
+
+
+def test_module_spin_up_and_run_all_bourne(api, oracle, bourne):
+    b, s = bourne, bourne["site"]
+    si, rain, snowf = _bourne_prelude(oracle, b)
+    asp = s["asp_250m"] - 180
+    sp = api.SPLASH(s["latitude"], s["elev_m"])
+    g = sp.spin_up(365, int(b["year"][0]), b["sw_in"][:365], b["Ta"][:365], rain[:365],
+                   s["slop_250m"], asp, snowf[:365], si)
+    o = oracle.spin_up(s["latitude"], s["elev_m"], 365, int(b["year"][0]), b["sw_in"][:365],
+                       b["Ta"][:365], rain[:365], s["slop_250m"], asp, snowf[:365], si)
+    assert g["passes"] == o["passes"]
+    for k in ("sm", "snow", "qin", "tdrain", "ro", "pet"):
+        close(g[k], o[k], "spin_up." + k)
+    assert np.array_equal(g["snwage"], o["snwage"])
+    r = sp.run_all(b["doy"], b["year"], b["sw_in"], b["Ta"], rain, o["sm"][-1], s["slop_250m"],
+                   asp, o["snow"][-1], snowf, si, o["qin"][-1], o["tdrain"][-1], o["snwage"][-1])
+    q = oracle.run_all(s["latitude"], s["elev_m"], b["doy"], b["year"], b["sw_in"], b["Ta"], rain,
+                       o["sm"][-1], s["slop_250m"], asp, o["snow"][-1], snowf, si, o["qin"][-1],
+                       o["tdrain"][-1], o["snwage"][-1])
+    for k in ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "qin_prev", "tdrain"):
+        close(r[k], q[k], "run_all." + k)
+    assert np.array_equal(r["snwage"], q["snwage"])
+
+
+# ---------------------------------------------------------------- splash.point (BASELINE config 0)
+@pytest.mark.parametrize("flat", [False, True])
+@pytest.mark.parametrize("monthly", [False, True])
+def test_splash_point_bourne(api, oracle, bourne, flat, monthly):
+    b, s = bourne, bourne["site"]
+    slop, asp = (0.0, 0.0) if flat else (s["slop_250m"], s["asp_250m"])
+    g = api.splash_point(b["sw_in"], b["Ta"], b["P"], s["latitude"], s["elev_m"], slop, asp,
+                         b["soil"], s["Aups_250m"], s["resolution"], time_index=b["dates"],
+                         monthly_out=monthly)
+    o, aux = oracle.point(b["doy"], b["year"], b["month"], b["month_id"], b["nmonth"], b["sw_in"],
+                          b["Ta"], b["P"], s["latitude"], s["elev_m"], slop, asp, b["soil"],
+                          [s["Aups_250m"], 3, 3], s["resolution"], monthly_out=monthly)
+    worst = {k: close(g[k], o[k], f"point[{'flat' if flat else 'slope'}].{k}") for k in o}
+    print("max rel err", {k: f"{v:.2e}" for k, v in worst.items()})
+    print("max |dwn| =", np.max(np.abs(g["wn"] - o["wn"])))
+
+
+# ---------------------------------------------------------------- splash.grid
+def _synth(oracle, H, W, nt, terrain, seed=20221130):
+    doy, year, month, mid, nm = oracle.calendar(2001, nt)
+    st = oracle.synth_statics(seed, H, W, 0, H * W, terrain)
+    sw, tc, pn = oracle.synth_forcing(seed, H, W, 0, H * W, 0, doy, st["lat"], st["elev"])
+    dates = np.datetime64("2001-01-01") + np.arange(nt)
+    return dict(doy=doy, year=year, month=month, mid=mid, nm=nm, st=st, sw=sw, tc=tc, pn=pn,
+                dates=dates)
+
+
+@pytest.mark.parametrize("terrain,monthly", [(0, False), (1, False), (1, True)])
+def test_splash_grid_synthetic(api, oracle, terrain, monthly):
+    H, W, nt = 12, 32, 730
+    d = _synth(oracle, H, W, nt, terrain)
+    st = d["st"]
+    g = api.splash_grid(d["sw"], d["tc"], d["pn"], st["elev"], st["soil"], st["lat"], st["slop"],
+                        st["asp"], st["au"], st["resolution"], time_index=d["dates"],
+                        sim_control=dict(monthly_out=monthly), want_aux=True, want_diag=True)
+    o, aux = oracle.grid(d["doy"], d["year"], d["month"], d["mid"], d["nm"], d["sw"], d["tc"],
+                         d["pn"], st["lat"], st["elev"], st["slop"], st["asp"], st["soil"],
+                         st["au"], st["resolution"], monthly_out=monthly)
+    assert np.array_equal(g["aux"]["Tt"], aux["Tt"])
+    assert np.array_equal(g["aux"]["passes1"], aux["passes1"])
+    assert np.array_equal(g["aux"]["passes2"], aux["passes2"])
+    close(g["aux"]["AI"], aux["AI"], "AI", rtol=1e-10)
+    worst = {k: close(g[k], o[k], f"grid[{terrain},{monthly}].{k}") for k in o}
+    print("max rel err", {k: f"{v:.2e}" for k, v in worst.items()})
+    close(g["state_end"][[0, 1, 2]], aux["state1"].T[[0, 1, 2]], "state_end")
+    assert np.array_equal(g["state_end"][4], aux["state1"][:, 4])
+    # diagnostics: monthly grid totals == sums over the oracle's cells
+    if not monthly:
+        for k in ("aet", "ro", "bflow"):
+            ref = np.array([o[k][d["mid"] == m].sum() for m in range(d["nm"])])
+            assert np.allclose(g["diag"][k], ref, rtol=1e-9), k
+        last = np.array([np.where(d["mid"] == m)[0][-1] for m in range(d["nm"])])
+        assert np.allclose(g["diag"]["wn"], o["wn"][last].sum(1), rtol=1e-10)
+        assert np.allclose(g["diag"]["snow"], o["snow"][last].sum(1), rtol=1e-9, atol=1e-9)
+
+
+def test_splash_grid_na_cells_and_blocking(api, oracle):
+    """NA cells (72 % of the reference's SA_cru example) come back NaN; results do not depend on
+    how the grid is cut into launches"""
+    H, W, nt = 8, 40, 400
+    d = _synth(oracle, H, W, nt, 1)
+    st = d["st"]
+    rng = np.random.default_rng(5)
+    mask = rng.random(H * W) < 0.6
+    mask[:3] = True
+    sw, tc, pn = d["sw"].copy(), d["tc"].copy(), d["pn"].copy()
+    elev = st["elev"].copy()
+    sw[:, mask] = np.nan
+    tc[:, mask] = np.nan
+    pn[:, mask] = np.nan
+    elev[mask] = np.nan
+    kw = dict(time_index=d["dates"], sim_control=dict(monthly_out=False))
+    g = api.splash_grid(sw, tc, pn, elev, st["soil"], st["lat"], st["slop"], st["asp"], st["au"],
+                        st["resolution"], **kw)
+    for k in ("wn", "ro", "pet", "aet", "snow"):
+        assert np.isnan(g[k][:, mask]).all() and np.isfinite(g[k][:, ~mask]).all()
+    full = api.splash_grid(d["sw"], d["tc"], d["pn"], st["elev"], st["soil"], st["lat"],
+                           st["slop"], st["asp"], st["au"], st["resolution"], **kw)
+    blk = api.splash_grid(d["sw"], d["tc"], d["pn"], st["elev"], st["soil"], st["lat"], st["slop"],
+                          st["asp"], st["au"], st["resolution"], max_cells_per_launch=100, **kw)
+    for k in ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "sm_lim"):
+        assert np.array_equal(full[k][:, ~mask], g[k][:, ~mask]), k
+        assert np.array_equal(full[k], blk[k]), k
+
+
+# ---------------------------------------------------------------- device-resident stages
+def test_device_pipeline_chunking_and_generator(api, oracle):
+    """splash_dev_*: (i) the device generator reproduces the oracle's generator, (ii) a run cut
+    into time chunks (state carried in HBM) equals the single run bit for bit, (iii) monthly
+    output of a chunked run equals the aggregation of the daily run."""
+    import torch
+    dev = torch.device("cuda:0")
+    H, W, nt, seed = 16, 64, 800, 20221130
+    n = H * W
+    doy, year, month, mid, nm = oracle.calendar(2001, nt)
+    cal = api.Calendar(doy, year, month)
+    f64 = dict(dtype=torch.float64, device=dev)
+    lat, elev, slop, asp, res = (torch.empty(n, **f64) for _ in range(5))
+    soil, au = torch.empty(6, n, **f64), torch.empty(3, n, **f64)
+    api.dev_synth_statics(seed, H, W, 0, n, 1, lat, elev, slop, asp, res, soil, au)
+    sw, tc, pn = (torch.empty(nt, n, **f64) for _ in range(3))
+    api.dev_synth_forcing(seed, cal, 0, nt, 0, n, lat, elev, sw, tc, pn, n)
+    torch.cuda.synchronize()
+    st = oracle.synth_statics(seed, H, W, 0, n, 1)
+    osw, otc, opn = oracle.synth_forcing(seed, H, W, 0, n, 0, doy, st["lat"], st["elev"])
+    for k, t in (("lat", lat), ("elev", elev), ("slop", slop), ("asp", asp)):
+        assert np.allclose(t.cpu().numpy(), st[k], rtol=1e-15, atol=0), k
+    assert np.allclose(soil.cpu().numpy(), st["soil"], rtol=1e-15)
+    assert np.allclose(au.cpu().numpy(), st["au"], rtol=1e-14)
+    for a, b in ((sw, osw), (tc, otc), (pn, opn)):
+        a = a.cpu().numpy()
+        ulp = np.abs(a - b) / np.maximum(np.abs(np.spacing(b.astype(np.float32))), 1e-45)
+        assert (a == b).mean() > 0.9999 and ulp.max() <= 1.0
+
+    par = torch.empty(api.NPAR, n, **f64)
+    Tt = torch.empty(n, **f64)
+    state = torch.empty(api.NSTATE, n, **f64)
+    api.dev_soil_hydro(n, lat, elev, slop, asp, res, soil, au, par)
+    api.dev_snow_threshold(n, nt, tc, n, par, n, Tt)
+    work = torch.empty(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
+    passes = torch.zeros(2, n, dtype=torch.int32, device=dev)
+    api.dev_spin_up(cal, n, sw, tc, pn, n, Tt, par, n, state, n, work, passes=passes)
+    torch.cuda.synchronize()
+    assert int(passes.min()) >= 2 and int(passes.max()) <= 1000
+    state0 = state.clone()
+    names = ("wn", "snow", "ro", "aet", "pet")
+    one = {k: torch.empty(nt, n, **f64) for k in names}
+    api.dev_run_all(cal, 0, nt, n, sw, tc, pn, n, Tt, par, n, state, n, one, n)
+    end1 = state.clone()
+    # (ii) three uneven chunks, second one on a sub-range of cells pointers (ld > ncell)
+    state.copy_(state0)
+    chk = {k: torch.empty(nt, n, **f64) for k in names}
+    for t0, t1 in ((0, 45), (45, 400), (400, nt)):
+        outs = {k: chk[k][t0:] for k in names}
+        api.dev_run_all(cal, t0, t1 - t0, n, sw[t0:], tc[t0:], pn[t0:], n, Tt, par, n, state, n,
+                        outs, n)
+    torch.cuda.synchronize()
+    for k in names:
+        assert torch.equal(one[k], chk[k]), k
+    assert torch.equal(end1[:3], state[:3]) and torch.equal(end1[4], state[4])
+    # (iii) monthly, chunked at non-month boundaries
+    state.copy_(state0)
+    mon = {k: torch.zeros(nm, n, **f64) for k in names}
+    for t0, t1 in ((0, 45), (45, 400), (400, nt)):
+        m0 = int(mid[t0])
+        outs = {k: mon[k][m0:] for k in names}
+        api.dev_run_all(cal, t0, t1 - t0, n, sw[t0:], tc[t0:], pn[t0:], n, Tt, par, n, state, n,
+                        outs, n, monthly=True)
+    torch.cuda.synchronize()
+    midt = torch.as_tensor(mid.astype(np.int64), device=dev)
+    for k in names:
+        agg = torch.zeros(nm, n, **f64).index_add_(0, midt, one[k])
+        if k in ("wn", "snow"):
+            cnt = torch.bincount(midt, minlength=nm).to(torch.float64)
+            agg = agg / cnt[:, None]
+        assert torch.allclose(mon[k], agg, rtol=1e-12, atol=1e-12), k
+    # row-block partition == whole grid (what each rank of a multi-GPU run computes)
+    state.copy_(state0)
+    half = n // 2
+    part = {k: torch.empty(nt, n, **f64) for k in names}
+    for c0, c1 in ((0, half), (half, n)):
+        outs = {k: part[k][:, c0:] for k in names}
+        api.dev_run_all(cal, 0, nt, c1 - c0, sw[:, c0:], tc[:, c0:], pn[:, c0:], n, Tt[c0:],
+                        par[:, c0:], n, state[:, c0:], n, outs, n)
+    torch.cuda.synchronize()
+    for k in names:
+        assert torch.equal(one[k], part[k]), k
+    cal.close()
+
+
+def test_config1_flat_256x256_properties(api):
+    """BASELINE configs[1] size (256x256 flat, 365 d), GPU only: size-independent properties.
+    Idempotence (same inputs -> same bits), bounds (RES <= wn <= SAT, 0 <= sm_lim <= 1, snow,
+    ro, aet, pet >= 0) and no NaN in the five headline outputs."""
+    import torch
+    dev = torch.device("cuda:0")
+    H = W = 256
+    n, nt, seed = H * W, 365, 20221130
+    dates = np.datetime64("2001-01-01") + np.arange(nt)
+    cal = api.Calendar.from_dates(dates)
+    f64 = dict(dtype=torch.float64, device=dev)
+    lat, elev, slop, asp, res = (torch.empty(n, **f64) for _ in range(5))
+    soil, au = torch.empty(6, n, **f64), torch.empty(3, n, **f64)
+    api.dev_synth_statics(seed, H, W, 0, n, 0, lat, elev, slop, asp, res, soil, au)
+    sw, tc, pn = (torch.empty(nt, n, **f64) for _ in range(3))
+    api.dev_synth_forcing(seed, cal, 0, nt, 0, n, lat, elev, sw, tc, pn, n)
+    par = torch.empty(api.NPAR, n, **f64)
+    Tt = torch.empty(n, **f64)
+    api.dev_soil_hydro(n, lat, elev, slop, asp, res, soil, au, par)
+    api.dev_snow_threshold(n, nt, tc, n, par, n, Tt)
+    runs = []
+    for _ in range(2):
+        state = torch.empty(api.NSTATE, n, **f64)
+        p = par.clone()
+        work = torch.empty(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
+        api.dev_spin_up(cal, n, sw, tc, pn, n, Tt, p, n, state, n, work)
+        out = {k: torch.empty(nt, n, **f64) for k in ("wn", "snow", "ro", "aet", "pet", "sm_lim")}
+        api.dev_run_all(cal, 0, nt, n, sw, tc, pn, n, Tt, p, n, state, n, out, n)
+        torch.cuda.synchronize()
+        runs.append((out, p))
+    a, b = runs[0][0], runs[1][0]
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        assert torch.isfinite(a[k]).all(), k
+    p = runs[0][1]
+    SAT, RES = p[4], p[11]
+    assert (a["wn"] <= SAT[None] * (1 + 1e-15)).all() and (a["wn"] >= RES[None] * (1 - 1e-15)).all()
+    assert (a["sm_lim"] >= 0).all() and (a["sm_lim"] <= 1).all()
+    for k in ("snow", "ro", "aet", "pet"):
+        assert (a[k] >= 0).all(), k
+    cal.close()

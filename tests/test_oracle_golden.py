@@ -1,0 +1,195 @@
+"""CPU suite, part 1: the oracle against the golden vectors.
+
+* SOLAR / EVAP: the oracle must reproduce, bit for bit, the outputs of the REAL reference classes
+  stored in tests/golden/ref_evap_kat.npz (made by tools/make_golden.py from oracle/_ref), and --
+  when oracle/_ref is present -- a fresh random sweep of the live reference library.
+* Bourne (BASELINE config 0): regression of the oracle's splash.point run + agreement with the
+  numbers SURVEY.md 8(c) recorded from running the unmodified reference C++.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+
+
+def test_evap_solar_bit_exact_vs_reference_kat(oracle, kat):
+    k = kat
+    e = oracle.evap_batch(k["lat"], k["elv"], k["sw"], k["n"], k["y"], k["sw_in"], k["tc"],
+                          k["slop"], k["asp"], k["snow"], k["nd"])
+    s = oracle.solar_batch(k["lat"], k["elv"], k["n"], k["y"], k["sw_in"], k["tc"], k["slop"],
+                           k["asp"], k["snow"], k["nd"], k["sw"])
+    assert np.array_equal(e, k["evap"], equal_nan=True)
+    assert np.array_equal(s, k["solar"], equal_nan=True)
+
+
+def test_evap_solar_bit_exact_vs_live_reference(oracle):
+    from oracle.binding import Ref
+    if not Ref.available():
+        pytest.skip("oracle/_ref not built and no reference tree")
+    r = Ref()
+    rng = np.random.default_rng(7)
+    m = 200000
+    lat = rng.uniform(-89, 89, m)
+    elv = rng.uniform(0, 5000, m)
+    sw = rng.uniform(0, 1.2, m)
+    n = rng.integers(1, 367, m).astype(np.int32)
+    y = rng.choice([0, 2001, 2004, 1999, 2100], m).astype(np.int32)
+    sw_in = np.where(rng.random(m) < 0.05, 0.0, rng.uniform(0, 450, m))
+    tc = rng.uniform(-40, 45, m)
+    slop = np.where(rng.random(m) < 0.3, 0.0, rng.uniform(0, 60, m))
+    asp = rng.uniform(-180, 180, m)
+    snow = np.where(rng.random(m) < 0.5, 0.0, rng.uniform(0, 800, m))
+    nd = np.floor(rng.uniform(0, 40, m))
+    a = oracle.evap_batch(lat, elv, sw, n, y, sw_in, tc, slop, asp, snow, nd)
+    b = r.evap_batch(lat, elv, sw, n, y, sw_in, tc, slop, asp, snow, nd)
+    assert np.array_equal(a, b, equal_nan=True)
+    a = oracle.solar_batch(lat, elv, n, y, sw_in, tc, slop, asp, snow, nd, sw)
+    b = r.solar_batch(lat, elv, n, y, sw_in, tc, slop, asp, snow, nd, sw)
+    assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_expf_algorithm_matches_glibc():
+    """the expf restatement used on the device (table + cubic, glibc e_expf.c) == libm expf"""
+    from decimal import Decimal, getcontext
+    import struct
+    getcontext().prec = 60
+    N = 32
+    T = []
+    for i in range(N):
+        v = float(Decimal(2) ** (Decimal(i) / Decimal(N)))
+        bits = struct.unpack("<Q", struct.pack("<d", v))[0]
+        T.append((bits - (i << 47)) & 0xFFFFFFFFFFFFFFFF)
+    # the table literal in the device header must be this table
+    src = open(os.path.join(os.path.dirname(GOLD), "..", "rsplash_amd", "csrc",
+                            "splash_device.hpp")).read()
+    body = src[src.index("kExp2fTab[32] = {"):]
+    body = body[:body.index("};")]
+    lits = [int(x.strip(",").rstrip("ULL"), 16) for x in body.replace("{", " ").split()
+            if x.strip(",").startswith("0x")]
+    assert lits == T
+    Tn = np.array(T, dtype=np.uint64)
+    InvLn2N = float.fromhex("0x1.71547652b82fep+0") * N
+    SHIFT = float.fromhex("0x1.8p+52")
+    C0 = float.fromhex("0x1.c6af84b912394p-5") / N / N / N
+    C1 = float.fromhex("0x1.ebfce50fac4f3p-3") / N / N
+    C2 = float.fromhex("0x1.62e42ff0c52d6p-1") / N
+    lo, hi = np.float32(0.0).view(np.uint32), np.float32(8.0).view(np.uint32)
+    x = np.arange(lo, hi, 2003, dtype=np.uint32).view(np.float32)
+    xd = x.astype(np.float64)
+    z = InvLn2N * xd
+    kd = z + SHIFT
+    ki = kd.view(np.uint64)
+    kd = kd - SHIFT
+    r = z - kd
+    t = Tn[(ki % np.uint64(N)).astype(np.int64)] + (ki << np.uint64(47))
+    s = t.view(np.float64)
+    y = ((C0 * r + C1) * (r * r) + (C2 * r + 1.0)) * s
+    em = y.astype(np.float32)
+    libm = ctypes.CDLL("libm.so.6")
+    libm.expf.restype = ctypes.c_float
+    libm.expf.argtypes = [ctypes.c_float]
+    ref = np.array([libm.expf(float(v)) for v in x], dtype=np.float32)
+    assert np.array_equal(em, ref)
+
+
+def test_bourne_point_regression_and_survey_probe(oracle, bourne):
+    b = bourne
+    s = b["site"]
+    res, aux = oracle.point(b["doy"], b["year"], b["month"], b["month_id"], b["nmonth"],
+                            b["sw_in"], b["Ta"], b["P"], s["latitude"], s["elev_m"],
+                            s["slop_250m"], s["asp_250m"], b["soil"], [s["Aups_250m"], 3, 3],
+                            s["resolution"])
+    g = json.load(open(os.path.join(GOLD, "bourne_oracle.json")))
+    # regression of the oracle itself (same libm => tight)
+    for k, v in g["oracle"]["mean"].items():
+        assert res[k].mean() == pytest.approx(v, rel=1e-12)
+    assert aux["AI"] == pytest.approx(g["oracle"]["AI"], rel=1e-13)
+    assert [int(aux["passes1"]), int(aux["passes2"])] == g["oracle"]["passes"]
+    # numbers printed by the survey from the real reference C++ (6-7 significant digits)
+    p = g["survey_reference_probe"]
+    si = aux["soil_info"]
+    assert si[0] == pytest.approx(p["SAT"], abs=6e-5)
+    assert si[1] == pytest.approx(p["WP"], abs=6e-5)
+    assert si[2] == pytest.approx(p["FC"], abs=6e-5)
+    assert si[3] == pytest.approx(p["Ksat"], abs=6e-5)
+    assert si[4] == pytest.approx(p["lambda"], abs=6e-7)
+    assert aux["AI"] == pytest.approx(p["AI"], abs=6e-6)
+    for k, v in p["mean"].items():
+        assert res[k].mean() == pytest.approx(v, rel=5e-6), k
+    assert int(aux["passes1"]) == p["passes_per_spin_up"] == int(aux["passes2"])
+    assert not any(np.isnan(res[k]).any() for k in res)
+
+
+def test_scalar_au_equals_three_sided_default(oracle, bourne):
+    """length(Au)==1 => ncellin = ncellout = 3 (R/splash.point.R:106-110)"""
+    b, s = bourne, bourne["site"]
+    r1, _ = oracle.point(b["doy"][:730], b["year"][:730], b["month"][:730], b["month_id"][:730],
+                         24, b["sw_in"][:730], b["Ta"][:730], b["P"][:730], s["latitude"],
+                         s["elev_m"], 0.0, 0.0, b["soil"], None, 250.0)
+    r2, _ = oracle.point(b["doy"][:730], b["year"][:730], b["month"][:730], b["month_id"][:730],
+                         24, b["sw_in"][:730], b["Ta"][:730], b["P"][:730], s["latitude"],
+                         s["elev_m"], 0.0, 0.0, b["soil"], [0.0, 3, 3], 250.0)
+    for k in r1:
+        assert np.array_equal(r1[k], r2[k], equal_nan=True)
+
+
+def test_flat_terrain_tdrain_nan_is_sticky_but_outputs_finite(oracle, bourne):
+    """SURVEY 8a trap 3: on flat terrain tan(0)=0 => Kb=1 => t_drain = -log(1)/0 = NaN, sticky"""
+    b, s = bourne, bourne["site"]
+    res, aux = oracle.point(b["doy"], b["year"], b["month"], b["month_id"], b["nmonth"],
+                            b["sw_in"], b["Ta"], b["P"], s["latitude"], s["elev_m"], 0.0, 0.0,
+                            b["soil"], None, 250.0)
+    assert np.isnan(aux["state0"][3]) and np.isnan(aux["state1"][3])
+    for k in res:
+        assert np.isfinite(res[k]).all(), k
+
+
+def test_monthly_aggregation(oracle, bourne):
+    """R/splash.point.R:207-214: mean of storages, sum of fluxes per calendar month"""
+    b, s = bourne, bourne["site"]
+    args = (b["doy"], b["year"], b["month"], b["month_id"], b["nmonth"], b["sw_in"], b["Ta"],
+            b["P"], s["latitude"], s["elev_m"], s["slop_250m"], s["asp_250m"], b["soil"],
+            [s["Aups_250m"], 3, 3], s["resolution"])
+    d, _ = oracle.point(*args)
+    m, _ = oracle.point(*args, monthly_out=True)
+    assert m["wn"].shape == (b["nmonth"],)
+    for mi in (0, 1, 37, b["nmonth"] - 1):
+        sel = b["month_id"] == mi
+        for k in ("wn", "snow", "sm_lim"):
+            assert m[k][mi] == pytest.approx(d[k][sel].mean(), rel=1e-13)
+        for k in ("ro", "aet", "pet", "cond", "bflow", "netr"):
+            assert m[k][mi] == pytest.approx(d[k][sel].sum(), rel=1e-13, abs=1e-300)
+
+
+def test_snow_partition_edges(oracle):
+    """Tt = max(tc[p_snow>=0.5]) is -Inf when no day qualifies => all rain (R/splash.point.R:122)"""
+    tc = np.array([20.0, 25.0, 30.0])
+    pn = np.array([1.0, 2.0, 3.0])
+    Tt, rain, snow = oracle.snow_partition(tc, pn, np.array([6, 6, 6], np.int32), 10.0, 100.0)
+    assert Tt == -np.inf and np.array_equal(rain, pn) and not snow.any()
+    tc = np.array([-20.0, -1.0, 0.5, 15.0])
+    Tt, rain, snow = oracle.snow_partition(tc, np.ones(4), np.array([1, 1, 1, 1], np.int32), 60.0,
+                                           2000.0)
+    assert np.isfinite(Tt) and snow[0] == pytest.approx(1.0) and rain[3] == 1.0
+    assert np.allclose(rain + snow, 1.0)
+
+
+def test_synthetic_generator_is_counter_based(oracle):
+    """same (seed, cell, day) => same value regardless of the block it is generated in"""
+    doy, year, month, mid, nm = oracle.calendar(2001, 400)
+    st = oracle.synth_statics(20221130, 64, 64, 0, 4096, 1)
+    a = oracle.synth_forcing(20221130, 64, 64, 0, 4096, 0, doy, st["lat"], st["elev"])
+    st2 = oracle.synth_statics(20221130, 64, 64, 1000, 500, 1)
+    b = oracle.synth_forcing(20221130, 64, 64, 1000, 500, 100, doy[100:200], st2["lat"],
+                             st2["elev"])
+    for x, y in zip(a, b):
+        assert np.array_equal(x[100:200, 1000:1500], y)
+    assert np.array_equal(st["soil"][:, 1000:1500], st2["soil"])
+    # forcing is f32-representable (mirrors FLT4S rasters)
+    for x in a:
+        assert np.array_equal(x, x.astype(np.float32).astype(np.float64))
+    assert doy[364] == 365 and doy[365] == 1 and year[365] == 2002 and nm == 14
