@@ -39,6 +39,24 @@ SEED = 20221130
 OUT5 = ("wn", "snow", "ro", "aet", "pet")
 
 
+def host_cores():
+    """threads this process may really use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,7 +217,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle.binding import Oracle
         o = Oracle()
-        cores = len(os.sched_getaffinity(0))
+        cores = host_cores()
         doy, year, month = api.time_fields(dates)
 
         def cpu_run(ns, threads):
@@ -223,19 +241,31 @@ def main():
         st = state0[:, :ns2].clone()
         api.dev_run_all(cal, 0, nt, ns2, sw, tc, pn, n, Tt, par, n, st, ns2, gs, ns2, stream=sp)
         torch.cuda.synchronize()
-        par_err = {}
+        # cell-days on which the reference itself is ill-conditioned (sun grazing the slope:
+        # DESIGN.md "Conditioning"); a cell is set aside from the strict check once it has one
+        from oracle.binding import grazing_mask
+        hp = par[:, :ns2].cpu().numpy()
+        graz = grazing_mask(o, hp[0], hp[2], hp[3], doy, year)
+        okc = ~graz.any(0)
+        par_all, par_ok = {}, {}
         for i, k in enumerate(OUT5):
             a, b = gs[k].cpu().numpy(), oref[i]
             big = np.abs(b) > 1e-9
-            par_err[k] = float(np.max(np.abs(a[big] - b[big]) / np.abs(b[big]))) if big.any() else 0.0
+            rel = np.where(big, np.abs(a - b) / np.where(big, np.abs(b), 1.0), 0.0)
+            par_all[k] = float(rel.max())
+            par_ok[k] = float(rel[:, okc].max())
+        dwn = np.abs(gs["wn"].cpu().numpy() - oref[0])
         line["cpu_baseline"] = {
             "value": ns2 * nt / tcpu, "unit": "cell-days/s", "cores": cores, "kind": "port",
             "sample": f"first {ns2} cells x {nt} days of the same grid (run_all + rain/snow split "
                       f"from the GPU's spun-up state), OpenMP over cells, {tcpu:.1f} s",
         }
         line["parity_sample"] = {
-            "cells": ns2, "max_abs_dwn_mm": float(np.max(np.abs(gs["wn"].cpu().numpy() - oref[0]))),
-            "max_rel_err": par_err, "tolerance": 1e-5,
+            "cells": ns2, "tolerance": 1e-5,
+            "well_conditioned_cells": int(okc.sum()),
+            "max_rel_err": par_ok, "max_abs_dwn_mm": float(dwn[:, okc].max()),
+            "grazing_sun_cells": int((~okc).sum()),
+            "max_rel_err_incl_grazing": par_all, "max_abs_dwn_mm_incl_grazing": float(dwn.max()),
         }
     if rank == 0:
         print(json.dumps(line))

@@ -300,6 +300,36 @@ class Oracle:
         return self.lib.orc_max_threads()
 
 
+def grazing_mask(oracle, lat, slop, asp_c, doy, year, hs_deg=0.01):
+    """Cell-days on which the reference itself is ill-conditioned (numpy, approximate).
+
+    When the sun only grazes the slope, the slope sunset angle hs of src/SOLAR.cpp:129-159 is
+    ~0 although not exactly 0: ru/rv = -cos(hs) = -1 + O(hs^2), the daily geometry integral
+    ru*hs + rv*sin(hs) (src/SOLAR.cpp:165) cancels to O(hs^3) and src/SOLAR.cpp:223 divides by
+    it, so rw, and with it every flux of that day, carries relative rounding noise of order
+    1e-16/hs^2.  Two correct libm implementations (glibc vs the GPU's) then differ by far more
+    than 1e-5 on that cell-day -- as the reference does between two of its own builds -- and the
+    cell's state carries the difference forward.  hs depends only on (lat, slope, aspect, day).
+    Returns a bool array [nt, ncell]: 0 < hs < hs_deg.   asp_c is asp-180."""
+    pir = np.pi / 180.0
+    orb = np.array([oracle.orbit(int(n), int(y)) for n, y in zip(doy, year)])
+    delta = orb[:, 4]
+    sd, cd = np.sin(delta * pir)[:, None], np.cos(delta * pir)[:, None]
+    sl, cl = np.sin(lat * pir), np.cos(lat * pir)
+    ss, cs = np.sin(slop * pir), np.cos(slop * pir)
+    sa, ca = np.sin(asp_c * pir), np.cos(asp_c * pir)
+    a = sd * (cl * ss * ca - sl * cs)
+    b = cd * (cl * cs + sl * ss * ca)
+    c = cd * (ss * sa)
+    b2c2 = b * b + c * c
+    d = b2c2 - a * a
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sinfirst = np.where(d < 0, a * c / b2c2, (a * c + b * np.sqrt(np.abs(d))) / b2c2)
+        ruv = (-a + c * sinfirst) / b
+    lim = 1.0 - np.cos(hs_deg * pir)
+    return (ruv > -1.0) & (1.0 + ruv < lim)
+
+
 class Ref:
     """The real reference SOLAR/EVAP classes (oracle/_ref); raises if it was never built."""
 

@@ -1,0 +1,138 @@
+/*
+ * splash_shim.c -- the `.Call` doorway an rsplash maintainer adds to the package's src/ so that
+ * splash.grid()/splash.point() run on librsplash_hip.so (include/splash_hip.h).
+ *
+ * It replaces, for the gridded path, the Rcpp module registration of the reference
+ * (src/SPLASH.cpp:12-21, src/RcppExports.cpp:9-25): instead of one R->C++ crossing per cell and
+ * method (R/splash.point.R:92,148,152,158), one crossing per row block.
+ *
+ * NOT compiled in this repository's image (no R headers there); it is deliberately thin: unpack
+ * SEXPs, allocate results, call the C ABI, raise an R error on a non-zero code.  Everything with
+ * logic in it lives behind the C ABI, which the test-suite exercises.
+ *
+ * Build inside the package:   PKG_LIBS = -L<dir> -lrsplash_hip   (src/Makevars)
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+
+#include "splash_hip.h"
+
+/* sw_in, tc, pn: numeric matrices [ncell x nt] exactly as raster::getValues(brick, row, nrows)
+ * returns them (R/splash.grid.R:278-280): column-major => time-major [nt][ncell], zero-copy.
+ * stat: numeric matrix [ncell x 5] = lat, elev, slop, asp, resolution; soil [ncell x 6];
+ * au [ncell x 3] or NULL; doy/year/month: integer(nt); monthly: logical(1). */
+SEXP C_splash_grid_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP stat, SEXP soil, SEXP au, SEXP doy,
+                       SEXP year, SEXP month, SEXP monthly, SEXP device)
+{
+    SEXP dim = getAttrib(sw_in, R_DimSymbol);
+    if (isNull(dim) || LENGTH(dim) != 2) error("sw_in must be a [ncell x nt] matrix");
+    const size_t ncell = (size_t)INTEGER(dim)[0];
+    const int nt = INTEGER(dim)[1];
+    if (LENGTH(doy) != nt || LENGTH(year) != nt || LENGTH(month) != nt)
+        error("doy/year/month must have one entry per day");
+    if ((size_t)XLENGTH(tc) != ncell * nt || (size_t)XLENGTH(pn) != ncell * nt)
+        error("tc and pn must have the dimensions of sw_in");
+
+    splash_grid_in in;
+    in.ncell = ncell;
+    in.nt = nt;
+    in.doy = INTEGER(doy);
+    in.year = INTEGER(year);
+    in.month = INTEGER(month);
+    in.sw_in = REAL(sw_in);
+    in.tc = REAL(tc);
+    in.pn = REAL(pn);
+    const double* st = REAL(stat); /* column-major [ncell x 5] == [5][ncell] */
+    in.lat = st;
+    in.elev = st + ncell;
+    in.slop = st + 2 * ncell;
+    in.asp = st + 3 * ncell;
+    in.resolution = st + 4 * ncell;
+    in.soil = REAL(soil);          /* [ncell x 6] == [6][ncell] */
+    in.au = isNull(au) ? NULL : REAL(au);
+
+    splash_opts opt;
+    opt.monthly_out = asLogical(monthly);
+    opt.device = asInteger(device);
+    opt.max_cells_per_launch = 0;
+
+    /* number of output steps: months present in the calendar, or days */
+    int nmonth = 1;
+    for (int t = 1; t < nt; t++)
+        if (in.month[t] != in.month[t - 1] || in.year[t] != in.year[t - 1]) nmonth++;
+    const int nt_out = opt.monthly_out ? nmonth : nt;
+
+    static const char* names[] = {"wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr",
+                                  "sm_lim", ""};
+    SEXP res = PROTECT(mkNamed(VECSXP, names));
+    splash_grid_out out;
+    for (int k = 0; k < SPLASH_NOUT; k++) {
+        SEXP m = PROTECT(allocMatrix(REALSXP, (int)ncell, nt_out)); /* [ncell x nt_out] */
+        out.out[k] = REAL(m);
+        SET_VECTOR_ELT(res, k, m);
+        UNPROTECT(1);
+    }
+    out.state_end = NULL;
+    out.diag = NULL;
+    out.aux = NULL;
+
+    char err[512];
+    int rc = splash_grid_run(&in, &opt, &out, err, sizeof err);
+    if (rc != SPLASH_OK) {
+        UNPROTECT(1);
+        error("splash_grid_run failed (%d): %s", rc, err);
+    }
+    UNPROTECT(1);
+    return res;
+}
+
+/* splash.point: the same pipeline for one site (numeric vectors of length nt) */
+SEXP C_splash_point_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP lat, SEXP elev, SEXP slop, SEXP asp,
+                        SEXP soil_data, SEXP Au, SEXP resolution, SEXP doy, SEXP year, SEXP month,
+                        SEXP monthly)
+{
+    const int nt = LENGTH(sw_in);
+    if (LENGTH(tc) != nt || LENGTH(pn) != nt || LENGTH(doy) != nt) error("series lengths differ");
+    if (LENGTH(soil_data) != 6) error("soil_data must have 6 values");
+    int nmonth = 1;
+    for (int t = 1; t < nt; t++)
+        if (INTEGER(month)[t] != INTEGER(month)[t - 1] || INTEGER(year)[t] != INTEGER(year)[t - 1])
+            nmonth++;
+    const int mo = asLogical(monthly);
+    const int nt_out = mo ? nmonth : nt;
+    static const char* names[] = {"wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr",
+                                  "sm_lim", ""};
+    SEXP res = PROTECT(mkNamed(VECSXP, names));
+    double* outp[SPLASH_NOUT];
+    for (int k = 0; k < SPLASH_NOUT; k++) {
+        SEXP v = PROTECT(allocVector(REALSXP, nt_out));
+        outp[k] = REAL(v);
+        SET_VECTOR_ELT(res, k, v);
+        UNPROTECT(1);
+    }
+    char err[512];
+    int rc = splash_point_run(nt, INTEGER(doy), INTEGER(year), INTEGER(month), REAL(sw_in), REAL(tc),
+                              REAL(pn), asReal(lat), asReal(elev), asReal(slop), asReal(asp),
+                              REAL(soil_data), REAL(Au), LENGTH(Au), asReal(resolution), mo, outp,
+                              err, sizeof err);
+    if (rc != SPLASH_OK) {
+        UNPROTECT(1);
+        error("splash_point_run failed (%d): %s", rc, err);
+    }
+    UNPROTECT(1);
+    return res;
+}
+
+static const R_CallMethodDef CallEntries[] = {
+    {"C_splash_grid_run", (DL_FUNC)&C_splash_grid_run, 11},
+    {"C_splash_point_run", (DL_FUNC)&C_splash_point_run, 14},
+    {NULL, NULL, 0}};
+
+/* add these two entries to the package's existing R_init_rsplash (src/RcppExports.cpp:21-24),
+ * or use this initialiser if the Rcpp module is dropped */
+void R_init_rsplash_hip(DllInfo* dll)
+{
+    R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
+    R_useDynamicSymbols(dll, FALSE);
+}

@@ -183,6 +183,29 @@ __device__ __forceinline__ float expf_glibc(float x)
     return (float)y;
 }
 
+// x^2..x^6 rounded once from a double-double product chain (error ~1e-32 relative before the
+// final rounding), i.e. correctly rounded except in astronomically rare ties.
+__device__ __forceinline__ void pow_int_cr(double x, double& p2, double& p3, double& p4, double& p5,
+                                           double& p6)
+{
+#pragma clang fp contract(off)
+    // (h, l) <- (h, l) * x  with h*x split exactly by FMA
+    double h = x * x, l = fma(x, x, -h);
+    p2 = h; // x*x is the correctly rounded square already
+#define STEP(out)                         \
+    {                                     \
+        double ph = h * x;                \
+        double pl = fma(h, x, -ph);       \
+        pl = fma(l, x, pl);               \
+        double sh = ph + pl;              \
+        l = pl - (sh - ph);               \
+        h = sh;                           \
+        out = h;                          \
+    }
+    STEP(p3) STEP(p4) STEP(p5) STEP(p6)
+#undef STEP
+}
+
 // src/EVAP.cpp:405-462 -- Huber et al. (2009) viscosity in the reference's float/double mix.
 // Every rounding point of the C++ original is kept: a `float` variable is a rounding to float;
 // an expression containing a double literal is evaluated in double.
@@ -209,8 +232,15 @@ __device__ __forceinline__ float viscosity_h2o(float tc, float p)
     float ctbar = (float)((1.0 / (double)tbar) - 1.0);                 // :439
     double cd_ = (double)ctbar;
     double rb = (double)rbar - 1.0;                                    // pow(rbar - 1.0, j) base
-    double rb2 = rb * rb, rb3 = rb2 * rb, rb4 = rb3 * rb, rb5 = rb4 * rb, rb6 = rb5 * rb;
-    double ct2 = cd_ * cd_, ct3 = ct2 * cd_, ct4 = ct3 * cd_, ct5 = ct4 * cd_;
+    // Integer powers as the correctly rounded value of the exact power (what glibc's pow returns
+    // except within ~0.01 ulp of a rounding tie): a float-rounding of the running sum flips on a
+    // 1-ulp(double) difference about once per 1e8 cell-days, which at grid scale is every run.
+    double rb2, rb3, rb4, rb5, rb6, ct2, ct3, ct4, ct5;
+    pow_int_cr(rb, rb2, rb3, rb4, rb5, rb6);
+    {
+        double ct6;
+        pow_int_cr(cd_, ct2, ct3, ct4, ct5, ct6);
+    }
 
 #define H(v) ((double)(float)(v))
 #define ACC(c2, h, pw_) c2 = (float)((double)(c2) + H(h) * (pw_))
