@@ -136,6 +136,10 @@ int splash_dev_evap_batch(size_t m, const double* lat, const double* elv, const 
                           const double* slop, const double* asp, const double* snow,
                           const double* nd, double* out, void* stream);
 
+/* test hook: the device build of the FP64 log/exp/pow/acos used by the day step, for n arguments
+ * (host pointers): out [4][n] = flog(x), fexp(x), fpow(x,y), facos(x) */
+int splash_dev_math_probe(size_t n, const double* x, const double* y, double* out);
+
 /* ---------------------------------------------------------------- host-buffer entry points - */
 typedef struct {
     size_t ncell;

@@ -61,12 +61,12 @@ class Opts(C.Structure):
 class CellAux(C.Structure):
     _fields_ = [("soil_info", C.c_double * 12), ("wmax_r", C.c_double), ("Tt", C.c_double),
                 ("AI", C.c_double), ("passes1", C.c_int), ("passes2", C.c_int),
-                ("state0", C.c_double * 5), ("state1", C.c_double * 5)]
+                ("state0", C.c_double * 5), ("state1", C.c_double * 5), ("fragile", C.c_int)]
 
 
 AUX_DTYPE = np.dtype([("soil_info", "f8", 12), ("wmax_r", "f8"), ("Tt", "f8"), ("AI", "f8"),
                       ("passes1", "i4"), ("passes2", "i4"), ("state0", "f8", 5),
-                      ("state1", "f8", 5)], align=True)
+                      ("state1", "f8", 5), ("fragile", "i4")], align=True)
 assert AUX_DTYPE.itemsize == C.sizeof(CellAux)
 
 OUT_NAMES = ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "sm_lim")
@@ -112,7 +112,7 @@ class Oracle:
         L.orc_grid.argtypes = [C.c_int, C.c_int, _ip, _ip, _ip, _ip, C.c_int] + [_dp] * 10 + \
             [C.POINTER(Opts), C.POINTER(_dp), C.c_void_p]
         L.orc_grid_transient.argtypes = [C.c_int, C.c_int, _ip, _ip, _ip] + [_dp] * 10 + \
-            [C.POINTER(_dp), C.c_int]
+            [C.POINTER(_dp), C.c_int, _ip]
         L.orc_synth_statics.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int] + \
             [_dp] * 7
         L.orc_synth_forcing.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
@@ -274,8 +274,10 @@ class Oracle:
             ptrs = (_dp * 5)(*[out[k].ctypes.data_as(_dp) for k in range(5)])
         else:
             ptrs = (_dp * 5)(*[None] * 5)
+        self.fragile = np.zeros(ncell, np.int32)
         self.lib.orc_grid_transient(ncell, nt, ia[0][1], ia[1][1], ia[2][1], *[x[1] for x in fa],
-                                    st.ctypes.data_as(_dp), ptrs, n_threads)
+                                    st.ctypes.data_as(_dp), ptrs, n_threads,
+                                    self.fragile.ctypes.data_as(_ip))
         return out, st
 
     def synth_statics(self, seed, H, W, cell0, ncell, terrain):

@@ -579,6 +579,24 @@ double orc_get_wtd(double wn, double depth, double bub_press, double theta_s, do
     return wtd;
 }
 
+double orc_debug[16]; /* intermediates of the last orc_run_one_day call (debugging aid) */
+
+/* Conditioning bookkeeping (not part of the restatement): number of day steps, on the calling
+ * thread, in which the drainage time of src/SPLASH.cpp:1472 was computed from a transmittance
+ * that is rounding noise.  With the water table clamped to the column base and
+ * |psi_m| > 1e11 * depth*1000, the two powers at :1422 are bub/psi_m and
+ * bub/fl(psi_m + depth*1000) raised to 3*lambda+1: their bases differ by the ROUNDING of that
+ * sum (nothing at all once |psi_m| > 2^53*depth*1000), so T_uns, hence Q = T*Ai/1000, is a few
+ * ulp of ~1e-20 or exactly 0, and t_drain = -log(1 - log(Kb)*Au*R/Q)/log(Kb) is either +inf
+ * (sticky) or a value set by those ulps.  No two libm implementations agree there. */
+static __thread long tl_fragile_events = 0;
+long orc_fragile_events(int reset)
+{
+    long v = tl_fragile_events;
+    if (reset) tl_fragile_events = 0;
+    return v;
+}
+
 /* src/SPLASH.cpp:920-1588 (live code only; quick_run :150-918 has the same arithmetic and
  * additionally returns pet).  Dead locals (psi_m/wtd/w_z at :999-1022, max_sw :1040, To :1358,
  * T_qs :1321, Q_uns/Q_sat) are not restated. */
@@ -759,6 +777,7 @@ void orc_run_one_day(double lat, double elv, int n, int y, double wn, double sw_
     double q_in_f = 0.0;
     td -= 1.0;
     if ((R > 0.0) && (sm > Wmax)) {
+        if (Au > 0.0 && wtd >= depth && fabs(psi_m) > 1.0e11 * (wtd * 1000.0)) tl_fragile_events++;
         t_drain = -1.0 * log(1.0 - (log(Kb) * (Au * R / Q))) / log(Kb);
         q_in_f = (Qt - Au * R * log(Kb)) / Ai;
     }
@@ -810,6 +829,10 @@ void orc_run_one_day(double lat, double elv, int n, int y, double wn, double sw_
     double mx = STDMAX(q_in_o, q_in_f);
     double qin_nday = STDMAX(mx, 0.0);
 
+    orc_debug[0] = Kb; orc_debug[1] = Q; orc_debug[2] = T; orc_debug[3] = t_drain;
+    orc_debug[4] = q_in_f; orc_debug[5] = q_in_o; orc_debug[6] = R; orc_debug[7] = Ksat_visc;
+    orc_debug[8] = hyd_grad_out; orc_debug[9] = Qt; orc_debug[10] = infi; orc_debug[11] = Wmax;
+    orc_debug[12] = surf_moist; orc_debug[13] = T_uns; orc_debug[14] = Acs_out; orc_debug[15] = log(Kb);
     dsoil->sm = sm;
     dsoil->ro = ro;
     dsoil->swe = snow;
@@ -1128,6 +1151,7 @@ void orc_point(int nt, const int* doy, const int* year, const int* month, const 
 {
     int monthly = opt ? opt->monthly_out : 0;
     double soil_info[12], wmax_r;
+    orc_fragile_events(1);
     orc_soil_info(soil_data, au, resolution, soil_info, &wmax_r); /* :96-115 */
 
     /* :120-128 */
@@ -1206,6 +1230,7 @@ void orc_point(int nt, const int* doy, const int* year, const int* month, const 
         aux->state0[3] = tdv[ns - 1];
         aux->state0[4] = age[ns - 1];
         memcpy(aux->state1, state_end, sizeof(state_end));
+        aux->fragile = (int)orc_fragile_events(0);
     }
 
     if (!monthly) {
@@ -1307,7 +1332,7 @@ void orc_grid_transient(int ncell, int nt, const int* doy, const int* year, cons
                         const double* sw_in, const double* tc, const double* pn,
                         const double* lat, const double* elev, const double* slop,
                         const double* asp, const double* soil_info, const double* Tt,
-                        double* state, double* const out5[5], int n_threads)
+                        double* state, double* const out5[5], int n_threads, int* fragile)
 {
     int nthreads = n_threads > 0 ? n_threads : orc_max_threads();
     (void)nthreads;
@@ -1320,6 +1345,7 @@ void orc_grid_transient(int ncell, int nt, const int* doy, const int* year, cons
         double wn = state[c], swe = state[(size_t)ncell + c], qin = state[2 * (size_t)ncell + c];
         double td = state[3 * (size_t)ncell + c], nd = state[4 * (size_t)ncell + c];
         double asp_c = asp[c]; /* already asp-180 (R/splash.point.R:131) */
+        orc_fragile_events(1);
         orc_smr ds;
         orc_etr dv;
         for (int t = 0; t < nt; t++) {
@@ -1344,6 +1370,7 @@ void orc_grid_transient(int ncell, int nt, const int* doy, const int* year, cons
         state[2 * (size_t)ncell + c] = qin;
         state[3 * (size_t)ncell + c] = td;
         state[4 * (size_t)ncell + c] = nd;
+        if (fragile) fragile[c] = (int)orc_fragile_events(0);
     }
 }
 

@@ -117,7 +117,11 @@ typedef struct {
     int passes1, passes2;
     double state0[5]; /* wn, snow, qin, td, nd handed to run_all */
     double state1[5]; /* state after the last transient day */
+    int fragile;      /* day steps whose drainage time came from a rounding-noise transmittance */
 } orc_cell_aux;
+
+/* count of such steps on the calling thread since the last reset (see splash_oracle.c) */
+long orc_fragile_events(int reset);
 
 /*
  * splash.point for one cell (R/splash.point.R:29-225).  Forcing is read with a stride
@@ -149,7 +153,7 @@ void orc_grid_transient(int ncell, int nt, const int* doy, const int* year, cons
                         const double* lat, const double* elev, const double* slop,
                         const double* asp, const double* soil_info /*[12][ncell]*/,
                         const double* Tt, double* state /*[5][ncell] in/out*/,
-                        double* const out5[5], int n_threads);
+                        double* const out5[5], int n_threads, int* fragile /*[ncell] or NULL*/);
 
 /* ---- synthetic inputs (SURVEY.md 8d spec; splitmix64 counter RNG) ---- */
 double orc_synth_u(uint64_t seed, uint64_t stream, uint64_t cell, uint64_t day);

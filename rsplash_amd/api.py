@@ -223,6 +223,16 @@ def evap_batch(lat, elv, sw, n, y, sw_in, tc, slop, asp, snow, nd):
     return out
 
 
+def math_probe(x, y):
+    """test hook: device flog(x), fexp(x), fpow(x, y), facos(x) -> [4, n]"""
+    xa, xp = _d(x)
+    ya, yp = _d(y)
+    out = np.empty((4, len(xa)))
+    check(lib.splash_dev_math_probe(len(xa), xp, yp, out.ctypes.data_as(_dp)),
+          "splash_dev_math_probe")
+    return out
+
+
 # ---------------------------------------------------------------------------- device-resident API
 def _ptr(x):
     """device pointer of a torch tensor (or an int / None)."""

@@ -436,6 +436,24 @@ extern "C" int splash_dev_evap_batch(size_t m, const double* lat, const double* 
     return SPLASH_OK;
 }
 
+// test hook: device flog/fexp/fpow/facos for n arguments (host pointers); out [4][n]
+extern "C" int splash_dev_math_probe(size_t n, const double* x, const double* y, double* out)
+{
+    REQ(x && y && out, "math_probe: NULL argument");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    if (n == 0) return SPLASH_OK;
+    DevBuf dx, dy, dout;
+    HIP_TRY(dx.alloc(n * 8), nullptr, 0);
+    HIP_TRY(dy.alloc(n * 8), nullptr, 0);
+    HIP_TRY(dout.alloc(4 * n * 8), nullptr, 0);
+    HIP_TRY(hipMemcpy(dx.p, x, n * 8, hipMemcpyHostToDevice), nullptr, 0);
+    HIP_TRY(hipMemcpy(dy.p, y, n * 8, hipMemcpyHostToDevice), nullptr, 0);
+    HIP_TRY(launch_math_probe(n, dx.as<double>(), dy.as<double>(), dout.as<double>(), nullptr),
+            nullptr, 0);
+    HIP_TRY(hipMemcpy(out, dout.p, 4 * n * 8, hipMemcpyDeviceToHost), nullptr, 0);
+    return SPLASH_OK;
+}
+
 // ------------------------------------------------------------------ splash.grid / splash.point
 extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
                                const splash_grid_out* out, char* err, size_t errlen)

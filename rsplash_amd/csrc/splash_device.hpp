@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "splash_kernels.hpp"
+#include "splash_math.hpp"
 
 namespace splash {
 
@@ -64,28 +65,28 @@ struct DayOut {
 
 // Cell-static terms hoisted out of the day loop (the reference recomputes all of them per day).
 struct CellConst {
-    // SOLAR (src/SOLAR.cpp:129-131, 170)
+    // SOLAR (src/SOLAR.cpp:129-131, 170, 197)
     double ka, kb, kc;      // a = sd*ka, b = cd*kb, c = cd*kc
-    double tau_o;
-    // EVAP (src/EVAP.cpp:110)
+    double tau_o, tau_a, tau_binv; // tau_o, 0.1898*tau_o, 1/(0.8102*tau_o)
+    // EVAP (src/EVAP.cpp:110, 120)
     double patm;
     float patm_f;
+    double visc0;           // viscosity at tw = 0 (every day with tc < 0)
     // SPLASH soil column
-    double SAT, RES, Au, Ai;
-    double d1000;           // depth*1000
+    double SAT, RES, Au, Ai, inv_Ai;
+    double d1000, inv_d1000; // depth*1000 and its inverse
     double depth;
-    double theta_s, theta_r, dtheta; // dtheta = theta_s - theta_r
-    double inv_lambda, e3l1;        // 1/lambda, 3*lambda+1
+    double theta_s, theta_r, dtheta, inv_dtheta; // dtheta = theta_s - theta_r
+    double inv_lambda, e3l1, e_uns; // 1/lambda, 3*lambda+1, (3*lambda+1)/lambda
     double lambda;
-    double bub;
-    double Wmax, wm_th;     // src/SPLASH.cpp:1029 and Wmax/(depth*1000)
+    double bub, bpr, z_bpr; // bubbling pressure [mm], [cm], 10 cm / bpr
+    double Wmax, wm_th, inv_wr; // src/SPLASH.cpp:1029, Wmax/(depth*1000), 1/(Wmax-RES)
     double int_perm;        // Ksat/fluidity
-    double tan_slop, inv_cos2; // tan(slop), 1/cos^2(slop)
+    double tan2_slop, inv_cos2; // tan^2(slop), 1/cos^2(slop)
     double h_f;             // Green-Ampt wetting-front suction (src/SPLASH.cpp:1987)
     double kun_exp;         // 3 + 2/lambda
     double so_cellout;      // sid_oct*cellout
-    double tu_fac;          // (24*cellout*sid_oct)/(1000*Ai)
-    double tu_coef;         // bub/(3*lambda+1)
+    double tu_all;          // (bub/(3*lambda+1)) * (24*cellout*sid_oct)/(1000*Ai)
     double kb_coef;         // log(Kb) = Ksat_visc*kb_coef   (src/SPLASH.cpp:1291-1326)
     double qt_coef;         // Qt = Ksat_visc*qt_coef*hyd_grad_out (src/SPLASH.cpp:1333-1360)
     bool deep;              // depth >= 2.0
@@ -305,7 +306,8 @@ __device__ __forceinline__ double specific_heat(double tc)
 // ---- cell setup ----------------------------------------------------------------------------
 // Loads one cell's raw parameters (cellpar rows) and derives the day-loop constants.
 // cellout is passed separately because splash.point overwrites it with the aridity index
-// between the two spin-ups (R/splash.point.R:150).
+// between the two spin-ups (R/splash.point.R:150).  Runs once per kernel per cell, so it uses
+// the library pow/exp/log throughout.
 __device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, size_t ld,
                                   size_t cell, double cellout)
 {
@@ -326,6 +328,8 @@ __device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, 
     c.kb = cl * cs + sl * ss * ca;
     c.kc = ss * sa;
     c.tau_o = (kC + kD) * (1.0 + (2.67e-5) * elv); // :170
+    c.tau_a = c.tau_o * 0.1898;                    // :197
+    c.tau_binv = 1.0 / (c.tau_o * (1 - 0.1898));
 
     // EVAP::elv2pres, src/EVAP.cpp:319-336
     {
@@ -333,16 +337,21 @@ __device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, 
         double pa = (1.0 - elv * kL / kTo);
         c.patm = pow(pa, ep) * kPo;
         c.patm_f = (float)c.patm;
+        c.visc0 = (double)viscosity_h2o(0.0f, c.patm_f); // tw = 0 whenever tc < 0 (:100-105)
     }
 
     c.SAT = SAT;
     c.RES = RES;
     c.Au = Au;
     c.Ai = Ai;
+    c.inv_Ai = 1.0 / Ai;
     c.depth = depth;
     c.d1000 = depth * 1000.0;
+    c.inv_d1000 = 1.0 / c.d1000;
     c.lambda = lambda;
     c.bub = bub;
+    c.bpr = bub / 10; // src/SPLASH.cpp:1940
+    c.z_bpr = 10.0 / c.bpr;
     c.deep = (depth >= 2.0);
 
     // src/SPLASH.cpp:971-993
@@ -350,26 +359,30 @@ __device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, 
     c.theta_s = SAT / c.d1000;
     c.theta_r = RES / c.d1000;
     c.dtheta = c.theta_s - c.theta_r;
+    c.inv_dtheta = 1.0 / c.dtheta;
     const double theta_fc = FC / c.d1000;
     const double theta_wp = WP / c.d1000;
     const double theta_q0 = theta_wp + 0.001;
     const double sid_oct = sqrt(Ai / (2.0 * (1 + sqrt(2.0))));
     c.inv_lambda = 1 / lambda;
     c.e3l1 = 3.0 * lambda + 1.0;
+    c.e_uns = c.e3l1 * c.inv_lambda;
     c.kun_exp = 3.0 + (2.0 / lambda);
 
     // src/SPLASH.cpp:1027-1029
     const double coeff_A = exp(log(33.0) + (1.0 / lambda) * log(theta_fc));
     c.Wmax = pow((coeff_A * KG_o / (depth)), (1.0 / ((1 / lambda) + 1.0))) * (c.d1000);
     c.wm_th = c.Wmax / c.d1000;
+    c.inv_wr = 1.0 / (c.Wmax - RES);
 
     c.int_perm = Ksat / kFluidity; // :1260
-    c.tan_slop = tan(slop * kPir); // :1278
+    const double tan_slop = tan(slop * kPir); // :1278
+    c.tan2_slop = tan_slop * tan_slop;
     c.inv_cos2 = 1.0 / (cs * cs);  // :2011
     c.h_f = ((2 + 3 * lambda) / (1 + 3 * lambda)) * (bub / 2); // :1987
-    c.tu_coef = bub / c.e3l1;
+    const double tu_coef = bub / c.e3l1;
     c.so_cellout = sid_oct * cellout;
-    c.tu_fac = ((24.0 * cellout * sid_oct) / (1000.0 * Ai));
+    c.tu_all = tu_coef * ((24.0 * cellout * sid_oct) / (1000.0 * Ai));
 
     // Recession constant: log(Kb) = Ksat_visc * kb_coef, src/SPLASH.cpp:1291-1326
     {
@@ -380,11 +393,11 @@ __device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, 
         } else if (wtd_q0 > depth) {
             wtd_q0 = depth;
         }
-        double tq0 = c.tu_coef * (pow((bub / psi_q0), c.e3l1) -
-                                  pow((bub / (psi_q0 + (wtd_q0 * 1000.0))), c.e3l1));
-        double q_q0 = tq0 * c.tan_slop * ((24.0 * sid_oct * cellout) / (1.0e6));
+        double tq0 = tu_coef * (pow((bub / psi_q0), c.e3l1) -
+                                pow((bub / (psi_q0 + (wtd_q0 * 1000.0))), c.e3l1));
+        double q_q0 = tq0 * tan_slop * ((24.0 * sid_oct * cellout) / (1.0e6));
         double acs_qs = depth * sid_oct * cellout;
-        double q_qs = c.tan_slop * 24.0 * acs_qs / 1000.0;
+        double q_qs = tan_slop * 24.0 * acs_qs / 1000.0;
         c.kb_coef = (q_q0 - q_qs) / ((SAT - WP) * (Ai / 1000.0));
     }
     // Drainage at Wmax: Qt = Ksat_visc*qt_coef*hyd_grad_out, src/SPLASH.cpp:1333-1360
@@ -398,8 +411,8 @@ __device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, 
             wtd = depth;
         }
         double acs = (depth - wtd) * cellin * sid_oct;
-        double to_uns = c.tu_coef * (pow((bub / psi_m), c.e3l1) -
-                                     pow((bub / (psi_m + (wtd * 1000.0))), c.e3l1));
+        double to_uns = tu_coef * (pow((bub / psi_m), c.e3l1) -
+                                   pow((bub / (psi_m + (wtd * 1000.0))), c.e3l1));
         double qo_uns = to_uns * ((24.0 * cellin * sid_oct) / (1.0e6));
         double qo_sat = 24.0 * acs / 1000.0;
         c.qt_coef = qo_sat + qo_uns;
@@ -411,57 +424,72 @@ struct Etr { // src/etr.h:44-56 (fields the water balance needs)
     double cond, pet, aet, snowmelt, sublimation, pw, rn_d, visc, econ, pet_max;
 };
 
+// hour angle (radians) and its sine from the cosine, with the reference's saturation at
+// >= 1 / <= -1 (src/SOLAR.cpp:149-159, 231-240; src/EVAP.cpp:209-218).  sin(acos x) is taken as
+// sqrt((1-x)(1+x)) (both factors exact near |x| = 1), which replaces a library sin per angle;
+// sin(180 deg) keeps the value the reference gets from sin(pi rounded to double).
+__device__ __forceinline__ void hour_angle(double cosv, bool at_one_is_zero, double& h,
+                                           double& sinh_)
+{
+    const double kSinPi = 1.2246467991473532e-16;
+    if (cosv >= 1.0) {
+        h = at_one_is_zero ? 0.0 : kPI;
+        sinh_ = at_one_is_zero ? 0.0 : kSinPi;
+    } else if (cosv <= -1.0) {
+        h = at_one_is_zero ? kPI : 0.0;
+        sinh_ = at_one_is_zero ? kSinPi : 0.0;
+    } else {
+        const double x = at_one_is_zero ? cosv : -cosv;
+        h = facos(x);
+        sinh_ = sqrt((1.0 - x) * (1.0 + x));
+    }
+}
+
 // src/SOLAR.cpp:77-267 + src/EVAP.cpp:82-264 for one cell-day.
 // sw is the supply fraction (src/SPLASH.cpp:1042-1048), snow already includes today's snowfall.
+// Angles are kept in radians (the reference converts to degrees and back at every use).
 __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, double sw,
                                          double sw_in, double tc, double snow, double nd, Etr& o)
 {
     // ----- SOLAR
-    double sw_s = sw > 1.0 ? 1.0 : sw; // :92
-    double a = d.sd * c.ka, b = d.cd * c.kb, cc = d.cd * c.kc;
-    double b2c2 = b * b + cc * cc;
-    double dd = b2c2 - a * a;
-    double sinfirst;
-    if (dd < 0) {
-        sinfirst = (a * cc) / b2c2;
-    } else {
-        sinfirst = (a * cc + b * sqrt(dd)) / b2c2;
-    }
-    double ru = -1 * a + cc * sinfirst;
-    double rv = b;
+    const double sw_s = sw > 1.0 ? 1.0 : sw; // :92
+    const double a = d.sd * c.ka, b = d.cd * c.kb, cc = d.cd * c.kc;
+    const double b2c2 = b * b + cc * cc;
+    const double dd = b2c2 - a * a;
+    const double acc = a * cc;
+    const double num = (dd < 0) ? acc : (acc + b * sqrt(dd)); // :133-137
+    const double sinfirst = num / b2c2;
+    const double ru = -1 * a + cc * sinfirst;
+    const double rv = b;
+    const double ruv = ru / rv;
 
-    double ruv = ru / rv;
-    double hs; // degrees, :149-159
-    if (ruv >= 1.0) {
-        hs = 180.0;
-    } else if (ruv <= -1.0) {
-        hs = 0.0;
-    } else {
-        hs = acos(-1.0 * ruv) / kPir;
-    }
-    double sin_hs = dsin_deg(hs);
-    double geo = (ru * hs * kPir + rv * sin_hs);
-    double ra_d = (86400.0 / kPI) * d.dr * kGsc * geo; // :164-165
+    double hs, sin_hs; // :149-159: ruv >= 1 polar day (hs = 180), ruv <= -1 polar night (hs = 0)
+    hour_angle(ruv, false, hs, sin_hs);
+    const double geo = (ru * hs + rv * sin_hs);
+    const double ra_d = (86400.0 / kPI) * d.dr * kGsc * geo; // :164-165
 
-    double r_in = 86400 * sw_in;
+    const double r_in = 86400 * sw_in;
     double tau; // :174-178
     if (isnan(ra_d) || r_in == 0 || ra_d < r_in) {
         tau = c.tau_o;
     } else {
         tau = r_in / ra_d;
     }
-    double sf = pow(((tau - c.tau_o * 0.1898) / (c.tau_o * (1 - 0.1898))), (1 / 0.7410)); // :197
+    double sf = fpow((tau - c.tau_a) * c.tau_binv, (1 / 0.7410)); // :197
     if (isnan(sf)) {
         sf = 0.0;
     } else if (sf > 1.0) {
         sf = 1.0;
     }
-    double rnl = (0.0883289 + (1.0 - kB) * sf) * (kA + 1.95974 * tc); // :203
+    const double rnl = (0.0883289 + (1.0 - kB) * sf) * (kA + 1.95974 * tc); // :203
 
-    double max_alb_snw = (1.0 - 0.443700) + (0.443700 * exp(-0.895189 * nd)); // :208
-    double sfc = snow / (140.0 + snow);
-    double alb_v = kAlbSw - 0.17 * sw_s;
-    double alb = alb_v * (1.0 - sfc) + sfc * max_alb_snw;
+    const double alb_v = kAlbSw - 0.17 * sw_s; // :215
+    double alb = alb_v;                        // snow-free: sfc = 0 => alb = alb_v exactly
+    if (snow > 0.0 || isnan(snow)) {           // :208-219
+        const double max_alb_snw = (1.0 - 0.443700) + (0.443700 * fexp(-0.895189 * nd));
+        const double sfc = snow / (140.0 + snow);
+        alb = alb_v * (1.0 - sfc) + sfc * max_alb_snw;
+    }
     double rw; // :220-224
     if ((sw_in == 0.0) || (hs == 0.0)) {
         rw = (1.0 - alb) * tau * d.dr * kGsc;
@@ -469,74 +497,64 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
         rw = (1.0 - alb) * (r_in) / ((86400.0 / kPI) * geo);
     }
 
-    double xn = (rnl - rw * ru) / (rw * rv);
-    double hn; // :231-240
-    if (xn >= 1.0) {
-        hn = 0;
-    } else if (xn <= -1.0) {
-        hn = 180.0;
-    } else {
-        hn = acos(xn) / kPir;
-    }
-    double sin_hn = dsin_deg(hn);
-    double rn_d = (kPir * hn * (rw * ru - rnl) + rw * rv * sin_hn) * (86400.0 / kPI); // :245-246
-    double rnn_d = rw * rv * (sin_hs - sin_hn);                                        // :252-255
-    rnn_d += rw * ru * (hs - hn) * kPir;
-    rnn_d -= rnl * (kPI - hn * kPir);
+    const double inv_rwrv = 1.0 / (rw * rv);
+    const double xn = (rnl - rw * ru) * inv_rwrv; // :231
+    double hn, sin_hn; // xn >= 1: net radiation negative all day (hn = 0)
+    hour_angle(xn, true, hn, sin_hn);
+    const double rn_d = (hn * (rw * ru - rnl) + rw * rv * sin_hn) * (86400.0 / kPI); // :245-246
+    double rnn_d = rw * rv * (sin_hs - sin_hn);                                       // :252-255
+    rnn_d += rw * ru * (hs - hn);
+    rnn_d -= rnl * (kPI - hn);
     rnn_d *= (86400.0 / kPI);
 
     // ----- EVAP
-    double tw = tc < 0.0 ? 0.0 : tc; // :100-105
     double s; // sat_slope :299-301
     {
-        double q = tc + 237.3;
-        s = exp((tc * 17.269) / q) / (q * q) * ((17.269) * (237.3) * (610.78));
+        const double inv_q = 1.0 / (tc + 237.3);
+        s = fexp((tc * 17.269) * inv_q) * (inv_q * inv_q) * ((17.269) * (237.3) * (610.78));
     }
     double lv; // enthalpy_vap :313-315
     {
-        double q = (tc + 273.15) / (tc + 273.15 - 33.91);
+        const double q = (tc + 273.15) / (tc + 273.15 - 33.91);
         lv = q * q * 1.91846e6;
     }
-    double pw = density_h2o(tc, c.patm);                        // :113
-    double g = (kMa * specific_heat(tc) * c.patm) / (kMv * lv); // psychro :486
-    double econ = s / (lv * pw * (s + g));                      // :117
-    float visc_f = viscosity_h2o((float)tw, c.patm_f);          // :120
-    double cn = (1.0e3) * econ * fabs(rnn_d) * 0.1;             // :124
-    double eet_d = (1.0e3) * (s / (lv * pw * (s + 0.24 * g))) * rn_d; // :129
-    double rx = (3.6e6) * econ;                                 // :145
-    double pet_max = rx * ((rw * (ru + rv)) - rnl);             // :148
+    const double pw = density_h2o(tc, c.patm);                        // :113
+    const double g = (kMa * specific_heat(tc) * c.patm) / (kMv * lv); // psychro :486
+    const double lvpw = lv * pw;
+    const double econ = s / (lvpw * (s + g));                         // :117
+    double visc = c.visc0;                                            // :100-105, :120
+    if (!(tc < 0.0)) visc = (double)viscosity_h2o((float)tc, c.patm_f);
+    const double cn = (1.0e3) * econ * fabs(rnn_d) * 0.1;             // :124
+    const double eet_d = (1.0e3) * (s / (lvpw * (s + 0.24 * g))) * rn_d; // :129
+    const double rx = (3.6e6) * econ;                                 // :145
+    const double pet_max = rx * ((rw * (ru + rv)) - rnl);             // :148
 
-    double B_r = g / (sw * s); // :157-166 (uses the UNclamped sw argument)
-    double EF = 1 / (B_r + 1.0);
-    double sup = pet_max * EF;
+    // :157-166  EF = 1/(g/(sw*s) + 1) = sw*s/(g + sw*s)
+    const double sws = sw * s;
+    double sup = pet_max * (sws / (g + sws));
     if (sup < 0.0 || isnan(sup)) {
         sup = 0.0;
     }
-    double cos_hi = sup / (rw * rv * rx) + rnl / (rw * rv) - ru / rv; // :208
-    double hi;
-    if (cos_hi >= 1.0) {
-        hi = 0.0;
-    } else if (cos_hi <= -1.0) {
-        hi = 180.0;
-    } else {
-        hi = acos(cos_hi) / kPir;
-    }
-    double snowmelt; // :233-237
-    if (tc >= 3.0) {
-        double m = (rn_d / (pw * kKfus)) * 1000.0;
-        snowmelt = SPL_MIN(snow, m);
-    } else {
-        snowmelt = 0.0;
-    }
-    double melt_enrg = (snowmelt / 1000) * pw * kKfus; // :241-249
-    double AE = rn_d - melt_enrg;
-    double sub_c = (AE * econ) * 1000.0;
-    double sublimation = SPL_MIN(snowmelt, sub_c);
-    melt_enrg += ((sublimation / 1000.0) / econ);
+    const double cos_hi = (sup / rx + rnl) * inv_rwrv - ruv; // :208
+    double hi, sin_hi; // cos_hi >= 1: supply exceeds demand (hi = 0)
+    hour_angle(cos_hi, true, hi, sin_hi);
 
-    double aet_d = sup * hi * kPir; // :254-263
-    aet_d += rx * rw * rv * (sin_hn - dsin_deg(hi));
-    aet_d += (rx * rw * ru - rx * rnl) * (hn - hi) * kPir;
+    double snowmelt = 0.0, sublimation = 0.0, melt_enrg = 0.0; // :233-249
+    if (tc >= 3.0) {
+        const double m = (rn_d / (pw * kKfus)) * 1000.0;
+        snowmelt = SPL_MIN(snow, m);
+        melt_enrg = (snowmelt / 1000) * pw * kKfus;
+    }
+    {
+        const double AE = rn_d - melt_enrg;
+        const double sub_c = (AE * econ) * 1000.0;
+        sublimation = SPL_MIN(snowmelt, sub_c);
+        melt_enrg += ((sublimation / 1000.0) / econ);
+    }
+
+    double aet_d = sup * hi; // :254-263
+    aet_d += rx * rw * rv * (sin_hn - sin_hi);
+    aet_d += (rx * rw * ru - rx * rnl) * (hn - hi);
     aet_d *= (24.0 / kPI);
     aet_d -= (melt_enrg * econ * 1000.0);
     if (aet_d < 0.0) {
@@ -550,22 +568,38 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     o.sublimation = sublimation;
     o.pw = pw;
     o.rn_d = rn_d;
-    o.visc = (double)visc_f;
+    o.visc = visc;
     o.econ = econ;
     o.pet_max = pet_max;
 }
 
 // ---- SPLASH helpers ---------------------------------------------------------------------------
-// src/SPLASH.cpp:1921-1961 with z = 10 cm (call at :1265)
+// Theta = (theta - theta_r)/(theta_s - theta_r) for a column holding w mm.  The reference forms
+// theta = w/(depth*1000) with the same expression as theta_r and theta_s, so Theta is EXACTLY 0
+// at w == RES and EXACTLY 1 at w == SAT, and its code is discontinuous there (Theta = 0 puts the
+// water table at the column base, wtd = depth; Theta = 1 at the surface, wtd = 0; one ulp beyond
+// either end lands in the `wtd < 0 || isnan -> 0.01` guard).  The buckets are clamped to
+// [RES, SAT] every day, so both ends are hit constantly: they are reproduced exactly, and the
+// multiply-by-reciprocal form is only used strictly inside the interval.
+__device__ __forceinline__ double rel_saturation(const CellConst& c, double w)
+{
+    double th = (w * c.inv_d1000 - c.theta_r) * c.inv_dtheta;
+    th = th < 0.0 ? 0.0 : th; // rounding of the reciprocal form only (w >= RES)
+    th = th > 1.0 ? 1.0 : th;
+    th = (w == c.RES) ? 0.0 : th;
+    th = (w == c.SAT) ? 1.0 : th;
+    return th;
+}
+
+// src/SPLASH.cpp:1921-1961 with z = 10 cm (call at :1265): Brooks-Corey water content of the
+// top 10 cm.  With L = log(Theta):  psi = bpr*Theta^(-1/lambda),  (psi+z)/bpr =
+// Theta^(-1/lambda) + z/bpr,  theta = dtheta*((psi+z)/bpr)^(-lambda) + theta_r.
 __device__ __forceinline__ double moist_surf(const CellConst& c, double wn)
 {
-    const double z = 10.0;
-    double bubbling_pr = c.bub / 10;
-    double theta_mean = (wn) / (c.d1000);
-    double water_pot_BC = bubbling_pr / pow(((theta_mean - c.theta_r) / c.dtheta), c.inv_lambda);
-    double total_head_BC = water_pot_BC + z;
-    double theta_BC = c.dtheta * pow((total_head_BC / bubbling_pr), (-1 * c.lambda)) + c.theta_r;
-    if (theta_mean < c.theta_r) {
+    const double L = flog(rel_saturation(c, wn));
+    const double head_ratio = fexp(-L * c.inv_lambda) + c.z_bpr;
+    double theta_BC = c.dtheta * fexp(-c.lambda * flog(head_ratio)) + c.theta_r;
+    if (wn < c.RES) { // theta_mean < theta_r
         theta_BC = c.theta_r;
     } else if (isnan(theta_BC)) {
         theta_BC = c.theta_s;
@@ -578,24 +612,20 @@ __device__ __forceinline__ double inf_GA(const CellConst& c, double theta_i, dou
                                          double P)
 {
     const double tdur = 6.0;
-    double r = P / tdur;
-    double delta_head = c.h_f;
-    double delta_theta = (c.theta_s - theta_i);
-    double I = 0.0;
-    if (r <= Ksat) {
-        I = P;
-    } else {
+    const double r = P / tdur;
+    double I = P;
+    if (!(r <= Ksat)) {
+        const double delta_theta = (c.theta_s - theta_i);
         if (delta_theta <= 0.0) {
             I = Ksat * tdur;
         } else {
-            double tp = (Ksat * delta_theta * -1.0 * delta_head) / (r * (r - Ksat));
+            const double hd = c.h_f * delta_theta;
+            double tp = (Ksat * delta_theta * -1.0 * c.h_f) / (r * (r - Ksat));
             if (tp <= 0.0 || isnan(tp)) {
                 tp = 0.01;
             }
-            double tp_s = tp * c.inv_cos2;
-            I = r * tp_s + (Ksat * (tdur - tp_s) -
-                            (delta_head * delta_theta *
-                             log(1 - (r * tp_s / (delta_head * delta_theta)))));
+            const double tp_s = tp * c.inv_cos2;
+            I = r * tp_s + (Ksat * (tdur - tp_s) - (hd * flog(1 - (r * tp_s / hd))));
         }
     }
     if (I > P) {
@@ -604,23 +634,48 @@ __device__ __forceinline__ double inf_GA(const CellConst& c, double theta_i, dou
     return I;
 }
 
-// Transmittance of the column at water content sm (src/SPLASH.cpp:1406-1431 and 1511-1536):
-// returns T_uns already scaled to flux density [mm/day] and guarded, and Acs_out via reference.
+// Unsaturated transmittance of the column at water content sm, scaled to flux density [mm/day]
+// and guarded (src/SPLASH.cpp:1406-1431 and 1511-1536), and the saturated cross-section.
+//   T_uns = C * (A - B),  A = (bub/psi_m)^e,  B = (bub/(psi_m + wtd*1000))^e,  e = 3*lambda+1
+// With L = log(Theta): Theta^(1/lambda) gives psi_m and A = Theta^(e/lambda): one log, two exps.
+// B = A * (1+u)^(-e) with u = wtd*1000/psi_m, so A - B = -A * expm1(-e*log1p(u)):
+//   * water table inside the column (wtd unclamped): psi_m + wtd*1000 == bub to rounding, B = 1
+//     (the reference's base bub/(psi_m+wtd*1000) is 1 +- 1 ulp; kept: B = 1 + e*(x2-1));
+//   * clamped (dry column, wtd = depth, or the 0.01 guard): the expm1/log1p form keeps full
+//     relative accuracy of the DIFFERENCE however close the two powers are.  That matters
+//     although T_uns is then ~1e-30 mm/day: src/SPLASH.cpp:1472 divides by it (Q), so its
+//     relative accuracy -- not its size -- sets the drainage time.  (Past |psi_m| ~ 1e11*depth
+//     the reference's own difference is rounding noise of fl(psi_m + depth*1000): DESIGN.md
+//     "Conditioning"; the parity tests set such cell-days aside.)
 __device__ __forceinline__ double transmittance_uns(const CellConst& c, double Ksat_visc,
                                                     double sm, double& Acs_out)
 {
-    double theta_i = (sm) / (c.d1000);
-    double psi_m = c.bub / pow(((theta_i - c.theta_r) / c.dtheta), c.inv_lambda);
+    const double L = flog(rel_saturation(c, sm));
+    const double psi_m = c.bub / fexp(L * c.inv_lambda);
     double wtd = ((c.bub - psi_m) / 1000.0);
+    bool clamped = false;
     if (wtd < 0.0 || isnan(wtd)) {
         wtd = 0.01;
+        clamped = true;
     } else if (wtd > c.depth) {
         wtd = c.depth;
+        clamped = true;
     }
     Acs_out = (c.depth - wtd) * c.so_cellout;
-    double T_uns = (Ksat_visc * c.tu_coef) * (pow((c.bub / psi_m), c.e3l1) -
-                                              pow((c.bub / (psi_m + (wtd * 1000.0))), c.e3l1));
-    T_uns *= c.tu_fac;
+    const double w1000 = wtd * 1000.0;
+    const double A = fexp(L * c.e_uns);
+    double diff; // A - B
+    if (!clamped) {
+        const double x2 = c.bub / (psi_m + w1000);
+        diff = A - fma(c.e3l1, x2 - 1.0, 1.0);
+    } else {
+        const double u = w1000 / psi_m; // in (-1, 0] for a dry column; -0 when psi_m = -inf
+        const double l1p = (fabs(u) < 1.0e-5) ? u * (1.0 - u * (0.5 - u * (1.0 / 3.0))) : flog(1.0 + u);
+        const double z = -c.e3l1 * l1p;
+        const double em1 = (fabs(z) < 1.0e-5) ? z * (1.0 + z * (0.5 + z * (1.0 / 6.0))) : fexp(z) - 1.0;
+        diff = -A * em1;
+    }
+    double T_uns = (Ksat_visc * c.tu_all) * diff;
     if (T_uns < 0.0 || isnan(T_uns)) {
         T_uns = 0.0;
     }
@@ -635,15 +690,8 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     const double wn = st.wn;
     double snow = st.snow, qin = st.qin, td = st.td, nd = st.nd;
 
-    // :984-990 clamp of the start-of-day volumetric content
-    double theta_i = (wn) / (c.d1000);
-    if (theta_i >= c.theta_s) {
-        theta_i = c.theta_s - 0.001;
-    } else if (theta_i <= c.theta_r) {
-        theta_i = c.theta_r + 0.001;
-    }
     // :1042-1048
-    double sw = ((wn - c.RES) / (c.Wmax - c.RES));
+    double sw = (wn - c.RES) * c.inv_wr;
     if (sw < 0.0 || isnan(sw)) {
         sw = 0.0;
     } else if (sw > 1.0) {
@@ -660,33 +708,32 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     Etr ev;
     evap_day(c, d, sw, sw_in, tc, snow, nd, ev); // :1235
     snow -= ev.snowmelt;                          // :1240
-    double snowmelt = ev.snowmelt - ev.sublimation; // :1243
+    const double snowmelt = ev.snowmelt - ev.sublimation; // :1243
 
     // :1260-1272
-    double Ksat_visc = c.int_perm * ((ev.pw * kG) / ev.visc) * 3.6;
-    double inflow = pn + ev.cond + snowmelt;
-    double surf_moist = moist_surf(c, wn);
-    double theta_m = SPL_MAX(c.wm_th, theta_i);
-    double infi = inf_GA(c, surf_moist, Ksat_visc, inflow);
-    double ro_h_arg = inflow - infi;
-    double ro_h = SPL_MAX(ro_h_arg, 0.0);
+    const double Ksat_visc = c.int_perm * ((ev.pw * kG) / ev.visc) * 3.6;
+    const double inflow = pn + ev.cond + snowmelt;
+    const double surf_moist = moist_surf(c, wn);
+    const double infi = inf_GA(c, surf_moist, Ksat_visc, inflow);
+    const double ro_h_arg = inflow - infi;
+    const double ro_h = SPL_MAX(ro_h_arg, 0.0);
     double R = infi - ev.aet;
 
     // :1275-1284
-    double hyd_grad_z = (infi / (Ksat_visc * 24)) - 1.0;
-    double hyd_grad_out = sqrt(hyd_grad_z * hyd_grad_z + c.tan_slop * c.tan_slop);
+    const double hyd_grad_z = (infi / (Ksat_visc * 24)) - 1.0;
+    const double hyd_grad_out = sqrt(hyd_grad_z * hyd_grad_z + c.tan2_slop);
 
     // :1291-1326 (cell-static part folded into kb_coef); Kb and log(Kb) keep the reference's
-    // exp-then-log rounding
-    double Kb = exp(Ksat_visc * c.kb_coef);
-    // :1360
-    double Qt = (Ksat_visc * c.qt_coef) * hyd_grad_out;
+    // exp-then-log rounding.  Kb is only consumed under the two conditions below.
+    const double lkb_arg = Ksat_visc * c.kb_coef;
 
     // :1365-1372
     double q_in_o = 0.0;
-    if ((td <= 0.0) || (qin <= 0.0)) {
-        q_in_o = 0.0;
-    } else {
+    double Kb = 0.0;
+    bool have_kb = false;
+    if (!((td <= 0.0) || (qin <= 0.0))) {
+        Kb = fexp(lkb_arg);
+        have_kb = true;
         q_in_o = qin * Kb;
     }
     // :1377-1397
@@ -705,32 +752,43 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
 
     // :1406-1457 transmittance after recharge
     double Acs_out;
-    double T_uns = transmittance_uns(c, Ksat_visc, sm, Acs_out);
-    double T_sat;
+    const double T_uns1 = transmittance_uns(c, Ksat_visc, sm, Acs_out);
+    const double sm1 = sm;
+    double T_uns = T_uns1, T_sat;
     if (c.deep) { // depth >= 2.0: vertical drainage corrections :1433-1450
-        double Kunsat = Ksat_visc * pow((theta_m / c.theta_s), c.kun_exp); // :1275
+        // :984-990 clamp of the start-of-day volumetric content, :1267 theta_m
+        double theta_i = wn * c.inv_d1000;
+        if (wn >= c.SAT) { // theta_i >= theta_s (division by depth*1000 is monotone)
+            theta_i = c.theta_s - 0.001;
+        } else if (wn <= c.RES) {
+            theta_i = c.theta_r + 0.001;
+        }
+        const double theta_m = SPL_MAX(c.wm_th, theta_i);
+        const double Kunsat = Ksat_visc * fpow((theta_m / c.theta_s), c.kun_exp); // :1275
         T_uns += Kunsat * 24.0;
-        T_sat = Ksat_visc * 24.0 * ((Acs_out + c.Ai) / c.Ai);
+        T_sat = Ksat_visc * 24.0 * ((Acs_out + c.Ai) * c.inv_Ai);
     } else {
-        T_sat = Ksat_visc * 24.0 * (Acs_out / c.Ai);
+        T_sat = Ksat_visc * 24.0 * (Acs_out * c.inv_Ai);
     }
-    double T = (T_sat + T_uns) * hyd_grad_out;
-    double Q = (T * c.Ai) / 1000;
+    const double T = (T_sat + T_uns) * hyd_grad_out;
 
     // :1465-1483
     double t_drain = 0.0;
     double q_in_f = 0.0;
     td -= 1.0;
     if ((R > 0.0) && (sm > c.Wmax)) {
-        double lkb = log(Kb);
-        t_drain = -1.0 * log(1.0 - (lkb * (c.Au * R / Q))) / lkb;
-        q_in_f = (Qt - c.Au * R * lkb) / c.Ai;
+        if (!have_kb) Kb = fexp(lkb_arg);
+        const double Q = (T * c.Ai) / 1000; // :1456
+        const double Qt = (Ksat_visc * c.qt_coef) * hyd_grad_out; // :1360
+        const double lkb = flog(Kb);
+        t_drain = -1.0 * flog(1.0 - (lkb * (c.Au * R / Q))) / lkb;
+        q_in_f = (Qt - c.Au * R * lkb) * c.inv_Ai;
     }
     if (q_in_f < 0.0 || isnan(q_in_f)) {
         q_in_f = 0.0;
     }
-    double td_arg = (td + t_drain) / 2;
-    double tdrain_out = SPL_MAX(td_arg, 0.0);
+    const double td_arg = (td + t_drain) / 2;
+    const double tdrain_out = SPL_MAX(td_arg, 0.0);
 
     // :1488-1506
     sm += (q_in_f);
@@ -740,12 +798,13 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     } else if (sm < c.RES) {
         sm = c.RES;
     }
-    double ro = ro_d + ro_h;
+    const double ro = ro_d + ro_h;
 
-    // :1511-1547 transmittance after upslope inflow (no vertical-drainage correction here)
-    double Acs2;
-    double T_uns2 = transmittance_uns(c, Ksat_visc, sm, Acs2);
-    double T2 = (Ksat_visc * 24.0 * (Acs2 / c.Ai) + T_uns2) * hyd_grad_out;
+    // :1511-1547 transmittance after upslope inflow (no vertical-drainage correction here);
+    // identical to the first evaluation whenever the inflow left sm unchanged
+    double Acs2 = Acs_out, T_uns2 = T_uns1;
+    if (sm != sm1) T_uns2 = transmittance_uns(c, Ksat_visc, sm, Acs2);
+    const double T2 = (Ksat_visc * 24.0 * (Acs2 * c.inv_Ai) + T_uns2) * hyd_grad_out;
 
     // :1552-1567
     sm -= (T2);
@@ -755,8 +814,8 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
         sm = c.RES;
     }
     // :1574
-    double mx = SPL_MAX(q_in_o, q_in_f);
-    double qin_nday = SPL_MAX(mx, 0.0);
+    const double mx = SPL_MAX(q_in_o, q_in_f);
+    const double qin_nday = SPL_MAX(mx, 0.0);
 
     st.wn = sm;
     st.snow = snow;
@@ -775,23 +834,25 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
 // snow_term = elev*0.0004596581 + |lat|*0.0110592101 (cell-static part of snowfall_prob, :576)
 __device__ __forceinline__ double snowfall_prob(double tc, double snow_term)
 {
-    return 1 / (1 + exp(-0.4710405934 + 1.0473543991 * tc - snow_term));
+    return 1 / (1 + fexp(-0.4710405934 + 1.0473543991 * tc - snow_term));
 }
 
 __device__ __forceinline__ void rain_snow_split(const DayConst& d, double tc, double pn, double Tt,
                                                 double snow_term, double& rain, double& snowfall)
 {
-    double p = snowfall_prob(tc, snow_term);
+    // p_snow = 1/(1+exp(x)) >= 0.5  <=>  1+exp(x) <= 2  <=>  x <= 0 (exp is monotone and
+    // exp(0) = 1 exactly), so the logistic itself is not needed for the branch
+    const double x = -0.4710405934 + 1.0473543991 * tc - snow_term;
     double f_rain = 1.0;
-    if (p >= 0.5) {
+    if (x <= 0.0) {
         double Ttm = Tt + (Tt * d.ttm_s);
-        double x = ((tc - Ttm) / d.trm14);
-        double x2 = x * x, x3 = x2 * x;
+        double q = ((tc - Ttm) / d.trm14);
+        double q2 = q * q, q3 = q2 * q;
         double fr;
         if (tc <= Ttm) {
-            fr = 5 * x3 + 6.76 * x2 + 3.19 * x + 0.5;
+            fr = 5 * q3 + 6.76 * q2 + 3.19 * q + 0.5;
         } else {
-            fr = 5 * x3 - 6.76 * x2 + 3.19 * x + 0.5;
+            fr = 5 * q3 - 6.76 * q2 + 3.19 * q + 0.5;
         }
         if (fr < 0) fr = 0;
         if (fr > 1) fr = 1;

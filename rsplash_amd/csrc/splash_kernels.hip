@@ -101,8 +101,9 @@ __global__ __launch_bounds__(kBlock) void k_snow_threshold(size_t ncell, int nt,
 #pragma unroll 4
     for (int t = 0; t < nt; t++) {
         double v = __builtin_nontemporal_load(&tc[(size_t)t * ldf + i]);
-        double p = snowfall_prob(v, snow_term);
-        if (p >= 0.5 && v > best) best = v;
+        // p_snow >= 0.5  <=>  the logistic's exponent <= 0 (see rain_snow_split)
+        const double x = -0.4710405934 + 1.0473543991 * v - snow_term;
+        if (x <= 0.0 && v > best) best = v;
     }
     Tt[i] = best;
 }
@@ -139,83 +140,6 @@ __device__ __forceinline__ DayConst day_const(const DayRec& d)
 }
 
 // ================================================================ K4 spin-up ===================
-// SPLASH::spin_up, src/SPLASH.cpp:1594-1749, for one lane.  The "extra" day-1 step that closes
-// each pass (:1674, :1729) is the same evaluation as day 1 of the following pass, so it is
-// computed once and reused.  Lanes whose loop has ended keep stepping (the wavefront runs until
-// its slowest lane converges) but no longer update their results.
-// series: optional per-day outputs of the LAST executed pass (module mirror), [7][n][ld].
-template <bool SERIES>
-__device__ __forceinline__ int spin_up_lane(const CellConst& c, const DayRec* __restrict__ days,
-                                            int n, const Forcing& f, bool valid, State& final_st,
-                                            double& pet_sum, double& p_sum,
-                                            double* const* series, size_t sld)
-{
-    State e{c.RES, 0.0, 0.0, 0.0, 0.0}; // wn_vec(n,RES) etc. read at [n-1] on day 1, :1633-1648
-    DayOut o;
-    double sw0, tc0, pn0, rain0, snf0;
-    f.raw(0, sw0, tc0, pn0);
-    f.split(days[0], 0, tc0, pn0, rain0, snf0);
-    day_step(c, day_const(days[0]), sw0, tc0, rain0, snf0, e, o);
-    pet_sum = o.pet;
-    p_sum = rain0 + snf0;
-    int count = 1;
-    bool active = valid;
-    bool first = true;
-    final_st = e;
-    for (;;) {
-        State cur = e;
-        const double start_sm = e.wn;
-        double ro0 = o.ro, pet0 = o.pet;
-        if (SERIES && active) {
-            series[0][f.cell] = e.wn;
-            series[1][f.cell] = e.snow;
-            series[2][f.cell] = e.qin;
-            series[3][f.cell] = e.td;
-            series[4][f.cell] = ro0;
-            series[5][f.cell] = e.nd;
-            if (first) series[6][f.cell] = pet0;
-        }
-        double swv, tcv, pnv;
-        f.raw(1, swv, tcv, pnv);
-        for (int i = 1; i < n; i++) {
-            double swn = swv, tcn = tcv, pnn = pnv;
-            if (i + 1 < n) f.raw(i + 1, swn, tcn, pnn); // prefetch next day
-            double rain, snf;
-            f.split(days[i], i, tcv, pnv, rain, snf);
-            day_step(c, day_const(days[i]), swv, tcv, rain, snf, cur, o);
-            if (first) { // pet_vec is only filled in the first pass, :1667 vs :1718-1723
-                pet_sum += o.pet;
-                p_sum += rain + snf;
-            }
-            if (SERIES && active) {
-                size_t k = (size_t)i * sld + f.cell;
-                series[0][k] = cur.wn;
-                series[1][k] = cur.snow;
-                series[2][k] = cur.qin;
-                series[3][k] = cur.td;
-                series[4][k] = o.ro;
-                series[5][k] = cur.nd;
-                if (first) series[6][k] = o.pet;
-            }
-            swv = swn;
-            tcv = tcn;
-            pnv = pnn;
-        }
-        State nxt = cur;
-        day_step(c, day_const(days[0]), sw0, tc0, rain0, snf0, nxt, o); // :1674 / :1729
-        double diff_sm = nxt.wn - start_sm;                              // :1678-1688
-        if (diff_sm < 0) diff_sm = start_sm - nxt.wn;
-        if (active) final_st = cur;
-        bool cont = active && (diff_sm > 1.0) && (count < 1000); // :1697
-        active = cont;
-        if (!__any(active)) break;
-        if (active) count++;
-        e = nxt;
-        first = false;
-    }
-    return count;
-}
-
 // Grid spin-up: both spin-ups of splash.point (R/splash.point.R:141-152) as a resumable per-cell
 // job.  The number of passes is data dependent (2..1000, src/SPLASH.cpp:1697): most cells need
 // 2-5, a few per thousand never meet the 1 mm criterion and run all 1000.  A wavefront costs as
@@ -327,20 +251,51 @@ __global__ __launch_bounds__(kBlock) void k_spin_phase(SpinPhaseArgs a)
     }
 }
 
-// module mirror: one spin-up with explicit snowfall and soil_info-derived cellpar, series out
+// Module mirror of SPLASH::spin_up (src/SPLASH.cpp:1594-1749): ONE spin-up of ONE cell with an
+// explicit snowfall series, written literally like the reference (a 365-day pass, then the
+// closing day-1 step that tests convergence), returning the series of the last pass.
+// series [7][n]: sm, snow, qin, tdrain, ro, snwage, pet (pet from the first pass only, :1667).
 __global__ __launch_bounds__(64) void k_spin_up_mod(SpinArgs a, double* const* series, size_t sld,
                                                    const double* snowfall)
 {
-    size_t cell = (size_t)blockIdx.x * 64 + threadIdx.x;
-    const bool valid = cell < a.ncell;
-    const size_t ci = valid ? cell : a.ncell - 1;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const size_t ci = 0;
     Forcing f{a.sw, a.tc, a.pn, snowfall, a.ldf, 0.0, 0.0, ci};
     CellConst c;
     cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci]);
-    State st;
-    double pet_sum, p_sum;
-    int p1 = spin_up_lane<true>(c, a.days, a.n, f, valid, st, pet_sum, p_sum, series, sld);
-    if (valid && a.passes) a.passes[ci] = p1;
+    State w{c.RES, 0.0, 0.0, 0.0, 0.0}; // wn_vec(n,RES), others 0: read at [n-1] on day 1
+    int count = 1;
+    for (;;) {
+        State cur = w;
+        DayOut o;
+        double start_sm = 0.0;
+        for (int i = 0; i < a.n; i++) {
+            double swv, tcv, pnv, rain, snf;
+            f.raw(i, swv, tcv, pnv);
+            f.split(a.days[i], i, tcv, pnv, rain, snf);
+            day_step(c, day_const(a.days[i]), swv, tcv, rain, snf, cur, o);
+            if (i == 0) start_sm = cur.wn;
+            const size_t k = (size_t)i * sld;
+            series[0][k] = cur.wn;
+            series[1][k] = cur.snow;
+            series[2][k] = cur.qin;
+            series[3][k] = cur.td;
+            series[4][k] = o.ro;
+            series[5][k] = cur.nd;
+            if (count == 1) series[6][k] = o.pet;
+        }
+        State nxt = cur; // :1674 / :1729
+        double sw0, tc0, pn0, rain0, snf0;
+        f.raw(0, sw0, tc0, pn0);
+        f.split(a.days[0], 0, tc0, pn0, rain0, snf0);
+        day_step(c, day_const(a.days[0]), sw0, tc0, rain0, snf0, nxt, o);
+        double diff_sm = nxt.wn - start_sm; // :1678-1688
+        if (diff_sm < 0) diff_sm = start_sm - nxt.wn;
+        if (!((diff_sm > 1.0) && (count < 1000))) break; // :1697
+        w = cur;
+        count++;
+    }
+    if (a.passes) a.passes[0] = count;
 }
 
 // ================================================================ K5 run_all ===================
@@ -490,14 +445,17 @@ __global__ __launch_bounds__(64) void k_run_all_mod(RunArgs a)
 }
 
 // fixed-order reduction of the per-workgroup diagnostic partials: diag[m][k] += sum_b part[b][m][k]
-__global__ void k_diag_reduce(const double* __restrict__ part, size_t nblocks, int nmonth,
-                              double* __restrict__ diag)
+// one wavefront per element: lane l sums blocks l, l+64, ... then a butterfly (deterministic)
+__global__ __launch_bounds__(64) void k_diag_reduce(const double* __restrict__ part,
+                                                   size_t nblocks, int nmonth,
+                                                   double* __restrict__ diag)
 {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nmonth * SPLASH_NDIAG_K) return;
+    const int e = blockIdx.x;
+    const size_t stride = (size_t)nmonth * SPLASH_NDIAG_K;
     double s = 0.0;
-    for (size_t b = 0; b < nblocks; b++) s += part[b * (size_t)nmonth * SPLASH_NDIAG_K + e];
-    diag[e] += s;
+    for (size_t b = threadIdx.x; b < nblocks; b += 64) s += part[b * stride + e];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) diag[e] += s;
 }
 
 // ================================================================ test hooks ===================
@@ -520,9 +478,12 @@ __global__ __launch_bounds__(kBlock) void k_evap_batch(size_t m, const double* l
     c.kb = cl * cs + sl * ss * ca;
     c.kc = ss * sa;
     c.tau_o = (kC + kD) * (1.0 + (2.67e-5) * elv[i]);
+    c.tau_a = c.tau_o * 0.1898;
+    c.tau_binv = 1.0 / (c.tau_o * (1 - 0.1898));
     double ep = (kG * kMa) / (kR * kL);
     c.patm = pow((1.0 - elv[i] * kL / kTo), ep) * kPo;
     c.patm_f = (float)c.patm;
+    c.visc0 = (double)viscosity_h2o(0.0f, c.patm_f);
     DayConst d{dr[i], sd[i], cd[i], 0.0, 1.0};
     Etr e;
     evap_day(c, d, sw[i], sw_in[i], tc[i], snow[i], nd[i], e);
@@ -538,6 +499,19 @@ __global__ __launch_bounds__(kBlock) void k_evap_batch(size_t m, const double* l
     o[8] = e.rn_d;
     o[9] = e.visc;
     o[10] = e.pet_max;
+}
+
+// flog / fexp / fpow / facos on the device (the host build of the same header is checked against
+// libm by tests/csrc/test_math.cpp; this probe checks the device build)
+__global__ __launch_bounds__(kBlock) void k_math_probe(size_t n, const double* x, const double* y,
+                                                      double* out)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    out[i] = flog(x[i]);
+    out[n + i] = fexp(x[i]);
+    out[2 * n + i] = fpow(x[i], y[i]);
+    out[3 * n + i] = facos(x[i]);
 }
 
 // general-argument forms of the two exported helper methods (src/SPLASH.cpp:1921-1961, 1963-2023)
@@ -753,8 +727,7 @@ hipError_t launch_diag_reduce(const double* part, size_t nblocks, int nmonth, do
 {
     int e = nmonth * SPLASH_NDIAG_K;
     if (e == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_diag_reduce, dim3((e + 63) / 64), dim3(64), 0, s, part, nblocks, nmonth,
-                       diag);
+    hipLaunchKernelGGL(k_diag_reduce, dim3(e), dim3(64), 0, s, part, nblocks, nmonth, diag);
     return hipGetLastError();
 }
 
@@ -769,6 +742,13 @@ hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, con
     if (m == 0) return hipSuccess;
     hipLaunchKernelGGL(k_evap_batch, dim3(nblk(m, kBlock)), dim3(kBlock), 0, s, m, lat, elv, sw, dr,
                        sd, cd, sw_in, tc, slop, asp, snow, nd, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_math_probe(size_t n, const double* x, const double* y, double* out, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_math_probe, dim3(nblk(n, kBlock)), dim3(kBlock), 0, s, n, x, y, out);
     return hipGetLastError();
 }
 

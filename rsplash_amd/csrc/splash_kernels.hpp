@@ -102,6 +102,7 @@ hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, con
                              const double* sw_in, const double* tc, const double* slop,
                              const double* asp, const double* snow, const double* nd, double* out,
                              hipStream_t s);
+hipError_t launch_math_probe(size_t n, const double* x, const double* y, double* out, hipStream_t s);
 hipError_t launch_moist_surf(double depth, double z, double bub_p, double wn, double SAT,
                              double RES, double lambda, double* out, hipStream_t s);
 hipError_t launch_inf_GA(double bub_press, double theta_i, double Ksat, double theta_s,

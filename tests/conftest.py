@@ -50,15 +50,19 @@ def kat():
     return dict(np.load(os.path.join(GOLD, "ref_evap_kat.npz")))
 
 
-def rel_err(x, ref, floor=1e-9):
-    """max relative error where |ref| > floor, max abs error elsewhere"""
+ATOL = 1e-9  # mm (or mm/day): below any physical meaning; guards values that should be ~0
+
+
+def rel_err(x, ref, atol=ATOL):
+    """worst |x-ref| / (|ref| + atol/rtol-free form): returns (max relative error over entries with
+    |ref| > 1e-4, max absolute error over all entries).  The NaN pattern must match exactly."""
     x, ref = np.asarray(x, float), np.asarray(ref, float)
     assert x.shape == ref.shape
     nanx, nanr = np.isnan(x), np.isnan(ref)
     assert (nanx == nanr).all(), f"NaN pattern differs: {nanx.sum()} vs {nanr.sum()}"
     ok = ~nanr
-    big = ok & (np.abs(ref) > floor)
-    rel = float(np.max(np.abs(x[big] - ref[big]) / np.abs(ref[big]))) if big.any() else 0.0
-    small = ok & ~big
-    ab = float(np.max(np.abs(x[small] - ref[small]))) if small.any() else 0.0
-    return rel, ab
+    err = np.abs(x[ok] - ref[ok])
+    r = np.abs(ref[ok])
+    excess = err - atol  # error beyond the absolute floor, relative to |ref|
+    rel = float(np.max(np.where(excess > 0, excess / np.maximum(r, 1e-300), 0.0))) if err.size else 0.0
+    return rel, float(err.max()) if err.size else 0.0
