@@ -76,7 +76,7 @@ struct CellConst {
     double SAT, RES, Au, Ai, inv_Ai;
     double d1000, inv_d1000; // depth*1000 and its inverse
     double depth;
-    double theta_s, theta_r, dtheta, inv_dtheta; // dtheta = theta_s - theta_r
+    double theta_s, inv_theta_s, theta_r, dtheta, inv_dtheta; // dtheta = theta_s - theta_r
     double inv_lambda, e3l1, e_uns; // 1/lambda, 3*lambda+1, (3*lambda+1)/lambda
     double lambda;
     double bub, bpr, z_bpr; // bubbling pressure [mm], [cm], 10 cm / bpr
@@ -357,6 +357,7 @@ __device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, 
     // src/SPLASH.cpp:971-993
     const double KG_o = 1000.0 / (997 * kG);
     c.theta_s = SAT / c.d1000;
+    c.inv_theta_s = 1.0 / c.theta_s;
     c.theta_r = RES / c.d1000;
     c.dtheta = c.theta_s - c.theta_r;
     c.inv_dtheta = 1.0 / c.dtheta;
@@ -508,24 +509,28 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     rnn_d *= (86400.0 / kPI);
 
     // ----- EVAP
-    double s; // sat_slope :299-301
+    double s; // sat_slope :299-301 (tc + 237.3 > 0 for any air temperature above -237 C)
     {
-        const double inv_q = 1.0 / (tc + 237.3);
+        const double inv_q = frcp(tc + 237.3);
         s = fexp((tc * 17.269) * inv_q) * (inv_q * inv_q) * ((17.269) * (237.3) * (610.78));
     }
     double lv; // enthalpy_vap :313-315
     {
-        const double q = (tc + 273.15) / (tc + 273.15 - 33.91);
+        const double u = tc + 273.15;
+        const double q = u * frcp(u - 33.91);
         lv = q * q * 1.91846e6;
     }
     const double pw = density_h2o(tc, c.patm);                        // :113
-    const double g = (kMa * specific_heat(tc) * c.patm) / (kMv * lv); // psychro :486
+    const double g = (kMa * specific_heat(tc) * c.patm) * frcp(kMv * lv); // psychro :486
     const double lvpw = lv * pw;
-    const double econ = s / (lvpw * (s + g));                         // :117
+    // econ = s/(lv*pw*(s+g)) (:117) and s/(lv*pw*(s+0.24g)) (:129) from one reciprocal
+    const double sg1 = s + g, sg2 = s + 0.24 * g;
+    const double inv_e = frcp(lvpw * sg1 * sg2);
+    const double econ = s * sg2 * inv_e;
     double visc = c.visc0;                                            // :100-105, :120
     if (!(tc < 0.0)) visc = (double)viscosity_h2o((float)tc, c.patm_f);
     const double cn = (1.0e3) * econ * fabs(rnn_d) * 0.1;             // :124
-    const double eet_d = (1.0e3) * (s / (lvpw * (s + 0.24 * g))) * rn_d; // :129
+    const double eet_d = (1.0e3) * (s * sg1 * inv_e) * rn_d;          // :129
     const double rx = (3.6e6) * econ;                                 // :145
     const double pet_max = rx * ((rw * (ru + rv)) - rnl);             // :148
 
@@ -543,13 +548,13 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     if (tc >= 3.0) {
         const double m = (rn_d / (pw * kKfus)) * 1000.0;
         snowmelt = SPL_MIN(snow, m);
-        melt_enrg = (snowmelt / 1000) * pw * kKfus;
+        melt_enrg = (snowmelt * 1.0e-3) * pw * kKfus;
     }
     {
         const double AE = rn_d - melt_enrg;
         const double sub_c = (AE * econ) * 1000.0;
         sublimation = SPL_MIN(snowmelt, sub_c);
-        melt_enrg += ((sublimation / 1000.0) / econ);
+        melt_enrg += ((sublimation * 1.0e-3) / econ);
     }
 
     double aet_d = sup * hi; // :254-263
@@ -607,14 +612,16 @@ __device__ __forceinline__ double moist_surf(const CellConst& c, double wn)
     return theta_BC;
 }
 
-// src/SPLASH.cpp:1963-2023 with tdur = 6 h (call at :1268)
-__device__ __forceinline__ double inf_GA(const CellConst& c, double theta_i, double Ksat,
-                                         double P)
+// src/SPLASH.cpp:1963-2023 with tdur = 6 h (call at :1268).  The surface moisture (moist_surf,
+// :1265) only enters when the rain rate exceeds the conductivity, so it is evaluated inside that
+// branch (two logs and two exps saved on every other cell-day).
+__device__ __forceinline__ double inf_GA(const CellConst& c, double wn, double Ksat, double P)
 {
     const double tdur = 6.0;
-    const double r = P / tdur;
+    const double r = P * (1.0 / 6.0); // P/tdur
     double I = P;
     if (!(r <= Ksat)) {
+        const double theta_i = moist_surf(c, wn);
         const double delta_theta = (c.theta_s - theta_i);
         if (delta_theta <= 0.0) {
             I = Ksat * tdur;
@@ -652,7 +659,7 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
 {
     const double L = flog(rel_saturation(c, sm));
     const double psi_m = c.bub / fexp(L * c.inv_lambda);
-    double wtd = ((c.bub - psi_m) / 1000.0);
+    double wtd = ((c.bub - psi_m) * 1.0e-3);
     bool clamped = false;
     if (wtd < 0.0 || isnan(wtd)) {
         wtd = 0.01;
@@ -711,16 +718,15 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     const double snowmelt = ev.snowmelt - ev.sublimation; // :1243
 
     // :1260-1272
-    const double Ksat_visc = c.int_perm * ((ev.pw * kG) / ev.visc) * 3.6;
+    const double Ksat_visc = c.int_perm * ((ev.pw * kG) * frcp(ev.visc)) * 3.6;
     const double inflow = pn + ev.cond + snowmelt;
-    const double surf_moist = moist_surf(c, wn);
-    const double infi = inf_GA(c, surf_moist, Ksat_visc, inflow);
+    const double infi = inf_GA(c, wn, Ksat_visc, inflow);
     const double ro_h_arg = inflow - infi;
     const double ro_h = SPL_MAX(ro_h_arg, 0.0);
     double R = infi - ev.aet;
 
     // :1275-1284
-    const double hyd_grad_z = (infi / (Ksat_visc * 24)) - 1.0;
+    const double hyd_grad_z = (infi * frcp(Ksat_visc * 24)) - 1.0;
     const double hyd_grad_out = sqrt(hyd_grad_z * hyd_grad_z + c.tan2_slop);
 
     // :1291-1326 (cell-static part folded into kb_coef); Kb and log(Kb) keep the reference's
@@ -764,7 +770,7 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
             theta_i = c.theta_r + 0.001;
         }
         const double theta_m = SPL_MAX(c.wm_th, theta_i);
-        const double Kunsat = Ksat_visc * fpow((theta_m / c.theta_s), c.kun_exp); // :1275
+        const double Kunsat = Ksat_visc * fpow((theta_m * c.inv_theta_s), c.kun_exp); // :1275
         T_uns += Kunsat * 24.0;
         T_sat = Ksat_visc * 24.0 * ((Acs_out + c.Ai) * c.inv_Ai);
     } else {
@@ -778,7 +784,7 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     td -= 1.0;
     if ((R > 0.0) && (sm > c.Wmax)) {
         if (!have_kb) Kb = fexp(lkb_arg);
-        const double Q = (T * c.Ai) / 1000; // :1456
+        const double Q = (T * c.Ai) * 1.0e-3; // :1456
         const double Qt = (Ksat_visc * c.qt_coef) * hyd_grad_out; // :1360
         const double lkb = flog(Kb);
         t_drain = -1.0 * flog(1.0 - (lkb * (c.Au * R / Q))) / lkb;
@@ -827,7 +833,7 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     o.aet = ev.aet;
     o.cond = ev.cond;
     o.bflow = T2;
-    o.netr = ev.rn_d / 1e6; // src/SPLASH.cpp:1907
+    o.netr = ev.rn_d * 1.0e-6; // src/SPLASH.cpp:1907
 }
 
 // ---- rain / snow split: R/splash.point.R:120-128, 521-578 -------------------------------------

@@ -13,6 +13,11 @@ namespace splash {
 
 static constexpr int kBlock = 256;
 
+// minimum waves per SIMD requested from the register allocator for the two day-loop kernels
+#ifndef SPLASH_RUNALL_WPE
+#define SPLASH_RUNALL_WPE 2
+#endif
+
 // ================================================================ K1 soil_hydro ===============
 // R/splash.point.R:232-416 (soil_hydro) + :96-115 (soil_info) + :131 (asp-180)
 __global__ __launch_bounds__(kBlock) void k_soil_hydro(
@@ -149,7 +154,7 @@ __device__ __forceinline__ DayConst day_const(const DayRec& d)
 // list, so the long-running cells end up packed into few dense waves.
 //   job stage 1: spin-up #1 (cellout as given); its first pass also yields the aridity index
 //   job stage 2: spin-up #2 with cellout := AI (R/splash.point.R:150)
-__global__ __launch_bounds__(kBlock) void k_spin_phase(SpinPhaseArgs a)
+__global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPhaseArgs a)
 {
     const size_t nin = a.n_in ? (size_t)*a.n_in : a.ncell;
     if ((size_t)blockIdx.x * kBlock >= nin) return; // whole workgroup past the list
@@ -309,7 +314,7 @@ __device__ __forceinline__ double wave_sum(double v)
 // SPLASH::run_all, src/SPLASH.cpp:1833-1916 (+ sm_lim and monthly aggregation of
 // R/splash.point.R:197-214, + monthly grid totals for the water-balance diagnostics).
 template <bool MONTHLY, bool DIAG>
-__global__ __launch_bounds__(kBlock) void k_run_all(RunArgs a)
+__global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a)
 {
     __shared__ double red[DIAG ? 4 * SPLASH_NDIAG_K : 1];
     size_t cell = (size_t)blockIdx.x * kBlock + threadIdx.x;
