@@ -137,7 +137,7 @@ int splash_dev_evap_batch(size_t m, const double* lat, const double* elv, const 
                           const double* nd, double* out, void* stream);
 
 /* test hook: the device build of the FP64 log/exp/pow/acos used by the day step, for n arguments
- * (host pointers): out [4][n] = flog(x), fexp(x), fpow(x,y), facos(x) */
+ * (host pointers): out [5][n] = flog(x), fexp(x), fpow(x,y), facos(x), fsqrt(x) */
 int splash_dev_math_probe(size_t n, const double* x, const double* y, double* out);
 
 /* ---------------------------------------------------------------- host-buffer entry points - */

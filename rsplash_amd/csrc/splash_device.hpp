@@ -441,8 +441,13 @@ __device__ __forceinline__ void hour_angle(double cosv, bool at_one_is_zero, dou
         sinh_ = at_one_is_zero ? kSinPi : 0.0;
     } else {
         const double x = at_one_is_zero ? cosv : -cosv;
+#if defined(SPL_ABLATE) && SPL_ABLATE == 2
+        h = 1.0 - x;
+        sinh_ = x;
+#else
         h = facos(x);
-        sinh_ = sqrt((1.0 - x) * (1.0 + x));
+        sinh_ = fsqrt((1.0 - x) * (1.0 + x));
+#endif
     }
 }
 
@@ -458,7 +463,7 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     const double b2c2 = b * b + cc * cc;
     const double dd = b2c2 - a * a;
     const double acc = a * cc;
-    const double num = (dd < 0) ? acc : (acc + b * sqrt(dd)); // :133-137
+    const double num = (dd < 0) ? acc : (acc + b * fsqrt(dd < 0 ? 0.0 : dd)); // :133-137
     const double sinfirst = num / b2c2;
     const double ru = -1 * a + cc * sinfirst;
     const double rv = b;
@@ -476,7 +481,11 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     } else {
         tau = r_in / ra_d;
     }
+#if defined(SPL_ABLATE) && SPL_ABLATE == 4
+    double sf = (tau - c.tau_a) * c.tau_binv;
+#else
     double sf = fpow((tau - c.tau_a) * c.tau_binv, (1 / 0.7410)); // :197
+#endif
     if (isnan(sf)) {
         sf = 0.0;
     } else if (sf > 1.0) {
@@ -520,7 +529,11 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
         const double q = u * frcp(u - 33.91);
         lv = q * q * 1.91846e6;
     }
+#if defined(SPL_ABLATE) && SPL_ABLATE == 5
+    const double pw = 1000.0 - 0.1 * tc;
+#else
     const double pw = density_h2o(tc, c.patm);                        // :113
+#endif
     const double g = (kMa * specific_heat(tc) * c.patm) * frcp(kMv * lv); // psychro :486
     const double lvpw = lv * pw;
     // econ = s/(lv*pw*(s+g)) (:117) and s/(lv*pw*(s+0.24g)) (:129) from one reciprocal
@@ -528,7 +541,9 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     const double inv_e = frcp(lvpw * sg1 * sg2);
     const double econ = s * sg2 * inv_e;
     double visc = c.visc0;                                            // :100-105, :120
+#if !(defined(SPL_ABLATE) && SPL_ABLATE == 1)
     if (!(tc < 0.0)) visc = (double)viscosity_h2o((float)tc, c.patm_f);
+#endif
     const double cn = (1.0e3) * econ * fabs(rnn_d) * 0.1;             // :124
     const double eet_d = (1.0e3) * (s * sg1 * inv_e) * rn_d;          // :129
     const double rx = (3.6e6) * econ;                                 // :145
@@ -657,6 +672,10 @@ __device__ __forceinline__ double inf_GA(const CellConst& c, double wn, double K
 __device__ __forceinline__ double transmittance_uns(const CellConst& c, double Ksat_visc,
                                                     double sm, double& Acs_out)
 {
+#if defined(SPL_ABLATE) && SPL_ABLATE == 3
+    Acs_out = (c.depth - 0.5 * c.depth) * c.so_cellout;
+    return Ksat_visc * 1e-3 * sm;
+#endif
     const double L = flog(rel_saturation(c, sm));
     const double psi_m = c.bub / fexp(L * c.inv_lambda);
     double wtd = ((c.bub - psi_m) * 1.0e-3);
@@ -727,7 +746,7 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
 
     // :1275-1284
     const double hyd_grad_z = (infi * frcp(Ksat_visc * 24)) - 1.0;
-    const double hyd_grad_out = sqrt(hyd_grad_z * hyd_grad_z + c.tan2_slop);
+    const double hyd_grad_out = fsqrt(hyd_grad_z * hyd_grad_z + c.tan2_slop);
 
     // :1291-1326 (cell-static part folded into kb_coef); Kb and log(Kb) keep the reference's
     // exp-then-log rounding.  Kb is only consumed under the two conditions below.

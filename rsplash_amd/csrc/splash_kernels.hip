@@ -357,7 +357,11 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
             size_t k = (size_t)t * a.ldo + ci;
 #pragma unroll
             for (int q = 0; q < 9; q++)
+#if defined(SPL_ABLATE) && SPL_ABLATE == 6
+                if (a.out[q] && valid && v[q] == -12345.678) __builtin_nontemporal_store(v[q], &a.out[q][k]);
+#else
                 if (a.out[q] && valid) __builtin_nontemporal_store(v[q], &a.out[q][k]);
+#endif
         } else {
 #pragma unroll
             for (int q = 0; q < 9; q++) acc[q] += v[q];
@@ -517,6 +521,7 @@ __global__ __launch_bounds__(kBlock) void k_math_probe(size_t n, const double* x
     out[n + i] = fexp(x[i]);
     out[2 * n + i] = fpow(x[i], y[i]);
     out[3 * n + i] = facos(x[i]);
+    out[4 * n + i] = fsqrt(x[i]);
 }
 
 // general-argument forms of the two exported helper methods (src/SPLASH.cpp:1921-1961, 1963-2023)

@@ -36,6 +36,24 @@ SPL_HD double frcp(double b)
 #endif
 }
 
+// Square root to ~1 ulp for x >= 0 in the normal range (0 and NaN handled): hardware reciprocal
+// square root seed (v_rsq_f64) + two Heron steps, without the range scaling of the IEEE routine.
+// NOT correctly rounded: never used where the reference's result is subsequently rounded to
+// float (the viscosity routine keeps the library sqrt).
+SPL_HD double fsqrt(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = __builtin_amdgcn_rsq(x);
+    double y = x * r;
+    const double h = 0.5 * r;
+    y = fma(fma(-y, y, x), h, y);
+    y = fma(fma(-y, y, x), h, y);
+    return (x == 0.0) ? x : y;
+#else
+    return sqrt(x);
+#endif
+}
+
 // natural logarithm, < 1 ulp for normal positive x; log(0) = -inf, log(x<0) = NaN.
 // Branch-free: the series runs for every argument and special values are patched by selects.
 SPL_HD double flog(double x)
@@ -97,7 +115,10 @@ SPL_HD double fexp(double x)
 SPL_HD double fpow(double x, double y) { return fexp(y * flog(x)); }
 
 // arc cosine in radians, |x| <= 1 (callers guard the range), < 2.5 ulp.
-// fdlibm e_acos.c scheme: rational approximation of asin on [0, 0.5], reflection elsewhere.
+// fdlibm e_acos.c scheme (rational approximation R(z) of (asin(t)-t)/t^3 on t^2 = z <= 0.25,
+// reflection elsewhere), written branch-free: both ranges share one evaluation of R with
+// z = x^2 (|x| <= 0.5) or z = (1-|x|)/2, so a wavefront whose lanes fall in different ranges
+// does not run two copies of the polynomial.
 SPL_HD double facos(double x)
 {
     const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
@@ -108,24 +129,18 @@ SPL_HD double facos(double x)
     const double qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00,
                  qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
     const double ax = fabs(x);
-    if (ax <= 0.5) {
-        const double z = x * x;
-        const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-        const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-        const double r = p * frcp(q);
-        return pio2_hi - (x - (pio2_lo - x * r));
-    }
-    const double z = (1.0 - ax) * 0.5;
+    const bool small = ax <= 0.5;
+    const double z = small ? x * x : (1.0 - ax) * 0.5;
     const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
     const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-    const double s = sqrt(z);
-    const double r = p * frcp(q);
-    if (x < 0.0) {
-        const double w = r * s - pio2_lo;
-        return pi - 2.0 * (s + w);
-    }
-    // x > 0.5: 2*asin(sqrt(z))
-    return 2.0 * (s + r * s);
+    const double r = p * frcp(q); // q in [0.3, 1]
+    // |x| <= 0.5: pi/2 - (x + x*r)
+    const double a_small = pio2_hi - (x - (pio2_lo - x * r));
+    // |x| > 0.5: 2*asin(sqrt(z)), reflected for x < 0
+    const double s = fsqrt(small ? 0.25 : z);
+    const double v = 2.0 * (s + r * s);
+    const double a_large = (x < 0.0) ? pi - (v - 2.0 * pio2_lo) : v;
+    return small ? a_small : a_large;
 }
 
 } // namespace splash

@@ -75,6 +75,7 @@ def test_device_math_vs_libm(api):
     out = api.math_probe(x, y)
     ulp = lambda a, b: np.abs(a - b) / np.spacing(np.abs(b))
     assert ulp(out[0], np.log(x)).max() <= 1.5
+    assert ulp(out[4], np.sqrt(x)).max() <= 1.5
     xe = np.r_[rng.uniform(-40, 40, n // 2), rng.uniform(-740, 700, n // 2)]
     oe = api.math_probe(xe, y)[1]
     assert ulp(oe, np.exp(xe)).max() <= 1.5
@@ -92,6 +93,7 @@ def test_device_math_vs_libm(api):
     assert sp[0][4] == 0.0 and sp[1][0] == 1.0 and sp[1][2] == np.inf and np.isnan(sp[1][3])
     assert sp[2][0] == 0.0 and np.isnan(sp[2][1])
     assert api.math_probe(np.array([-np.inf, -800.0]), np.ones(2))[1].tolist() == [0.0, 0.0]
+    assert sp[4][0] == 0.0 and np.isnan(sp[4][1]) and np.isnan(sp[4][3]) and sp[4][4] == 1.0
 
 
 # ---------------------------------------------------------------- module mirrors
