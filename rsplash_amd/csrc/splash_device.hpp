@@ -662,7 +662,7 @@ __device__ __forceinline__ double inf_GA(const CellConst& c, double wn, double K
 // With L = log(Theta): Theta^(1/lambda) gives psi_m and A = Theta^(e/lambda): one log, two exps.
 // B = A * (1+u)^(-e) with u = wtd*1000/psi_m, so A - B = -A * expm1(-e*log1p(u)):
 //   * water table inside the column (wtd unclamped): psi_m + wtd*1000 == bub to rounding, B = 1
-//     (the reference's base bub/(psi_m+wtd*1000) is 1 +- 1 ulp; kept: B = 1 + e*(x2-1));
+//     (the reference's base bub/(psi_m+wtd*1000) is 1 +- 1 ulp, i.e. B = 1 +- 2e-16);
 //   * clamped (dry column, wtd = depth, or the 0.01 guard): the expm1/log1p form keeps full
 //     relative accuracy of the DIFFERENCE however close the two powers are.  That matters
 //     although T_uns is then ~1e-30 mm/day: src/SPLASH.cpp:1472 divides by it (Q), so its
@@ -677,7 +677,7 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
     return Ksat_visc * 1e-3 * sm;
 #endif
     const double L = flog(rel_saturation(c, sm));
-    const double psi_m = c.bub / fexp(L * c.inv_lambda);
+    const double psi_m = c.bub * fexp(-L * c.inv_lambda); // bub / Theta^(1/lambda)
     double wtd = ((c.bub - psi_m) * 1.0e-3);
     bool clamped = false;
     if (wtd < 0.0 || isnan(wtd)) {
@@ -692,8 +692,7 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
     const double A = fexp(L * c.e_uns);
     double diff; // A - B
     if (!clamped) {
-        const double x2 = c.bub / (psi_m + w1000);
-        diff = A - fma(c.e3l1, x2 - 1.0, 1.0);
+        diff = A - 1.0; // bub/(psi_m + wtd*1000) is 1 +- 1 ulp: B = 1 to 1e-16
     } else {
         const double u = w1000 / psi_m; // in (-1, 0] for a dry column; -0 when psi_m = -inf
         const double l1p = (fabs(u) < 1.0e-5) ? u * (1.0 - u * (0.5 - u * (1.0 / 3.0))) : flog(1.0 + u);
