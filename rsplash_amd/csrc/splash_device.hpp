@@ -291,13 +291,8 @@ __device__ __forceinline__ double specific_heat(double tc)
     } else if (tc > 100) {
         cp = 2031.2260590;
     } else {
-        double t2 = tc * tc, t3 = t2 * tc, t4 = t3 * tc, t5 = t4 * tc;
-        cp = 1.0045714270;
-        cp += (2.050632750e-3) * tc;
-        cp += -(1.631537093e-4) * t2;
-        cp += (6.212300300e-6) * t3;
-        cp += -(8.830478888e-8) * t4;
-        cp += (5.071307038e-10) * t5;
+        cp = horner5((5.071307038e-10), tc, -(8.830478888e-8), (6.212300300e-6), -(1.631537093e-4),
+                     (2.050632750e-3), 1.0045714270);
         cp *= (1.0e3);
     }
     return cp;

@@ -20,6 +20,61 @@
 
 namespace splash {
 
+// p*r + C with the constant C held in a scalar register pair.  For a Horner step with a constant
+// that is not an inline literal hipcc emits v_mov_b32 x2 + v_fmac_f64 (the VOP2 form wants C in
+// the destination VGPR): three VALU issues instead of one.  Written as the VOP3 form with C as
+// the single scalar operand, the constant is materialised on the scalar pipe (s_mov_b32) and the
+// step is one v_fma_f64.  Polynomials are a large share of the day step, so this matters.
+SPL_HD double hfma(double p, double r, double C)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "s"(C));
+    return d;
+#else
+    return fma(p, r, C);
+#endif
+}
+
+// Whole Horner chains in one asm statement (hipcc pads every separate asm statement whose result
+// feeds the next with an s_nop; inside one statement the dependent v_fma_f64 issue back to back,
+// exactly as compiler-generated chains do).  p = (((c0*r + c1)*r + c2)*r + ...).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SPL_H1 "v_fma_f64 %0, %1, %2, %3\n\t"
+#define SPL_HN(k) "v_fma_f64 %0, %0, %2, %" #k "\n\t"
+SPL_HD double horner3(double c0, double r, double c1, double c2, double c3)
+{
+    double p;
+    asm(SPL_H1 SPL_HN(4) SPL_HN(5) : "=&v"(p) : "v"(c0), "v"(r), "s"(c1), "s"(c2), "s"(c3));
+    return p;
+}
+SPL_HD double horner2(double c0, double r, double c1, double c2)
+{
+    double p;
+    asm(SPL_H1 SPL_HN(4) : "=&v"(p) : "v"(c0), "v"(r), "s"(c1), "s"(c2));
+    return p;
+}
+SPL_HD double horner5(double c0, double r, double c1, double c2, double c3, double c4, double c5)
+{
+    double p;
+    asm(SPL_H1 SPL_HN(4) SPL_HN(5) SPL_HN(6) SPL_HN(7)
+        : "=&v"(p) : "v"(c0), "v"(r), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5));
+    return p;
+}
+#undef SPL_H1
+#undef SPL_HN
+#else
+SPL_HD double horner2(double c0, double r, double c1, double c2) { return fma(fma(c0, r, c1), r, c2); }
+SPL_HD double horner3(double c0, double r, double c1, double c2, double c3)
+{
+    return fma(fma(fma(c0, r, c1), r, c2), r, c3);
+}
+SPL_HD double horner5(double c0, double r, double c1, double c2, double c3, double c4, double c5)
+{
+    return fma(fma(fma(fma(fma(c0, r, c1), r, c2), r, c3), r, c4), r, c5);
+}
+#endif
+
 // Reciprocal for a finite, nonzero, normal-range argument: hardware seed (v_rcp_f64, ~2^-24
 // relative) + two Newton steps -> ~1 ulp.  Skips the range scaling and special-case fix-up of a
 // full IEEE division (6 instead of ~11 VALU instructions); only for denominators that are known
@@ -71,8 +126,8 @@ SPL_HD double flog(double x)
     const double f = m - 1.0; // exact
     const double s = f * frcp(2.0 + f); // 2+f in [1.7, 2.42]
     const double z = s * s, w = z * z;
-    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double t1 = w * horner2(Lg6, w, Lg4, Lg2);
+    const double t2 = z * horner3(Lg7, w, Lg5, Lg3, Lg1);
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)e;
@@ -91,17 +146,9 @@ SPL_HD double fexp(double x)
     const double k = rint(xc * log2e);
     const double r = fma(-k, ln2_lo, fma(-k, ln2_hi, xc)); // |r| <= ln2/2 (+ tiny)
     // exp(r) by its series to degree 13: remainder (ln2/2)^14/14! = 4e-18
-    double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
+    double p = horner5(1.0 / 6227020800.0, r, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0,
+                       1.0 / 362880.0, 1.0 / 40320.0);
+    p = horner5(p, r, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -131,8 +178,8 @@ SPL_HD double facos(double x)
     const double ax = fabs(x);
     const bool small = ax <= 0.5;
     const double z = small ? x * x : (1.0 - ax) * 0.5;
-    const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-    const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const double p = z * horner5(pS5, z, pS4, pS3, pS2, pS1, pS0);
+    const double q = fma(z, horner3(qS4, z, qS3, qS2, qS1), 1.0);
     const double r = p * frcp(q); // q in [0.3, 1]
     // |x| <= 0.5: pi/2 - (x + x*r)
     const double a_small = pio2_hi - (x - (pio2_lo - x * r));
