@@ -95,6 +95,20 @@ struct CellConst {
 // ---- small helpers -------------------------------------------------------------------------
 __device__ __forceinline__ double dsin_deg(double x) { return sin(x * kPir); }
 
+// src/EVAP.cpp:338-389 (Chen et al. 1977) in Horner form for the FP64 path (the evaluation-order
+// faithful form below is only needed where the result is rounded to float)
+__device__ __forceinline__ double density_h2o_fast(double tc, double p)
+{
+    double po = horner3(-(1.00659e-18), tc, (5.044070e-16), -(1.11663e-13), (1.471150e-11));
+    po = horner5(po, tc, -(1.35439e-9), (1.022130e-7), -(9.08659e-6), (6.788260e-5), 0.99983952);
+    const double ko = horner5((1.035530e-7), tc, -(4.91564e-5), 0.01281, -2.29995, 148.1830, 19652.17);
+    const double ca = horner4((8.584e-10), tc, -(7.655e-7), (1.324e-4), (5.223e-4), 3.26138);
+    const double cb = horner4((4.3220e-12), tc, -(1.0100e-9), (8.69900e-8), -(5.8948e-6), (7.2061e-5));
+    const double pbar = (1.0e-5) * p;
+    const double num = (ko + ca * pbar + cb * (pbar * pbar)); // ~2e4
+    return num * frcp(num - pbar) * ((1.0e3) * po);
+}
+
 // src/EVAP.cpp:338-389 (Chen et al. 1977).  Contraction is off so that the value later rounded
 // to float inside the viscosity routine is the same double the reference rounds.
 __device__ __forceinline__ double density_h2o(double tc, double p)
@@ -459,7 +473,7 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     const double dd = b2c2 - a * a;
     const double acc = a * cc;
     const double num = (dd < 0) ? acc : (acc + b * fsqrt(dd < 0 ? 0.0 : dd)); // :133-137
-    const double sinfirst = num / b2c2;
+    const double sinfirst = num * frcp(b2c2);
     const double ru = -1 * a + cc * sinfirst;
     const double rv = b;
     const double ruv = ru / rv;
@@ -527,7 +541,7 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
 #if defined(SPL_ABLATE) && SPL_ABLATE == 5
     const double pw = 1000.0 - 0.1 * tc;
 #else
-    const double pw = density_h2o(tc, c.patm);                        // :113
+    const double pw = density_h2o_fast(tc, c.patm);                   // :113
 #endif
     const double g = (kMa * specific_heat(tc) * c.patm) * frcp(kMv * lv); // psychro :486
     const double lvpw = lv * pw;
@@ -546,11 +560,12 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
 
     // :157-166  EF = 1/(g/(sw*s) + 1) = sw*s/(g + sw*s)
     const double sws = sw * s;
-    double sup = pet_max * (sws / (g + sws));
+    double sup = pet_max * (sws * frcp(g + sws)); // g > 0
     if (sup < 0.0 || isnan(sup)) {
         sup = 0.0;
     }
-    const double cos_hi = (sup / rx + rnl) * inv_rwrv - ruv; // :208
+    const double inv_econ = frcp(econ);
+    const double cos_hi = (sup * (inv_econ * (1.0 / 3.6e6)) + rnl) * inv_rwrv - ruv; // :208
     double hi, sin_hi; // cos_hi >= 1: supply exceeds demand (hi = 0)
     hour_angle(cos_hi, true, hi, sin_hi);
 
@@ -564,7 +579,7 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
         const double AE = rn_d - melt_enrg;
         const double sub_c = (AE * econ) * 1000.0;
         sublimation = SPL_MIN(snowmelt, sub_c);
-        melt_enrg += ((sublimation * 1.0e-3) / econ);
+        melt_enrg += ((sublimation * 1.0e-3) * inv_econ);
     }
 
     double aet_d = sup * hi; // :254-263

@@ -348,9 +348,12 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
         DayOut o;
         day_step(c, day_const(d), swv, tcv, rain, snf, st, o);
 
-        double lim = (st.wn - c.RES) / lim_den; // R/splash.point.R:197-200
-        if (lim < 0) lim = 0.0;
-        if (lim > 1) lim = 1.0;
+        double lim = 0.0;
+        if (a.out[8]) { // R/splash.point.R:197-200 (only when sm_lim is requested)
+            lim = (st.wn - c.RES) / lim_den;
+            if (lim < 0) lim = 0.0;
+            if (lim > 1) lim = 1.0;
+        }
         const double v[9] = {st.wn, o.ro, o.pet, o.aet, st.snow, o.cond, o.bflow, o.netr, lim};
 
         if (!MONTHLY) {

@@ -54,6 +54,13 @@ SPL_HD double horner2(double c0, double r, double c1, double c2)
     asm(SPL_H1 SPL_HN(4) : "=&v"(p) : "v"(c0), "v"(r), "s"(c1), "s"(c2));
     return p;
 }
+SPL_HD double horner4(double c0, double r, double c1, double c2, double c3, double c4)
+{
+    double p;
+    asm(SPL_H1 SPL_HN(4) SPL_HN(5) SPL_HN(6)
+        : "=&v"(p) : "v"(c0), "v"(r), "s"(c1), "s"(c2), "s"(c3), "s"(c4));
+    return p;
+}
 SPL_HD double horner5(double c0, double r, double c1, double c2, double c3, double c4, double c5)
 {
     double p;
@@ -68,6 +75,10 @@ SPL_HD double horner2(double c0, double r, double c1, double c2) { return fma(fm
 SPL_HD double horner3(double c0, double r, double c1, double c2, double c3)
 {
     return fma(fma(fma(c0, r, c1), r, c2), r, c3);
+}
+SPL_HD double horner4(double c0, double r, double c1, double c2, double c3, double c4)
+{
+    return fma(fma(fma(fma(c0, r, c1), r, c2), r, c3), r, c4);
 }
 SPL_HD double horner5(double c0, double r, double c1, double c2, double c3, double c4, double c5)
 {
