@@ -136,6 +136,19 @@ int splash_dev_evap_batch(size_t m, const double* lat, const double* elv, const 
                           const double* slop, const double* asp, const double* snow,
                           const double* nd, double* out, void* stream);
 
+/* ---------------------------------------------------------------- unSWC epilogue */
+/* R/unsSWC.R:14-88 / R/unsSWC.grid.R: from the column water content wn [mm] (output of the path
+ * above), the water held between the surface and uns_depth [m] (wn_z, mm), the water-table depth
+ * (wtd, m) and the mean volumetric content of that layer (theta).  soil [6][ncell] as for
+ * soil_hydro (the gravel fraction is applied as the reference does, :55-56, :82).  Any of the three
+ * outputs may be NULL. */
+int splash_dev_unswc(size_t ncell, int nt, const double* wn, size_t ldw, const double* soil,
+                     double uns_depth, double* wn_z, double* wtd, double* theta, size_t ldo,
+                     void* stream);
+int splash_unswc_run(size_t ncell, int nt, const double* wn /*[nt][ncell]*/,
+                     const double* soil /*[6][ncell]*/, double uns_depth, double* wn_z, double* wtd,
+                     double* theta, char* err, size_t errlen);
+
 /* test hook: the device build of the FP64 log/exp/pow/acos used by the day step, for n arguments
  * (host pointers): out [5][n] = flog(x), fexp(x), fpow(x,y), facos(x), fsqrt(x) */
 int splash_dev_math_probe(size_t n, const double* x, const double* y, double* out);

@@ -117,6 +117,8 @@ class Oracle:
             [_dp] * 7
         L.orc_synth_forcing.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
                                         C.c_int, _ip, _dp, _dp, _dp, _dp, _dp]
+        L.orc_unswc.argtypes = [_dp, C.c_double, C.c_int, _dp, C.c_size_t, _dp, _dp, _dp, _dp,
+                                C.c_size_t]
         L.orc_calendar.restype = C.c_int
         L.orc_calendar.argtypes = [C.c_int, C.c_int, _ip, _ip, _ip, _ip]
         L.orc_max_threads.restype = C.c_int
@@ -216,6 +218,15 @@ class Oracle:
         Tt = self.lib.orc_snow_partition(nt, tp, pp, mp, lat, elev, rain.ctypes.data_as(_dp),
                                          snow.ctypes.data_as(_dp))
         return Tt, rain, snow
+
+    def unswc(self, soil_data, uns_depth, wn):
+        """R/unsSWC.R: dict(wn_z, wtd, theta_i) + 'cond' (cancellation factor of the integral)"""
+        sd, sdp = _d(soil_data)
+        w, wp = _d(wn)
+        nt = len(w)
+        o = {k: np.empty(nt) for k in ("wn_z", "wtd", "theta_i", "cond")}
+        self.lib.orc_unswc(sdp, float(uns_depth), nt, wp, 1, *[o[k].ctypes.data_as(_dp) for k in o], 1)
+        return o
 
     # ---- drivers ---------------------------------------------------------
     def calendar(self, year0, nt):

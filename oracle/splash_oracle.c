@@ -1138,6 +1138,51 @@ double orc_snow_partition(int nt, const double* tc, const double* pn, const int*
     return Tt;
 }
 
+/* ------------------------------------------------------------------ unSWC */
+
+/* R/unsSWC.R:14-88 for one site: water held between the surface and uns_depth [m], water-table
+ * depth and mean volumetric content of that layer, from the column total wn [mm].
+ * cond (optional): |w_uns_0| / |w_uns|, the cancellation factor of the analytical integral
+ * (:41-43), large where the result is rounding noise. */
+void orc_unswc(const double* soil_data, double uns_depth, int nt, const double* wn, size_t stride,
+               double* wn_z, double* wtd_o, double* theta_o, double* cond, size_t ostride)
+{
+    orc_soil si;
+    orc_soil_hydro(soil_data[0], soil_data[1], soil_data[2], 0.0, soil_data[4], &si); /* :55 */
+    double theta_s = si.SAT, theta_r = si.RES;                                       /* :59-60 */
+    double lambda = 1 / si.B;                                                        /* :62 */
+    double bub_press = si.bubbling_p;
+    double depth = soil_data[5];
+    for (int t = 0; t < nt; t++) {
+        double w = wn[(size_t)t * stride] * (100 + soil_data[3]) / 100; /* :56 */
+        double theta_i = w / (depth * 1000);                            /* :64-66 */
+        if (theta_i >= theta_s) theta_i = theta_s - 0.0001;
+        if (theta_i <= theta_r) theta_i = theta_r + 0.0001;
+        double psi_m = bub_press / pow((((theta_i - theta_r) / (theta_s - theta_r))), (1 / lambda));
+        /* UnsWater, :17-50 */
+        double wtdini = (bub_press - psi_m) / 1000;
+        double wtd = (wtdini > depth) ? depth : ((wtdini < 0) ? 0 : wtdini);
+        double z_uns = (wtd <= uns_depth) ? wtd * 1000 : uns_depth * 1000;
+        double w_uns_z = theta_r * z_uns + (((psi_m + z_uns) * (theta_r - theta_s) *
+                                             pow((bub_press / (psi_m + z_uns)), lambda)) /
+                                            (lambda - 1));
+        double w_uns_0 = theta_r * 0 + (((psi_m + 0) * (theta_r - theta_s) *
+                                         pow((bub_press / (psi_m + 0)), lambda)) /
+                                        (lambda - 1));
+        double w_uns = w_uns_z - w_uns_0;
+        double sat_swc = (wtd <= uns_depth) ? theta_s * (uns_depth - wtd) * 1000 : 0;
+        double swc_tot = (w_uns + sat_swc);
+        if (swc_tot <= 0) swc_tot = theta_r * (uns_depth * 1000); /* :74 */
+        double uns_theta = (swc_tot / (uns_depth * 1000));        /* :80 */
+        swc_tot = swc_tot * (1 - (soil_data[3] / 100));           /* :82 */
+        size_t k = (size_t)t * ostride;
+        if (wn_z) wn_z[k] = swc_tot;
+        if (wtd_o) wtd_o[k] = wtd;
+        if (theta_o) theta_o[k] = uns_theta;
+        if (cond) cond[k] = fabs(w_uns_0) / fabs(w_uns);
+    }
+}
+
 /* ------------------------------------------------------------------ drivers */
 
 static const double kNaN = NAN;

@@ -102,6 +102,11 @@ double orc_snowfall_prob(double tc, double lat, double elev);
 double orc_snow_partition(int nt, const double* tc, const double* pn, const int* month,
                           double lat, double elev, double* rain, double* snowfall);
 
+/* R/unsSWC.R:14-88 (post-processing: water to depth uns_depth, water table, layer theta) */
+void orc_unswc(const double* soil_data /*[6]*/, double uns_depth, int nt, const double* wn,
+               size_t stride, double* wn_z, double* wtd, double* theta, double* cond,
+               size_t ostride);
+
 /* options for the point/grid drivers */
 typedef struct {
     int monthly_out; /* 0 daily, 1 monthly aggregation (R/splash.point.R:207-214) */

@@ -64,6 +64,10 @@ def _load():
     L.splash_dev_synth_forcing.argtypes = [C.c_uint64, _vp, C.c_int, C.c_int, C.c_int64,
                                            C.c_size_t, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]
     L.splash_dev_evap_batch.argtypes = [C.c_size_t, _dp, _dp, _dp, _ip, _ip] + [_dp] * 7 + [_vp]
+    L.splash_dev_unswc.argtypes = [C.c_size_t, C.c_int, _vp, C.c_size_t, _vp, C.c_double, _vp, _vp,
+                                   _vp, C.c_size_t, _vp]
+    L.splash_unswc_run.argtypes = [C.c_size_t, C.c_int, _dp, _dp, C.c_double, _dp, _dp, _dp,
+                                   C.c_char_p, C.c_size_t]
     L.splash_dev_math_probe.argtypes = [C.c_size_t, _dp, _dp, _dp]
     L.splash_grid_run.argtypes = [C.POINTER(GridIn), C.POINTER(Opts), C.POINTER(GridOut),
                                   C.c_char_p, C.c_size_t]
@@ -89,7 +93,8 @@ SYMBOLS = (
     "splash_dev_snow_threshold", "splash_dev_spin_up_work_size", "splash_dev_spin_up",
     "splash_dev_diag_work_size",
     "splash_dev_run_all", "splash_dev_synth_statics", "splash_dev_synth_forcing",
-    "splash_dev_evap_batch", "splash_dev_math_probe", "splash_grid_run", "splash_point_run", "splash_mod_spin_up",
+    "splash_dev_evap_batch", "splash_dev_math_probe", "splash_dev_unswc", "splash_unswc_run",
+    "splash_grid_run", "splash_point_run", "splash_mod_spin_up",
     "splash_mod_run_all", "splash_mod_moist_surf", "splash_mod_inf_GA",
 )
 

@@ -155,6 +155,39 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     return res
 
 
+# ---------------------------------------------------------------------------- unSWC
+def unSWC(soil_data, uns_depth, wn):
+    """R/unsSWC.R:14.  soil_data = c(sand, clay, OM, gravel, bulk density, depth); wn: series of
+    column water content [mm].  Returns dict(wn_z, wtd, theta_i) like the reference's list
+    (its first element is the water to uns_depth, :85-86)."""
+    soil = np.asarray(soil_data, dtype=np.float64).reshape(6, 1)
+    w = np.ascontiguousarray(np.asarray(wn, dtype=np.float64).reshape(-1, 1))
+    r = unSWC_grid(soil, uns_depth, w)
+    return {k: v[:, 0] for k, v in r.items()}
+
+
+def unSWC_grid(soil, uns_depth, wn):
+    """R/unsSWC.grid.R:14 on arrays: soil [6, ncell], wn [nt, ncell] -> dict of [nt, ncell]."""
+    w, wp = _d(wn)
+    nt, ncell = w.shape
+    so, sp = _d(soil)
+    if so.shape != (6, ncell):
+        raise ValueError("soil must be [6, ncell]")
+    out = {k: np.empty((nt, ncell)) for k in ("wn_z", "wtd", "theta_i")}
+    err = C.create_string_buffer(512)
+    rc = lib.splash_unswc_run(ncell, nt, wp, sp, float(uns_depth),
+                              *[out[k].ctypes.data_as(_dp) for k in ("wn_z", "wtd", "theta_i")],
+                              err, 512)
+    if rc:
+        raise SplashError(f"splash_unswc_run failed ({rc}): {err.value.decode()}")
+    return out
+
+
+def dev_unswc(ncell, nt, wn, ldw, soil, uns_depth, wn_z, wtd, theta, ldo, stream=None):
+    check(lib.splash_dev_unswc(ncell, nt, _ptr(wn), ldw, _ptr(soil), float(uns_depth), _ptr(wn_z),
+                               _ptr(wtd), _ptr(theta), ldo, stream), "splash_dev_unswc")
+
+
 # ---------------------------------------------------------------------------- Rcpp module mirror
 class SPLASH:
     """Mirror of the Rcpp class exposed by src/SPLASH.cpp:12-21 (`new(SPLASH, lat, elev)`)."""

@@ -383,6 +383,20 @@ extern "C" int splash_dev_synth_forcing(uint64_t seed, const splash_calendar* ca
     return SPLASH_OK;
 }
 
+// unSWC epilogue on device-resident rasters (R/unsSWC.R:14-88, R/unsSWC.grid.R)
+extern "C" int splash_dev_unswc(size_t ncell, int nt, const double* wn, size_t ldw,
+                                const double* soil, double uns_depth, double* wn_z, double* wtd,
+                                double* theta, size_t ldo, void* stream)
+{
+    REQ(wn && soil && (wn_z || wtd || theta), "unswc: NULL argument");
+    REQ(ldw >= ncell && ldo >= ncell && nt >= 0, "unswc: leading dimension < ncell");
+    REQ(uns_depth > 0, "unswc: uns_depth must be positive");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    HIP_TRY(launch_unswc(ncell, nt, wn, ldw, soil, uns_depth, wn_z, wtd, theta, ldo,
+                         (hipStream_t)stream), nullptr, 0);
+    return SPLASH_OK;
+}
+
 // ------------------------------------------------------------------ small RAII helpers
 namespace {
 
@@ -676,6 +690,34 @@ extern "C" int splash_point_run(int nt, const int* doy, const int* year, const i
     splash_grid_out o{};
     for (int k = 0; k < SPLASH_NOUT; k++) o.out[k] = outp[k];
     return splash_grid_run(&in, &opt, &o, err, errlen);
+}
+
+// unSWC for host buffers: wn [nt][ncell], soil [6][ncell] -> wn_z, wtd, theta [nt][ncell]
+extern "C" int splash_unswc_run(size_t ncell, int nt, const double* wn, const double* soil,
+                                double uns_depth, double* wn_z, double* wtd, double* theta,
+                                char* err, size_t errlen)
+{
+    if (!wn || !soil) return fail(SPLASH_EINVAL, err, errlen, "unswc_run: NULL input");
+    if (int rc = need_device(err, errlen)) return rc;
+    if (ncell == 0 || nt <= 0) return SPLASH_OK;
+    const size_t n = ncell * (size_t)nt;
+    DevBuf dw, ds, dz, dt_, dh;
+    HIP_TRY(dw.alloc(n * 8), err, errlen);
+    HIP_TRY(ds.alloc(6 * ncell * 8), err, errlen);
+    HIP_TRY(hipMemcpy(dw.p, wn, n * 8, hipMemcpyHostToDevice), err, errlen);
+    HIP_TRY(hipMemcpy(ds.p, soil, 6 * ncell * 8, hipMemcpyHostToDevice), err, errlen);
+    if (wn_z) HIP_TRY(dz.alloc(n * 8), err, errlen);
+    if (wtd) HIP_TRY(dt_.alloc(n * 8), err, errlen);
+    if (theta) HIP_TRY(dh.alloc(n * 8), err, errlen);
+    int rc = splash_dev_unswc(ncell, nt, dw.as<double>(), ncell, ds.as<double>(), uns_depth,
+                              wn_z ? dz.as<double>() : nullptr, wtd ? dt_.as<double>() : nullptr,
+                              theta ? dh.as<double>() : nullptr, ncell, nullptr);
+    if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
+    HIP_TRY(hipDeviceSynchronize(), err, errlen);
+    if (wn_z) HIP_TRY(hipMemcpy(wn_z, dz.p, n * 8, hipMemcpyDeviceToHost), err, errlen);
+    if (wtd) HIP_TRY(hipMemcpy(wtd, dt_.p, n * 8, hipMemcpyDeviceToHost), err, errlen);
+    if (theta) HIP_TRY(hipMemcpy(theta, dh.p, n * 8, hipMemcpyDeviceToHost), err, errlen);
+    return SPLASH_OK;
 }
 
 // ------------------------------------------------------------------ Rcpp-module mirrors

@@ -470,6 +470,83 @@ __global__ __launch_bounds__(64) void k_diag_reduce(const double* __restrict__ p
     if (threadIdx.x == 0) diag[e] += s;
 }
 
+// ================================================================ unSWC ==========
+// R/unsSWC.R:14-88 as a pointwise epilogue over a [nt][ld] raster of column water content wn:
+// water held between the surface and uns_depth (analytical integral of the Brooks-Corey profile,
+// :41-43), water-table depth and mean volumetric content of that layer.  One lane per cell; the
+// soil-only terms (soil_hydro with fgravel = 0, :55) are derived once per lane.
+// HBM traffic: 8 B read + 24 B written per cell-step (32 B algorithmic).
+__global__ __launch_bounds__(kBlock) void k_unswc(size_t ncell, int nt,
+                                                 const double* __restrict__ wn, size_t ldw,
+                                                 const double* __restrict__ soil,
+                                                 double uns_depth, double* __restrict__ wn_z,
+                                                 double* __restrict__ wtd_o,
+                                                 double* __restrict__ theta_o, size_t ldo)
+{
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= ncell) return;
+    const double sand = soil[i], clay = soil[ncell + i], OM = soil[2 * ncell + i];
+    const double gravel = soil[3 * ncell + i];
+    double bd = soil[4 * ncell + i];
+    const double depth = soil[5 * ncell + i];
+    // soil_hydro(sand, clay, OM, fgravel = 0, bd): R/splash.point.R:261-380 (fields used here)
+    const double fsand = sand / 100, fclay = clay / 100, fOM = OM / 100;
+    const double dp = 1 / ((fOM / 1.3) + ((1 - fOM) / 2.65));
+    if (isnan(bd))
+        bd = (1.5 + (dp - 1.5 - 1.10 * (1 - fclay)) * (1 - exp(-0.022 * 30.0))) / (1 + 6.27 * fOM);
+    if (bd < 0.81) bd = 0.81;
+    const double theta_s = 1 - (bd / dp);
+    const double sq_clay = sqrt(fclay);
+    const double fc = (theta_s / bd) * (0.4760944 + (0.9402962 - 0.4760944) * sq_clay) *
+                      exp(-1 * (0.05472678 * fsand - 0.01 * fOM) / (theta_s / bd));
+    const double wp_Ball = fc * (0.2018522 + (0.7809203 - 0.2018522) * sq_clay);
+    double wp = -2.464e-05 * sand + 3.650e-03 * clay + 8.680e-03 * OM + 9.393e-03 * bd;
+    if (!isnan(wp) && wp >= fc) wp = wp_Ball;
+    const double coef_B = (log(1500.0) - log(33.0)) / (log(fc) - log(wp));
+    const double coef_A = exp(log(33.0) + coef_B * log(fc));
+    double theta_r = (0.0285 + 0.00336 * (clay)) * bd;
+    if (!isnan(theta_r) && theta_r > wp) theta_r = wp;
+    const double m33i = 0.278 * fsand + 0.034 * fclay + 0.022 * fOM - 0.018 * (fsand * fOM) -
+                        0.027 * (fclay * fOM) - 0.584 * (fsand * fclay) + 0.078;
+    const double m33 = m33i + (0.636 * m33i - 0.107);
+    const double bub_init = -21.6 * fsand - 27.93 * fclay - 81.97 * m33 + 71.12 * (fsand * m33) +
+                            8.29 * (fclay * m33) + 14.05 * (fsand * fclay) + 27.16;
+    double bub = (bub_init + (0.02 * (bub_init * bub_init) - 0.113 * bub_init - 0.7)) *
+                 -101.97162129779;
+    if (!isnan(bub) && bub > 0) bub = coef_A * -101.97162129779;
+    const double lambda = 1 / coef_B; // R/unsSWC.R:62
+    const double inv_lambda = 1 / lambda;
+    const double d1000 = depth * 1000;
+    const double dth = theta_s - theta_r;
+    const double gfac = (100 + gravel) / 100, gout = (1 - (gravel / 100));
+    const double u1000 = uns_depth * 1000;
+    const double inv_lm1 = 1 / (lambda - 1);
+    const double inv_d1000 = 1 / d1000, inv_dth = 1 / dth, inv_u1000 = 1 / u1000;
+    for (int t = 0; t < nt; t++) {
+        const double w = __builtin_nontemporal_load(&wn[(size_t)t * ldw + i]) * gfac; // :56
+        double theta_i = w * inv_d1000;                                               // :64-66
+        if (theta_i >= theta_s) theta_i = theta_s - 0.0001;
+        if (theta_i <= theta_r) theta_i = theta_r + 0.0001;
+        const double L = flog((theta_i - theta_r) * inv_dth);
+        const double psi_m = bub * fexp(-L * inv_lambda); // bub / Theta^(1/lambda), :67
+        const double wtdini = (bub - psi_m) * 1.0e-3;     // UnsWater, :36-37
+        const double wtd = (wtdini > depth) ? depth : ((wtdini < 0) ? 0 : wtdini);
+        const double z_uns = (wtd <= uns_depth) ? wtd * 1000 : u1000; // :39
+        // :41-43  (bub/(psi_m+z))^lambda = exp(lambda*log(..)); at z = 0 the base is Theta^(1/lambda)
+        const double pz = fexp(lambda * flog(bub * frcp(psi_m + z_uns))); // psi_m + z <= bub < 0
+        const double p0 = fexp(L); // (bub/psi_m)^lambda = Theta
+        const double w_uns_z = theta_r * z_uns + (((psi_m + z_uns) * (theta_r - theta_s) * pz) * inv_lm1);
+        const double w_uns_0 = ((psi_m * (theta_r - theta_s) * p0) * inv_lm1);
+        const double sat_swc = (wtd <= uns_depth) ? theta_s * (uns_depth - wtd) * 1000 : 0; // :46
+        double swc_tot = (w_uns_z - w_uns_0) + sat_swc;
+        if (swc_tot <= 0) swc_tot = theta_r * u1000; // :74
+        const size_t k = (size_t)t * ldo + i;
+        if (theta_o) __builtin_nontemporal_store(swc_tot * inv_u1000, &theta_o[k]); // :80
+        if (wn_z) __builtin_nontemporal_store(swc_tot * gout, &wn_z[k]);       // :82
+        if (wtd_o) __builtin_nontemporal_store(wtd, &wtd_o[k]);
+    }
+}
+
 // ================================================================ test hooks ===================
 // SOLAR+EVAP for independent rows (src/EVAP.cpp:82-264)
 __global__ __launch_bounds__(kBlock) void k_evap_batch(size_t m, const double* lat,
@@ -755,6 +832,16 @@ hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, con
     if (m == 0) return hipSuccess;
     hipLaunchKernelGGL(k_evap_batch, dim3(nblk(m, kBlock)), dim3(kBlock), 0, s, m, lat, elv, sw, dr,
                        sd, cd, sw_in, tc, slop, asp, snow, nd, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_unswc(size_t ncell, int nt, const double* wn, size_t ldw, const double* soil,
+                        double uns_depth, double* wn_z, double* wtd, double* theta, size_t ldo,
+                        hipStream_t s)
+{
+    if (ncell == 0 || nt == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_unswc, dim3(nblk(ncell, kBlock)), dim3(kBlock), 0, s, ncell, nt, wn, ldw,
+                       soil, uns_depth, wn_z, wtd, theta, ldo);
     return hipGetLastError();
 }
 

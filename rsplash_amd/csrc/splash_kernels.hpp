@@ -102,6 +102,9 @@ hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, con
                              const double* sw_in, const double* tc, const double* slop,
                              const double* asp, const double* snow, const double* nd, double* out,
                              hipStream_t s);
+hipError_t launch_unswc(size_t ncell, int nt, const double* wn, size_t ldw, const double* soil,
+                        double uns_depth, double* wn_z, double* wtd, double* theta, size_t ldo,
+                        hipStream_t s);
 hipError_t launch_math_probe(size_t n, const double* x, const double* y, double* out, hipStream_t s);
 hipError_t launch_moist_surf(double depth, double z, double bub_p, double wn, double SAT,
                              double RES, double lambda, double* out, hipStream_t s);

@@ -415,3 +415,38 @@ def test_high_latitude_steep_slopes_and_conditioning(api, oracle):
         assert np.isfinite(a).all()
         close(a[:, okc], b[:, okc], "well-conditioned." + k)
     cal.close()
+
+
+# ---------------------------------------------------------------- unSWC epilogue
+def test_unswc_bourne_and_grid(api, oracle, bourne):
+    """R/unsSWC.R on the README workflow (README.md:52-59: water to the 0.49 m sensor depth from the
+    simulated column water) and on a synthetic grid.  The analytical integral (:41-43) is a
+    difference of two terms that cancel for dry columns; entries whose cancellation factor
+    exceeds 1e7 (reference = rounding noise) are compared with the matching looser bound."""
+    b, s = bourne, bourne["site"]
+    g = api.splash_point(b["sw_in"], b["Ta"], b["P"], s["latitude"], s["elev_m"], s["slop_250m"],
+                         s["asp_250m"], b["soil"], s["Aups_250m"], s["resolution"],
+                         time_index=b["dates"])
+    got = api.unSWC(b["soil"], s["max_depth_sm"], g["wn"])
+    ref = oracle.unswc(b["soil"], s["max_depth_sm"], g["wn"])
+    for k in ("wn_z", "wtd", "theta_i"):
+        tol = 1e-5 * np.abs(ref[k]) + 1e-9 + 1e-15 * ref["cond"] * np.abs(ref[k])
+        assert (np.abs(got[k] - ref[k]) <= tol).all(), k
+    assert np.all(got["wn_z"] > 0) and np.all(got["wtd"] <= b["soil"][5] + 1e-12)
+    # grid form
+    H, W, nt = 6, 32, 120
+    rng = np.random.default_rng(9)
+    st = oracle.synth_statics(20221130, H, W, 0, H * W, 1)
+    soil = st["soil"]
+    sat = np.array([oracle.soil_info(soil[:, j], None, 250.0)[0][[0, 7]] for j in range(H * W)])
+    wn = sat[:, 1] + (sat[:, 0] - sat[:, 1]) * rng.uniform(0, 1, (nt, H * W))
+    wn[0] = sat[:, 1]
+    wn[1] = sat[:, 0]
+    got = api.unSWC_grid(soil, 0.3, wn)
+    bad = 0
+    for j in range(H * W):
+        ref = oracle.unswc(soil[:, j], 0.3, wn[:, j])
+        for k in ("wn_z", "wtd", "theta_i"):
+            tol = 1e-5 * np.abs(ref[k]) + 1e-9 + 1e-14 * ref["cond"] * np.abs(ref[k])
+            bad += int((np.abs(got[k][:, j] - ref[k]) > tol).sum())
+    assert bad == 0
