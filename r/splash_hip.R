@@ -43,3 +43,13 @@ splash.point <- function(sw_in, tc, pn, lat, elev, slop = 0, asp = 0, soil_data,
   #    writeValues(brick, m, bs$row[i]) / matXX[startind[i]:endind[i], ] <- m consume unchanged
   #    (R/splash.grid.R:370-392)
 }
+
+# unSWC (R/unsSWC.R:14): same signature; the analytical integral runs in the HIP library
+unSWC <- function(soil_data, uns_depth, wn) {
+  res <- .Call("C_splash_unswc_run", matrix(as.numeric(wn), ncol = 1), matrix(as.numeric(soil_data), nrow = 1),
+               as.numeric(uns_depth))
+  result <- list(wn_z = res$wn_z[, 1], wtd = res$wtd[, 1])
+  if (xts::is.xts(wn)) result <- mapply(FUN = xts::xts, result, MoreArgs = list(order.by = time(wn)), SIMPLIFY = FALSE)
+  result$theta_i <- if (xts::is.xts(wn)) xts::xts(res$theta_i[, 1], time(wn)) else res$theta_i[, 1]
+  result
+}

@@ -124,9 +124,35 @@ SEXP C_splash_point_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP lat, SEXP elev, SEXP 
     return res;
 }
 
+/* unSWC / unSWC.grid (R/unsSWC.R:14, R/unsSWC.grid.R:14): wn [ncell x nt] matrix (one column per
+ * time step as getValues() gives it), soil [ncell x 6], uns_depth numeric(1) */
+SEXP C_splash_unswc_run(SEXP wn, SEXP soil, SEXP uns_depth)
+{
+    SEXP dim = getAttrib(wn, R_DimSymbol);
+    if (isNull(dim) || LENGTH(dim) != 2) error("wn must be a [ncell x nt] matrix");
+    const size_t ncell = (size_t)INTEGER(dim)[0];
+    const int nt = INTEGER(dim)[1];
+    static const char* names[] = {"wn_z", "wtd", "theta_i", ""};
+    SEXP res = PROTECT(mkNamed(VECSXP, names));
+    double* o[3];
+    for (int k = 0; k < 3; k++) {
+        SEXP m = PROTECT(allocMatrix(REALSXP, (int)ncell, nt));
+        o[k] = REAL(m);
+        SET_VECTOR_ELT(res, k, m);
+        UNPROTECT(1);
+    }
+    char err[512];
+    int rc = splash_unswc_run(ncell, nt, REAL(wn), REAL(soil), asReal(uns_depth), o[0], o[1], o[2],
+                              err, sizeof err);
+    UNPROTECT(1);
+    if (rc != SPLASH_OK) error("splash_unswc_run failed (%d): %s", rc, err);
+    return res;
+}
+
 static const R_CallMethodDef CallEntries[] = {
     {"C_splash_grid_run", (DL_FUNC)&C_splash_grid_run, 11},
     {"C_splash_point_run", (DL_FUNC)&C_splash_point_run, 14},
+    {"C_splash_unswc_run", (DL_FUNC)&C_splash_unswc_run, 3},
     {NULL, NULL, 0}};
 
 /* add these two entries to the package's existing R_init_rsplash (src/RcppExports.cpp:21-24),

@@ -450,3 +450,22 @@ def test_unswc_bourne_and_grid(api, oracle, bourne):
             tol = 1e-5 * np.abs(ref[k]) + 1e-9 + 1e-14 * ref["cond"] * np.abs(ref[k])
             bad += int((np.abs(got[k][:, j] - ref[k]) > tol).sum())
     assert bad == 0
+
+
+def test_splash_grid_leap_year_calendar(api, oracle):
+    """calendar crossing a leap year (2003-2005: doy 366, kN = 366 in the orbit, months of 29 days)
+    on flat terrain, monthly output (the reference's default for splash.grid)"""
+    H, W, nt = 6, 32, 1000
+    doy, year, month, mid, nm = oracle.calendar(2003, nt)
+    assert 366 in doy
+    st = oracle.synth_statics(7, H, W, 0, H * W, 0)
+    sw, tc, pn = oracle.synth_forcing(7, H, W, 0, H * W, 0, doy, st["lat"], st["elev"])
+    dates = np.datetime64("2003-01-01") + np.arange(nt)
+    g = api.splash_grid(sw, tc, pn, st["elev"], st["soil"], st["lat"], st["slop"], st["asp"],
+                        st["au"], st["resolution"], time_index=dates)  # monthly_out default TRUE
+    o, aux = oracle.grid(doy, year, month, mid, nm, sw, tc, pn, st["lat"], st["elev"], st["slop"],
+                         st["asp"], st["soil"], st["au"], st["resolution"], monthly_out=True)
+    ok = (aux["fragile"] == 0) & (aux["soil_info"][:, 4] >= 0.01)
+    assert g["wn"].shape == (nm, H * W) and ok.mean() > 0.9
+    for k in o:
+        close(g[k][:, ok], o[k][:, ok], "leap." + k)
