@@ -67,6 +67,9 @@ int splash_calendar_create(int nt, const int* doy, const int* year, const int* m
 void splash_calendar_destroy(splash_calendar* cal);
 int splash_calendar_nt(const splash_calendar* cal);
 int splash_calendar_nmonth(const splash_calendar* cal);
+/* host-only (works without a GPU): distance factor dr and sin/cos of the solar declination of
+ * one calendar day (src/SOLAR.cpp:98-124), the day-static terms the calendar tabulates */
+int splash_orbit_day(int doy, int year, double* dr, double* sin_delta, double* cos_delta);
 /* host copy of the orbit table, for tests: dr, sin(delta), cos(delta), each [nt] */
 int splash_calendar_orbit(const splash_calendar* cal, double* dr, double* sd, double* cd);
 

@@ -583,12 +583,14 @@ double orc_debug[16]; /* intermediates of the last orc_run_one_day call (debuggi
 
 /* Conditioning bookkeeping (not part of the restatement): number of day steps, on the calling
  * thread, in which the drainage time of src/SPLASH.cpp:1472 was computed from a transmittance
- * that is rounding noise.  With the water table clamped to the column base and
- * |psi_m| > 1e11 * depth*1000, the two powers at :1422 are bub/psi_m and
- * bub/fl(psi_m + depth*1000) raised to 3*lambda+1: their bases differ by the ROUNDING of that
- * sum (nothing at all once |psi_m| > 2^53*depth*1000), so T_uns, hence Q = T*Ai/1000, is a few
- * ulp of ~1e-20 or exactly 0, and t_drain = -log(1 - log(Kb)*Au*R/Q)/log(Kb) is either +inf
- * (sticky) or a value set by those ulps.  No two libm implementations agree there. */
+ * that is rounding noise.  With the water table clamped to the column base, the two powers at
+ * :1422 are bub/psi_m and bub/fl(psi_m + depth*1000) raised to 3*lambda+1: their bases differ
+ * through the ROUNDING of that sum.  Once |psi_m| >~ 2^53*depth*1000 the sum rounds back to psi_m,
+ * both powers are bit-identical, T_uns = 0 exactly and t_drain = +inf (sticky): deterministic, and
+ * any faithful implementation reproduces it.  In the band below that (increment = a few ulp of
+ * psi_m, here 2^42..2^54.5 times depth*1000) T_uns, hence Q = T*Ai/1000, is set by which way
+ * those few ulp fall, and so is t_drain = -log(1 - log(Kb)*Au*R/Q)/log(Kb).  No two libm
+ * implementations agree there: those day steps are counted. */
 static __thread long tl_fragile_events = 0;
 long orc_fragile_events(int reset)
 {
@@ -777,7 +779,9 @@ void orc_run_one_day(double lat, double elv, int n, int y, double wn, double sw_
     double q_in_f = 0.0;
     td -= 1.0;
     if ((R > 0.0) && (sm > Wmax)) {
-        if (Au > 0.0 && wtd >= depth && fabs(psi_m) > 1.0e11 * (wtd * 1000.0)) tl_fragile_events++;
+        if (Au > 0.0 && wtd >= depth && fabs(psi_m) > 4.4e12 * (wtd * 1000.0) &&
+            fabs(psi_m) < 2.6e16 * (wtd * 1000.0))
+            tl_fragile_events++;
         t_drain = -1.0 * log(1.0 - (log(Kb) * (Au * R / Q))) / log(Kb);
         q_in_f = (Qt - Au * R * log(Kb)) / Ai;
     }

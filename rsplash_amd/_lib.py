@@ -48,6 +48,7 @@ def _load():
     L.splash_calendar_nt.argtypes = [_vp]
     L.splash_calendar_nmonth.argtypes = [_vp]
     L.splash_calendar_orbit.argtypes = [_vp, _dp, _dp, _dp]
+    L.splash_orbit_day.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
     L.splash_dev_soil_hydro.argtypes = [C.c_size_t] + [_vp] * 8 + [_vp]
     L.splash_dev_snow_threshold.argtypes = [C.c_size_t, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t,
                                             _vp, _vp]
@@ -89,7 +90,7 @@ lib = _load()
 SYMBOLS = (
     "splash_hip_abi_version", "splash_hip_device_count", "splash_hip_last_error",
     "splash_calendar_create", "splash_calendar_destroy", "splash_calendar_nt",
-    "splash_calendar_nmonth", "splash_calendar_orbit", "splash_dev_soil_hydro",
+    "splash_calendar_nmonth", "splash_calendar_orbit", "splash_orbit_day", "splash_dev_soil_hydro",
     "splash_dev_snow_threshold", "splash_dev_spin_up_work_size", "splash_dev_spin_up",
     "splash_dev_diag_work_size",
     "splash_dev_run_all", "splash_dev_synth_statics", "splash_dev_synth_forcing",

@@ -34,6 +34,13 @@ def device_count():
     return lib.splash_hip_device_count()
 
 
+def orbit_day(doy, year):
+    """(dr, sin delta, cos delta) of one calendar day -- host-only, no GPU needed"""
+    v = [C.c_double() for _ in range(3)]
+    check(lib.splash_orbit_day(int(doy), int(year), *[C.byref(x) for x in v]), "splash_orbit_day")
+    return tuple(x.value for x in v)
+
+
 def time_fields(time_index):
     """doy / year / month vectors (what R derives with format(time_index, '%j' / '%Y' / '%m'),
     R/splash.point.R:57-59, 547)."""

@@ -130,6 +130,15 @@ void orbit_day(int n, int y, double& dr, double& sd, double& cd)
 
 } // namespace
 
+// host-only: the day-static orbit terms of one calendar day (no device needed)
+extern "C" int splash_orbit_day(int doy, int year, double* dr, double* sd, double* cd)
+{
+    if (doy < 1 || doy > 366 || !dr || !sd || !cd)
+        return fail(SPLASH_EINVAL, nullptr, 0, "orbit_day: bad argument");
+    orbit_day(doy, year, *dr, *sd, *cd);
+    return SPLASH_OK;
+}
+
 struct splash_calendar {
     int nt = 0, nmonth = 0, device = 0;
     std::vector<DayRec> host;

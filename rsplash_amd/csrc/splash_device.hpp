@@ -704,7 +704,14 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
     if (!clamped) {
         diff = A - 1.0; // bub/(psi_m + wtd*1000) is 1 +- 1 ulp: B = 1 to 1e-16
     } else {
-        const double u = w1000 / psi_m; // in (-1, 0] for a dry column; -0 when psi_m = -inf
+        // u = wtd*1000/psi_m, with the increment taken as the reference forms it: fl(psi_m +
+        // wtd*1000) - psi_m.  For |psi_m| >~ 2^53*wtd*1000 the sum rounds back to psi_m, the
+        // reference's two powers are then bit-identical, T_uns is exactly 0 and the drainage time
+        // of src/SPLASH.cpp:1472 is +inf (sticky): reproduced exactly.  Just below that the
+        // increment is a small multiple of ulp(psi_m) -- the same quantisation, though not the same
+        // bits, as the reference's.
+        const double xs = psi_m + w1000;
+        const double u = (xs - psi_m) / psi_m; // in (-1, 0] for a dry column; -0 when psi_m = -inf
         const double l1p = (fabs(u) < 1.0e-5) ? u * (1.0 - u * (0.5 - u * (1.0 / 3.0))) : flog(1.0 + u);
         const double z = -c.e3l1 * l1p;
         const double em1 = (fabs(z) < 1.0e-5) ? z * (1.0 + z * (0.5 + z * (1.0 / 6.0))) : fexp(z) - 1.0;

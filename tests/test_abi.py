@@ -59,3 +59,17 @@ def test_time_fields_and_month_ids(bourne):
     assert np.array_equal(doy, bourne["doy"]) and np.array_equal(year, bourne["year"])
     assert np.array_equal(month, bourne["month"])
     assert np.array_equal(api.month_ids(year, month), bourne["month_id"])
+
+
+def test_host_orbit_table_matches_oracle(oracle):
+    """the per-day orbit terms the calendar tabulates on the host (src/SOLAR.cpp:98-124) against the
+    oracle's (which is bit-identical to the real SOLAR class): dr bitwise, sin/cos(delta) to 1 ulp"""
+    import math
+    from rsplash_amd import api
+    pir = math.pi / 180.0
+    for year in (0, 1999, 2000, 2001, 2004, 2100):
+        for doy in (1, 59, 60, 80, 172, 266, 355, 365, 366):
+            dr, sd, cd = api.orbit_day(doy, year)
+            kN, nu, lam, dr_o, delta = oracle.orbit(doy, year)
+            assert dr == dr_o, (doy, year)
+            assert abs(sd - math.sin(delta * pir)) <= 2.3e-16 and abs(cd - math.cos(delta * pir)) <= 2.3e-16
