@@ -210,6 +210,15 @@ int splash_mod_run_all(double lat, double elv, int nt, const int* doys, const in
                        double* wn, double* ro, double* pet, double* aet, double* snow, double* cond,
                        double* bflow, double* netr, double* qin_prev, double* tdrain,
                        double* snwage /* each [nt] or NULL */);
+/* run_one_year (src/SPLASH.cpp:1751): n days of year y from the last elements of the state
+ * vectors (each of length n_end >= n) */
+int splash_mod_run_one_year(double lat, double elv, int n, int y, int n_end, const double* sw_in,
+                            const double* tair, const double* pn, const double* wn_vec, double slop,
+                            double asp, const double* snow, const double* snowfall,
+                            const double* soil_info, const double* qin_vec, const double* td_vec,
+                            const double* nds, double* wn, double* ro, double* pet, double* aet,
+                            double* snow_out, double* cond, double* bflow, double* netr,
+                            double* qin_prev, double* tdrain, double* snwage /* each [n] or NULL */);
 int splash_mod_moist_surf(double depth, double z, double bub_p, double wn, double SAT, double RES,
                           double lambda, double* theta);
 int splash_mod_inf_GA(double bub_press, double theta_i, double Ksat, double theta_s, double lambda,

@@ -79,6 +79,9 @@ def _load():
     L.splash_mod_run_all.argtypes = [C.c_double, C.c_double, C.c_int, _ip, _ip, _dp, _dp, _dp,
                                      C.c_double, C.c_double, C.c_double, C.c_double, _dp, _dp,
                                      C.c_double, C.c_double, C.c_double] + [_dp] * 11
+    L.splash_mod_run_one_year.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, _dp, _dp,
+                                          _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _dp, _dp,
+                                          _dp] + [_dp] * 11
     L.splash_mod_moist_surf.argtypes = [C.c_double] * 7 + [_dp]
     L.splash_mod_inf_GA.argtypes = [C.c_double] * 8 + [_dp]
     return L
@@ -96,7 +99,7 @@ SYMBOLS = (
     "splash_dev_run_all", "splash_dev_synth_statics", "splash_dev_synth_forcing",
     "splash_dev_evap_batch", "splash_dev_math_probe", "splash_dev_unswc", "splash_unswc_run",
     "splash_grid_run", "splash_point_run", "splash_mod_spin_up",
-    "splash_mod_run_all", "splash_mod_moist_surf", "splash_mod_inf_GA",
+    "splash_mod_run_all", "splash_mod_run_one_year", "splash_mod_moist_surf", "splash_mod_inf_GA",
 )
 
 

@@ -233,6 +233,20 @@ class SPLASH:
               "splash_mod_run_all")
         return out
 
+    def run_one_year(self, n, y, sw_in, tair, pn, wn_vec, slop, asp, snow, snowfall, soil_info,
+                     qin_vec, td_vec, nds):
+        """src/SPLASH.cpp:1751 -> dict of the 11 series of :1827-1829, each [n]"""
+        a = [_d(x) for x in (sw_in, tair, pn, wn_vec, snow, snowfall, soil_info, qin_vec, td_vec, nds)]
+        names = ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "qin_prev", "tdrain",
+                 "snwage")
+        out = {k: np.empty(n) for k in names}
+        check(lib.splash_mod_run_one_year(self.lat, self.elv, int(n), int(y), len(a[3][0]), a[0][1],
+                                          a[1][1], a[2][1], a[3][1], float(slop), float(asp), a[4][1],
+                                          a[5][1], a[6][1], a[7][1], a[8][1], a[9][1],
+                                          *[out[k].ctypes.data_as(_dp) for k in names]),
+              "splash_mod_run_one_year")
+        return out
+
     @staticmethod
     def moist_surf(depth, z, bub_p, wn, SAT, RES, lam):
         """src/SPLASH.cpp:1921"""

@@ -882,6 +882,29 @@ extern "C" int splash_mod_run_all(double lat, double elv, int nt, const int* doy
     return SPLASH_OK;
 }
 
+// SPLASH::run_one_year (src/SPLASH.cpp:1751-1830): day i+1 of year y for i < n, starting from the
+// LAST elements of the state vectors (wrap-around read at i == 0, :1794-1799); n_end = length of
+// the input vectors.  Same 11 series as run_all (:1827-1829), each [n].
+extern "C" int splash_mod_run_one_year(double lat, double elv, int n, int y, int n_end,
+                                       const double* sw_in, const double* tair, const double* pn,
+                                       const double* wn_vec, double slop, double asp,
+                                       const double* snow, const double* snowfall,
+                                       const double* soil_info, const double* qin_vec,
+                                       const double* td_vec, const double* nds, double* wn_o,
+                                       double* ro, double* pet, double* aet, double* snow_o,
+                                       double* cond, double* bflow, double* netr, double* qin_prev,
+                                       double* tdrain, double* snwage)
+{
+    REQ(n > 0 && n_end >= n && wn_vec && snow && qin_vec && td_vec && nds,
+        "mod_run_one_year: bad argument");
+    std::vector<int> doys(n), yrs(n, y);
+    for (int i = 0; i < n; i++) doys[i] = i + 1;
+    return splash_mod_run_all(lat, elv, n, doys.data(), yrs.data(), sw_in, tair, pn,
+                              wn_vec[n_end - 1], slop, asp, snow[n_end - 1], snowfall, soil_info,
+                              qin_vec[n_end - 1], td_vec[n_end - 1], nds[n_end - 1], wn_o, ro, pet,
+                              aet, snow_o, cond, bflow, netr, qin_prev, tdrain, snwage);
+}
+
 extern "C" int splash_mod_moist_surf(double depth, double z, double bub_p, double wn, double SAT,
                                      double RES, double lambda, double* theta)
 {

@@ -148,6 +148,25 @@ def test_module_spin_up_and_run_all_bourne(api, oracle, bourne):
     assert np.array_equal(r["snwage"], q["snwage"])
 
 
+def test_module_run_one_year(api, oracle, bourne):
+    """SPLASH::run_one_year (src/SPLASH.cpp:1751): year y, days 1..n, start = last vector elements"""
+    b, s = bourne, bourne["site"]
+    si, rain, snowf = _bourne_prelude(oracle, b)
+    asp = s["asp_250m"] - 180
+    n = 365
+    st = dict(wn=np.full(n, 150.0), snow=np.full(n, 30.0), qin=np.full(n, 0.01),
+              td=np.full(n, 2.0), nd=np.full(n, 3.0))
+    g = api.SPLASH(s["latitude"], s["elev_m"]).run_one_year(
+        n, 2010, b["sw_in"][:n], b["Ta"][:n], rain[:n], st["wn"], s["slop_250m"], asp, st["snow"],
+        snowf[:n], si, st["qin"], st["td"], st["nd"])
+    q = oracle.run_all(s["latitude"], s["elev_m"], np.arange(1, n + 1), np.full(n, 2010),
+                       b["sw_in"][:n], b["Ta"][:n], rain[:n], 150.0, s["slop_250m"], asp, 30.0,
+                       snowf[:n], si, 0.01, 2.0, 3.0)
+    for k in ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "qin_prev", "tdrain"):
+        close(g[k], q[k], "run_one_year." + k)
+    assert np.array_equal(g["snwage"], q["snwage"])
+
+
 # ---------------------------------------------------------------- splash.point (BASELINE config 0)
 @pytest.mark.parametrize("flat", [False, True])
 @pytest.mark.parametrize("monthly", [False, True])
