@@ -488,3 +488,28 @@ def test_splash_grid_leap_year_calendar(api, oracle):
     assert g["wn"].shape == (nm, H * W) and ok.mean() > 0.9
     for k in o:
         close(g[k][:, ok], o[k][:, ok], "leap." + k)
+
+
+def test_polar_day_and_night(api, oracle):
+    """latitudes 66-85 N/S: polar night (hs = 0: src/SOLAR.cpp:152-154, rw branch :220-221) and
+    polar day (hs = 180), deep snowpacks, tc < 0 most of the year (viscosity at 0 C)"""
+    H, W, nt = 4, 32, 500
+    doy, year, month, mid, nm = oracle.calendar(2001, nt)
+    st = oracle.synth_statics(11, H, W, 0, H * W, 1)
+    n = H * W
+    lat = np.r_[np.linspace(66, 85, n // 2), -np.linspace(66, 85, n - n // 2)]
+    st["lat"] = lat
+    sw, tc, pn = oracle.synth_forcing(11, H, W, 0, n, 0, doy, lat, st["elev"])
+    sw[sw < 20] = 0.0  # dark days: sw_in == 0 branch
+    dates = np.datetime64("2001-01-01") + np.arange(nt)
+    g = api.splash_grid(sw, tc, pn, st["elev"], st["soil"], lat, st["slop"], st["asp"], st["au"],
+                        st["resolution"], time_index=dates, sim_control=dict(monthly_out=False))
+    o, aux = oracle.grid(doy, year, month, mid, nm, sw, tc, pn, lat, st["elev"], st["slop"],
+                         st["asp"], st["soil"], st["au"], st["resolution"])
+    from oracle.binding import grazing_mask
+    ok = (aux["fragile"] == 0) & (aux["soil_info"][:, 4] >= 0.01)
+    ok &= ~grazing_mask(oracle, lat, st["slop"], st["asp"] - 180, doy, year).any(0)
+    assert ok.mean() > 0.6 and (sw == 0).mean() > 0.05
+    for k in o:
+        assert np.isfinite(g[k]).all(), k
+        close(g[k][:, ok], o[k][:, ok], "polar." + k)
