@@ -95,7 +95,10 @@ def main():
             dist.init_process_group(backend)
 
     import rsplash_amd
-    rsplash_amd.build_library()
+    if rank == 0:
+        rsplash_amd.build_library()  # no-op when the in-tree .so is current
+    if world > 1:
+        dist.barrier()               # other ranks load the library only after rank 0 has built it
     from rsplash_amd import api
 
     H, W, nt = args.rows, args.cols, args.days
