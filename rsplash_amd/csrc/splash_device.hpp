@@ -436,28 +436,23 @@ struct Etr { // src/etr.h:44-56 (fields the water balance needs)
 
 // hour angle (radians) and its sine from the cosine, with the reference's saturation at
 // >= 1 / <= -1 (src/SOLAR.cpp:149-159, 231-240; src/EVAP.cpp:209-218).  sin(acos x) is taken as
-// sqrt((1-x)(1+x)) (both factors exact near |x| = 1), which replaces a library sin per angle;
-// sin(180 deg) keeps the value the reference gets from sin(pi rounded to double).
+// sqrt((1-x)(1+x)) (both factors exact near |x| = 1), which replaces a library sin per angle.
+// Branch-free: the argument is saturated with selects (NaN stays NaN, as in the reference's else
+// branch) and acos(+-1) = 0 / pi fall out of the same evaluation, so the three-way branch and its
+// exec-mask bookkeeping disappear.  (sin(180 deg) is 0 here and 1.2e-16 in the reference.)
 __device__ __forceinline__ void hour_angle(double cosv, bool at_one_is_zero, double& h,
                                            double& sinh_)
 {
-    const double kSinPi = 1.2246467991473532e-16;
-    if (cosv >= 1.0) {
-        h = at_one_is_zero ? 0.0 : kPI;
-        sinh_ = at_one_is_zero ? 0.0 : kSinPi;
-    } else if (cosv <= -1.0) {
-        h = at_one_is_zero ? kPI : 0.0;
-        sinh_ = at_one_is_zero ? kSinPi : 0.0;
-    } else {
-        const double x = at_one_is_zero ? cosv : -cosv;
+    double x = at_one_is_zero ? cosv : -cosv;
+    x = (x >= 1.0) ? 1.0 : x;
+    x = (x <= -1.0) ? -1.0 : x;
 #if defined(SPL_ABLATE) && SPL_ABLATE == 2
-        h = 1.0 - x;
-        sinh_ = x;
+    h = 1.0 - x;
+    sinh_ = x;
 #else
-        h = facos(x);
-        sinh_ = fsqrt((1.0 - x) * (1.0 + x));
+    h = facos(x);
+    sinh_ = fsqrt((1.0 - x) * (1.0 + x));
 #endif
-    }
 }
 
 // src/SOLAR.cpp:77-267 + src/EVAP.cpp:82-264 for one cell-day.

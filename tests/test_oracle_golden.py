@@ -193,3 +193,42 @@ def test_synthetic_generator_is_counter_based(oracle):
     for x in a:
         assert np.array_equal(x, x.astype(np.float32).astype(np.float64))
     assert doy[364] == 365 and doy[365] == 1 and year[365] == 2002 and nm == 14
+
+
+def test_r_prelude_two_independent_restatements(oracle, bourne):
+    """soil_hydro / snowfall split exist only as R text (no interpreter here): the oracle's C
+    restatement and an independent numpy restatement (tests/r_prelude_numpy.py, vectorised like the
+    R code) must agree to rounding.  (Not a pin by execution -- DESIGN.md section 3 -- but a guard
+    against a transcription slip in either.)"""
+    import r_prelude_numpy as rp
+    rng = np.random.default_rng(42)
+    m = 3000
+    sand = rng.uniform(5, 90, m)
+    clay = rng.uniform(2, np.minimum(70, 98 - sand))
+    OM = rng.uniform(0.1, 12, m)
+    gravel = rng.uniform(0, 60, m)
+    bd = np.where(rng.random(m) < 0.3, np.nan, rng.uniform(0.5, 1.9, m))
+    a = rp.soil_hydro(sand, clay, OM, gravel, bd)
+    for j in range(m):
+        c = oracle.soil_hydro(sand[j], clay[j], OM[j], gravel[j], bd[j])
+        for k in c:
+            # A = exp(log 33 + B log fc) and theta_c amplify the last bit of log() by |B| (up to
+            # 1e4 where fc ~ wp); numpy's log and glibc's differ in that bit
+            rel = 1e-12 * (1 + 40 * abs(c["B"])) if k in ("A", "theta_c", "bubbling_p") else 1e-12
+            assert c[k] == pytest.approx(a[k][j], rel=rel, abs=1e-300), (k, j)
+    # Bourne site: the numbers the survey printed from the real run
+    s = bourne["soil"]
+    v = rp.soil_hydro(s[0], s[1], s[2], s[3], s[4])
+    assert float(v["SAT"]) * s[5] * 1000 == pytest.approx(257.3165, abs=6e-5)
+    assert 1 / float(v["B"]) == pytest.approx(0.370499, abs=6e-7)
+    # rain / snow split on the Bourne series and on synthetic cold/warm series
+    for lat, elev, tc in ((bourne["site"]["latitude"], bourne["site"]["elev_m"], bourne["Ta"]),
+                          (-55.0, 2500.0, rng.uniform(-25, 12, 800)),
+                          (5.0, 10.0, rng.uniform(18, 32, 800))):
+        month = rng.integers(1, 13, len(tc)).astype(np.int32)
+        pn = rng.uniform(0, 30, len(tc))
+        Tt, rain, snow = oracle.snow_partition(tc, pn, month, lat, elev)
+        Tt2, rain2, snow2 = rp.rain_snow(tc, pn, month, lat, elev)
+        assert Tt == Tt2
+        assert np.allclose(rain, rain2, rtol=1e-12, atol=1e-14)
+        assert np.allclose(snow, snow2, rtol=1e-12, atol=1e-12)
