@@ -513,3 +513,93 @@ def test_polar_day_and_night(api, oracle):
     for k in o:
         assert np.isfinite(g[k]).all(), k
         close(g[k][:, ok], o[k][:, ok], "polar." + k)
+
+
+def test_config3_thirty_years_streamed_in_year_chunks(api, oracle):
+    """BASELINE configs[3] at test size: 30 years (2001-2030, real leap days), spin-up, then the
+    transient run streamed one calendar year at a time through ONE reused forcing buffer filled by
+    the device generator (a 30-year 4096^2 raster cannot be resident), state carried in HBM,
+    monthly outputs.  Checked against the oracle's single 10 957-day run."""
+    import torch
+    dev = torch.device("cuda:0")
+    H, W, seed = 2, 32, 31
+    n = H * W
+    nt = 10957
+    doy, year, month, mid, nm = oracle.calendar(2001, nt)
+    assert year[-1] == 2030 and nm == 360
+    cal = api.Calendar(doy, year, month)
+    f64 = dict(dtype=torch.float64, device=dev)
+    lat, elev, slop, asp, res = (torch.empty(n, **f64) for _ in range(5))
+    soil, au = torch.empty(6, n, **f64), torch.empty(3, n, **f64)
+    api.dev_synth_statics(seed, H, W, 0, n, 1, lat, elev, slop, asp, res, soil, au)
+    par = torch.empty(api.NPAR, n, **f64)
+    api.dev_soil_hydro(n, lat, elev, slop, asp, res, soil, au, par)
+    # Tt needs the whole series: one streaming pass over tc, chunk by chunk (max of chunk maxima)
+    ybounds = [0] + [int(i) + 1 for i in np.where(np.diff(year) != 0)[0]] + [nt]
+    buf = [torch.empty(366, n, **f64) for _ in range(3)]
+    Tt = torch.full((n,), -np.inf, **f64)
+    Ttc = torch.empty(n, **f64)
+    for t0, t1 in zip(ybounds[:-1], ybounds[1:]):
+        api.dev_synth_forcing(seed, cal, t0, t1 - t0, 0, n, lat, elev, buf[0], buf[1], buf[2], n)
+        api.dev_snow_threshold(n, t1 - t0, buf[1], n, par, n, Ttc)
+        Tt = torch.maximum(Tt, Ttc)
+    # spin-up on the first 365 days
+    api.dev_synth_forcing(seed, cal, 0, 365, 0, n, lat, elev, buf[0], buf[1], buf[2], n)
+    state = torch.empty(api.NSTATE, n, **f64)
+    work = torch.empty(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
+    api.dev_spin_up(cal, n, buf[0], buf[1], buf[2], n, Tt, par, n, state, n, work)
+    names = ("wn", "snow", "ro", "aet", "pet")
+    mon = {k: torch.zeros(nm, n, **f64) for k in names}
+    for t0, t1 in zip(ybounds[:-1], ybounds[1:]):
+        api.dev_synth_forcing(seed, cal, t0, t1 - t0, 0, n, lat, elev, buf[0], buf[1], buf[2], n)
+        outs = {k: mon[k][int(mid[t0]):] for k in names}
+        api.dev_run_all(cal, t0, t1 - t0, n, buf[0], buf[1], buf[2], n, Tt, par, n, state, n, outs,
+                        n, monthly=True)
+    torch.cuda.synchronize()
+    st = oracle.synth_statics(seed, H, W, 0, n, 1)
+    sw, tc, pn = oracle.synth_forcing(seed, H, W, 0, n, 0, doy, st["lat"], st["elev"])
+    o, aux = oracle.grid(doy, year, month, mid, nm, sw, tc, pn, st["lat"], st["elev"], st["slop"],
+                         st["asp"], st["soil"], st["au"], st["resolution"], monthly_out=True)
+    from oracle.binding import grazing_mask
+    ok = (aux["fragile"] == 0) & (aux["soil_info"][:, 4] >= 0.01)
+    ok &= ~grazing_mask(oracle, st["lat"], st["slop"], st["asp"] - 180, doy[:366], year[:366]).any(0)
+    assert ok.mean() > 0.8
+    assert np.array_equal(Tt.cpu().numpy(), aux["Tt"])
+    for k in names:
+        close(mon[k].cpu().numpy()[:, ok], o[k][:, ok], "30y." + k)
+    cal.close()
+
+
+def test_config4_cru_shaped_land_mask_with_grid_totals(api, oracle):
+    """BASELINE configs[4] at test size: a lon/lat grid with 72 % NA (ocean) cells in the layout of
+    data/SA_cru.RData, cell size varying with latitude (resolution = sqrt(area)*1000,
+    R/splash.grid.R:98), monthly outputs and the monthly grid totals used for the basin /
+    water-balance diagnostics."""
+    H, W, nt = 20, 24, 730
+    n = H * W
+    doy, year, month, mid, nm = oracle.calendar(2014, nt)
+    st = oracle.synth_statics(5, H, W, 0, n, 1)
+    lat = np.repeat(13.25 - 0.5 * np.arange(H) * 3.4, W)  # 13 N ... 19 S in coarse steps
+    st["lat"] = lat
+    st["resolution"] = np.sqrt(55.6 * 55.6 * np.cos(np.radians(lat))) * 1000.0
+    st["au"][0] = st["resolution"] ** 2 * np.exp2(6 * np.random.default_rng(1).random(n))
+    sw, tc, pn = oracle.synth_forcing(5, H, W, 0, n, 0, doy, lat, st["elev"])
+    land = np.random.default_rng(2).random(n) < 0.28
+    land[:2] = False
+    for x in (sw, tc, pn):
+        x[:, ~land] = np.nan
+    elev = np.where(land, st["elev"], np.nan)
+    soil = np.where(land[None, :], st["soil"], np.nan)
+    dates = np.datetime64("2014-01-01") + np.arange(nt)
+    g = api.splash_grid(sw, tc, pn, elev, soil, lat, st["slop"], st["asp"], st["au"],
+                        st["resolution"], time_index=dates, want_diag=True, want_aux=True)
+    o, aux = oracle.grid(doy, year, month, mid, nm, sw, tc, pn, lat, elev, st["slop"], st["asp"],
+                         soil, st["au"], st["resolution"], monthly_out=True)
+    ok = land & (aux["fragile"] == 0) & (np.where(land, aux["soil_info"][:, 4], 1.0) >= 0.01)
+    for k in o:
+        assert np.isnan(g[k][:, ~land]).all() and np.isnan(o[k][:, ~land]).all()
+        close(g[k][:, ok], o[k][:, ok], "cru." + k)
+    # grid totals over the land cells (what an all-reduce would sum across GPUs)
+    if (ok == land).all():
+        for k in ("aet", "ro", "bflow"):
+            assert np.allclose(g["diag"][k], np.nansum(o[k], axis=1), rtol=1e-9)
