@@ -501,7 +501,7 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     double alb = alb_v;                        // snow-free: sfc = 0 => alb = alb_v exactly
     if (snow > 0.0 || isnan(snow)) {           // :208-219
         const double max_alb_snw = (1.0 - 0.443700) + (0.443700 * fexp(-0.895189 * nd));
-        const double sfc = snow / (140.0 + snow);
+        const double sfc = snow * frcp(140.0 + snow);
         alb = alb_v * (1.0 - sfc) + sfc * max_alb_snw;
     }
     double rw; // :220-224
@@ -566,7 +566,7 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
 
     double snowmelt = 0.0, sublimation = 0.0, melt_enrg = 0.0; // :233-249
     if (tc >= 3.0) {
-        const double m = (rn_d / (pw * kKfus)) * 1000.0;
+        const double m = (rn_d * frcp(pw * kKfus)) * 1000.0;
         snowmelt = SPL_MIN(snow, m);
         melt_enrg = (snowmelt * 1.0e-3) * pw * kKfus;
     }
@@ -647,12 +647,12 @@ __device__ __forceinline__ double inf_GA(const CellConst& c, double wn, double K
             I = Ksat * tdur;
         } else {
             const double hd = c.h_f * delta_theta;
-            double tp = (Ksat * delta_theta * -1.0 * c.h_f) / (r * (r - Ksat));
+            double tp = (Ksat * delta_theta * -1.0 * c.h_f) * frcp(r * (r - Ksat)); // r > Ksat > 0
             if (tp <= 0.0 || isnan(tp)) {
                 tp = 0.01;
             }
             const double tp_s = tp * c.inv_cos2;
-            I = r * tp_s + (Ksat * (tdur - tp_s) - (hd * flog(1 - (r * tp_s / hd))));
+            I = r * tp_s + (Ksat * (tdur - tp_s) - (hd * flog(1 - (r * tp_s * frcp(hd)))));
         }
     }
     if (I > P) {
@@ -706,7 +706,8 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
         // increment is a small multiple of ulp(psi_m) -- the same quantisation, though not the same
         // bits, as the reference's.
         const double xs = psi_m + w1000;
-        const double u = (xs - psi_m) / psi_m; // in (-1, 0] for a dry column; -0 when psi_m = -inf
+        const double u = (xs - psi_m) * frcp(psi_m); // in (-1, 0] for a dry column (NaN if psi_m = -inf:
+                                                      // T_uns then falls to the guard below, = 0)
         const double l1p = (fabs(u) < 1.0e-5) ? u * (1.0 - u * (0.5 - u * (1.0 / 3.0))) : flog(1.0 + u);
         const double z = -c.e3l1 * l1p;
         const double em1 = (fabs(z) < 1.0e-5) ? z * (1.0 + z * (0.5 + z * (1.0 / 6.0))) : fexp(z) - 1.0;
