@@ -73,3 +73,24 @@ def test_host_orbit_table_matches_oracle(oracle):
             kN, nu, lam, dr_o, delta = oracle.orbit(doy, year)
             assert dr == dr_o, (doy, year)
             assert abs(sd - math.sin(delta * pir)) <= 2.3e-16 and abs(cd - math.cos(delta * pir)) <= 2.3e-16
+
+
+def build_cpp_mirror(outdir):
+    """g++ the C++ host-mirror driver against the built library; returns the executable path"""
+    import subprocess
+    import rsplash_amd
+    so = rsplash_amd.build_library()
+    d = os.path.dirname(so)
+    exe = os.path.join(outdir, "cpp_mirror")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests/csrc/test_cpp_mirror.cpp"),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + d, "-lrsplash_hip",
+                           "-Wl,-rpath," + d, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_cpp_host_mirror_compiles_and_links(tmp_path):
+    """include/splash.hpp (class SPLASH with the Rcpp module's method signatures) against the .so"""
+    import subprocess
+    r = subprocess.run([build_cpp_mirror(str(tmp_path))], capture_output=True, text=True)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr

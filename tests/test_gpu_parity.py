@@ -167,6 +167,30 @@ def test_module_run_one_year(api, oracle, bourne):
     assert np.array_equal(g["snwage"], q["snwage"])
 
 
+def test_cpp_host_mirror_bourne(oracle, bourne, tmp_path):
+    """include/splash.hpp: class SPLASH from a plain C++ program (spin_up + run_all on one year)"""
+    import subprocess
+    from test_abi import build_cpp_mirror
+    b, s = bourne, bourne["site"]
+    si, rain, snowf = _bourne_prelude(oracle, b)
+    asp, n, y = s["asp_250m"] - 180, 365, int(b["year"][0])
+    head = [n, y, s["latitude"], s["elev_m"], s["slop_250m"], asp]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    np.concatenate([head, si[:12], b["sw_in"][:n], b["Ta"][:n], rain[:n], snowf[:n]]).astype("f8").tofile(fin)
+    subprocess.check_call([build_cpp_mirror(str(tmp_path)), fin, fout])
+    got = np.fromfile(fout).reshape(18, n)
+    o = oracle.spin_up(s["latitude"], s["elev_m"], n, y, b["sw_in"][:n], b["Ta"][:n], rain[:n],
+                       s["slop_250m"], asp, snowf[:n], si)
+    for i, k in enumerate(("sm", "snow", "qin", "tdrain", "ro", "snwage", "pet")):
+        close(got[i], o[k], "cpp.spin_up." + k)
+    q = oracle.run_all(s["latitude"], s["elev_m"], np.arange(1, n + 1), np.full(n, y), b["sw_in"][:n],
+                       b["Ta"][:n], rain[:n], o["sm"][-1], s["slop_250m"], asp, o["snow"][-1],
+                       snowf[:n], si, o["qin"][-1], o["tdrain"][-1], o["snwage"][-1])
+    for i, k in enumerate(("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "qin_prev",
+                           "tdrain", "snwage")):
+        close(got[7 + i], q[k], "cpp.run_all." + k)
+
+
 # ---------------------------------------------------------------- splash.point (BASELINE config 0)
 @pytest.mark.parametrize("flat", [False, True])
 @pytest.mark.parametrize("monthly", [False, True])
