@@ -93,6 +93,8 @@ int splash_dev_snow_threshold(size_t ncell, int nt, const double* tc, size_t ldf
  * src/SPLASH.cpp:1594-1749) on the first 365 days of the calendar: spin-up #1, aridity index
  * AI = sum(pet)/sum(P), cellout := AI (written to cellpar row 15), spin-up #2.  Writes the state
  * handed to run_all.  passes (optional) [2][ncell] int: executed passes of each spin-up.
+ * Spin-up #1 contributes nothing but the PET of its first pass (the reference iterates it to
+ * convergence and discards the result): it is run to convergence only when `passes` is given.
  * The pass count is data dependent (2..1000 per spin-up), so the stage runs as a few phases over
  * shrinking worklists; `work` is scratch of splash_dev_spin_up_work_size(ncell) bytes. */
 size_t splash_dev_spin_up_work_size(size_t ncell);

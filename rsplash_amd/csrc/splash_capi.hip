@@ -300,8 +300,11 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
     a.passes = passes;
     a.meta = (int*)(w + o_meta);
     a.ai = (double*)(w + o_ai);
-    // pass budgets per phase; the last one covers the 2 x 1000-pass worst case (src/SPLASH.cpp:1697)
-    static const int budget[] = {8, 16, 64, 2100};
+    // pass budgets per phase; the last one covers the 1000-pass worst case of a spin-up
+    // (src/SPLASH.cpp:1697).  With `passes` the first spin-up is iterated to its end as well (only
+    // to count its passes), otherwise it is a single pass: see k_spin_phase.
+    static const int budget_full[] = {8, 16, 64, 2100}, budget_fast[] = {4, 4, 16, 1100};
+    const int* budget = passes ? budget_full : budget_fast;
     for (int ph = 0; ph < 4; ph++) {
         a.fresh = (ph == 0);
         a.budget = budget[ph];
@@ -609,7 +612,7 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
         rc = splash_dev_snow_threshold(nb, nt, dtc, nb, par, nb, Tt, s);
         if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
         rc = splash_dev_spin_up(cal, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb,
-                                d_pass.as<int>(), d_swork.p, s);
+                                out->aux ? d_pass.as<int>() : nullptr, d_swork.p, s);
         if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
         splash_dev_out dout{};
         int q = 0;

@@ -219,7 +219,11 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         if (diff_sm < 0) diff_sm = e.wn - nxt.wn;
         if (!done) {
             if (acc) a.ai[ci] = pet_sum / p_sum; // R/splash.point.R:150
-            const bool cont = (diff_sm > 1.0) && (count < 1000); // :1697
+            // :1697.  Spin-up #1 only feeds the aridity index, and that uses the PET of its first
+            // pass alone (pet_vec is written in pass 0 only, :1667 vs :1718-1723; the states it
+            // returns are overwritten by spin-up #2, R/splash.point.R:148-152): unless its pass
+            // count is asked for, it stops after that pass.
+            const bool cont = (diff_sm > 1.0) && (count < 1000) && (stage == 2 || a.passes);
             if (cont) {
                 e = nxt;
                 count++;

@@ -318,10 +318,19 @@ def test_device_pipeline_chunking_and_generator(api, oracle):
     api.dev_snow_threshold(n, nt, tc, n, par, n, Tt)
     work = torch.empty(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
     passes = torch.zeros(2, n, dtype=torch.int32, device=dev)
+    par_cellout = par[15].clone()  # spin_up overwrites ncellout with the aridity index
     api.dev_spin_up(cal, n, sw, tc, pn, n, Tt, par, n, state, n, work, passes=passes)
     torch.cuda.synchronize()
     assert int(passes.min()) >= 2 and int(passes.max()) <= 1000
     state0 = state.clone()
+    # without `passes` spin-up #1 stops after the pass that yields the aridity index (its state is
+    # discarded by the reference as well): the same bits must come out
+    par2, state2 = par.clone(), torch.empty_like(state)
+    par2[15] = par_cellout
+    api.dev_spin_up(cal, n, sw, tc, pn, n, Tt, par2, n, state2, n, work)
+    torch.cuda.synchronize()
+    assert torch.equal(par2.view(torch.int64), par.view(torch.int64))
+    assert torch.equal(state2.view(torch.int64), state0.view(torch.int64))
     names = ("wn", "snow", "ro", "aet", "pet")
     one = {k: torch.empty(nt, n, **f64) for k in names}
     api.dev_run_all(cal, 0, nt, n, sw, tc, pn, n, Tt, par, n, state, n, one, n)
