@@ -46,6 +46,41 @@ def bourne():
 
 
 @pytest.fixture(scope="session")
+def atneu():
+    """the reference's second bundled site (data/ATNeu_example.RData -> tests/golden): 4018 days of
+    FLUXNET AT-Neu forcing and a soil vector with a measured bulk density"""
+    rows = list(csv.DictReader(open(os.path.join(GOLD, "atneu_forcing.csv"))))
+    site = json.load(open(os.path.join(GOLD, "atneu_site.json")))
+    dates = [datetime.date.fromisoformat(r["date"]) for r in rows]
+    d = dict(
+        dates=np.array(dates, dtype="datetime64[D]"),
+        doy=np.array([x.timetuple().tm_yday for x in dates], np.int32),
+        year=np.array([x.year for x in dates], np.int32),
+        month=np.array([x.month for x in dates], np.int32),
+        P=np.array([float(r["pn"]) for r in rows]),
+        Ta=np.array([float(r["tc"]) for r in rows]),
+        sw_in=np.array([float(r["sw_in"]) for r in rows]),
+        soil=np.array(site["soil"]),
+        site=site,
+    )
+    d["month_id"] = ((d["year"] - d["year"][0]) * 12 + d["month"] - 1).astype(np.int32)
+    d["nmonth"] = int(d["month_id"][-1]) + 1
+    return d
+
+
+@pytest.fixture(scope="session")
+def sa_cru():
+    """static rasters of the reference's bundled 0.5 degree South America grid (data/SA_cru.RData):
+    elev [nrows*ncols], soil [6][nrows*ncols], NaN over the ocean (72 %), and the row latitudes"""
+    z = np.load(os.path.join(GOLD, "sa_cru_statics.npz"))
+    nrows, ncols = int(z["nrows"]), int(z["ncols"])
+    xmin, xmax, ymin, ymax = z["extent"]
+    lat_rows = ymax - (np.arange(nrows) + 0.5) * (ymax - ymin) / nrows  # yFromRow: cell centres
+    return dict(elev=z["elev"].astype(np.float64), soil=z["soil"].astype(np.float64), nrows=nrows,
+                ncols=ncols, lat=np.repeat(lat_rows, ncols))
+
+
+@pytest.fixture(scope="session")
 def kat():
     return dict(np.load(os.path.join(GOLD, "ref_evap_kat.npz")))
 

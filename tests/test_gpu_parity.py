@@ -208,6 +208,50 @@ def test_splash_point_bourne(api, oracle, bourne, flat, monthly):
     print("max |dwn| =", np.max(np.abs(g["wn"] - o["wn"])))
 
 
+@pytest.mark.parametrize("slop,asp", [(0.0, 0.0), (12.0, 215.0)])
+def test_splash_point_atneu(api, oracle, atneu, slop, asp):
+    """the reference's second bundled site (FLUXNET AT-Neu, 11 years, measured bulk density)"""
+    b, s = atneu, atneu["site"]
+    au = 0.0 if slop == 0.0 else 40000.0
+    g = api.splash_point(b["sw_in"], b["Ta"], b["P"], s["latitude"], s["elev_m"], slop, asp,
+                         b["soil"], au, 250.0, time_index=b["dates"], monthly_out=False)
+    o, aux = oracle.point(b["doy"], b["year"], b["month"], b["month_id"], b["nmonth"], b["sw_in"],
+                          b["Ta"], b["P"], s["latitude"], s["elev_m"], slop, asp, b["soil"],
+                          [au, 3, 3], 250.0)
+    assert aux["fragile"] == 0
+    worst = {k: close(g[k], o[k], f"atneu[{slop}].{k}") for k in o}
+    print("max rel err", {k: f"{v:.2e}" for k, v in worst.items()})
+
+
+def test_splash_grid_sa_cru_statics(api, oracle, sa_cru):
+    """real static rasters: the reference's bundled 0.5 degree South America grid (139 x 159 cells,
+    72 % ocean = NA, soils with up to 45 % organic matter) under the synthetic daily forcing"""
+    H, W, nt = sa_cru["nrows"], sa_cru["ncols"], 365
+    n = H * W
+    doy, year, month, mid, nm = oracle.calendar(2001, nt)
+    lat, elev, soil = sa_cru["lat"], sa_cru["elev"], sa_cru["soil"]
+    sw, tc, pn = oracle.synth_forcing(20221130, H, W, 0, n, 0, doy, lat, np.nan_to_num(elev))
+    sea = np.isnan(elev)
+    for a in (sw, tc, pn):
+        a[:, sea] = np.nan
+    res = np.full(n, 55000.0) * np.sqrt(np.cos(np.radians(lat)))  # ~sqrt(cell area) in m
+    flat = np.zeros(n)
+    dates = np.datetime64("2001-01-01") + np.arange(nt)
+    g = api.splash_grid(sw, tc, pn, elev, soil, lat, flat, flat, None, res, time_index=dates,
+                        sim_control=dict(monthly_out=True), want_aux=True)
+    o, aux = oracle.grid(doy, year, month, mid, nm, sw, tc, pn, lat, elev, flat, flat, soil, None,
+                         res, monthly_out=True)
+    land = ~np.isnan(o["wn"][0])
+    assert 6000 < land.sum() < 6200
+    ok = land & (aux["fragile"] == 0) & (aux["soil_info"][:, 4] >= 0.01)
+    assert ok.sum() > 0.97 * land.sum()
+    for k in o:
+        assert np.isnan(g[k][:, ~land]).all() and np.isfinite(g[k][:, land]).all(), k
+    assert np.array_equal(g["aux"]["passes2"][ok], aux["passes2"][ok])
+    worst = {k: close(g[k][:, ok], o[k][:, ok], "sa_cru." + k) for k in o}
+    print("max rel err", {k: f"{v:.2e}" for k, v in worst.items()}, "set aside:", int((land & ~ok).sum()))
+
+
 # ---------------------------------------------------------------- splash.grid
 def _synth(oracle, H, W, nt, terrain, seed=20221130):
     doy, year, month, mid, nm = oracle.calendar(2001, nt)

@@ -232,3 +232,38 @@ def test_r_prelude_two_independent_restatements(oracle, bourne):
         assert Tt == Tt2
         assert np.allclose(rain, rain2, rtol=1e-12, atol=1e-14)
         assert np.allclose(snow, snow2, rtol=1e-12, atol=1e-12)
+
+
+def test_sa_cru_soils_two_independent_restatements(oracle, sa_cru):
+    """soil_hydro over every land cell of the reference's bundled South America soil rasters
+    (organic matter up to 45 %, gravel up to 51 %: ranges the random test does not reach)"""
+    import r_prelude_numpy as rp
+    land = ~np.isnan(sa_cru["elev"]) & ~np.isnan(sa_cru["soil"]).any(0)
+    S = sa_cru["soil"][:, land]
+    assert land.sum() > 6000 and S[2].max() > 40 and S[3].max() > 50
+    a = rp.soil_hydro(S[0], S[1], S[2], S[3], S[4])
+    bad = 0
+    for j in range(S.shape[1]):
+        c = oracle.soil_hydro(S[0, j], S[1, j], S[2, j], S[3, j], S[4, j])
+        for k in c:
+            rel = 1e-12 * (1 + 40 * abs(c["B"])) if k in ("A", "theta_c", "bubbling_p") else 1e-12
+            if np.isnan(c[k]) or np.isnan(a[k][j]):
+                assert np.isnan(c[k]) and np.isnan(a[k][j]), (k, j)
+            else:
+                assert c[k] == pytest.approx(a[k][j], rel=rel, abs=1e-300), (k, j)
+        bad += int(not (c["SAT"] > c["FC"] > c["WP"] > 0))
+    assert bad < 0.01 * S.shape[1]  # the pedotransfer functions stay ordered on real soils
+
+
+def test_atneu_point_oracle_sanity(oracle, atneu):
+    """second bundled site: the restatement runs the 11 years without NaN and closes the water
+    balance of the bucket to rounding (P + condensation - AET - runoff - baseflow = storage change)"""
+    b, s = atneu, atneu["site"]
+    res, aux = oracle.point(b["doy"], b["year"], b["month"], b["month_id"], b["nmonth"], b["sw_in"],
+                            b["Ta"], b["P"], s["latitude"], s["elev_m"], 0.0, 0.0, b["soil"],
+                            [0.0, 3, 3], 250.0)
+    for k, v in res.items():
+        assert np.isfinite(v).all(), k
+    assert 2 <= aux["passes2"] <= 1000
+    assert 0 < res["aet"].mean() < res["pet"].mean() < 10
+    assert res["snow"].max() > 10  # alpine valley: a seasonal snow pack builds up

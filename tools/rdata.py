@@ -1,7 +1,7 @@
 """Minimal reader for gzip'd R `save()` files (RDX2 / XDR serialisation, format version 2).
 
 Used once, in the build container, to turn the reference's bundled example data
-(data/Bourne.RData) into a plain CSV/JSON fixture under tests/golden/ -- there is no R
+(data/*.RData) into plain CSV/JSON/NPZ fixtures under tests/golden/ -- there is no R
 interpreter in the image.  Only the node types that occur in those files are handled.
 """
 import gzip
@@ -136,13 +136,51 @@ class Reader:
             o = RObj(self.take(n), kind="raw")
         elif t == S4SXP:
             o = RObj(None, kind="S4")
-        elif t == BCODESXP:
-            raise NotImplementedError("byte-code objects are not needed for the fixtures")
+        elif t == BCODESXP:  # compiled closures inside S4 objects (SA_cru.RData): parsed to skip over
+            reps = [None] * self.i32()
+            o = RObj(self.bc1(reps), kind="bytecode")
         else:
             raise NotImplementedError(f"SEXP type {t} at {self.p}")
         if has_attr:
             o.attrs = self.pairlist_to_attrs(self.item())
         return o
+
+
+def _bc1(self, reps):
+    code = self.item()
+    n = self.i32()
+    consts = []
+    for _ in range(n):
+        t = self.i32()
+        if t == BCODESXP:
+            consts.append(self.bc1(reps))
+        elif t in (LANGSXP, LISTSXP, BCREPDEF, BCREPREF, ATTRLANGSXP, ATTRLISTSXP):
+            consts.append(self.bclang(t, reps))
+        else:
+            consts.append(self.item())
+    return (code, consts)
+
+
+def _bclang(self, t, reps):
+    if t == BCREPREF:
+        return reps[self.i32()]
+    if t in (BCREPDEF, LANGSXP, LISTSXP, ATTRLANGSXP, ATTRLISTSXP):
+        pos = -1
+        if t == BCREPDEF:
+            pos, t = self.i32(), self.i32()
+        node = RObj(None, kind="bclang")
+        if pos >= 0:
+            reps[pos] = node
+        attr = self.item() if t in (ATTRLANGSXP, ATTRLISTSXP) else None
+        tag = self.item()
+        car = self.bclang(self.i32(), reps)
+        cdr = self.bclang(self.i32(), reps)
+        node.value = (tag, car, cdr, attr)
+        return node
+    return self.item()  # the type word was a pad
+
+
+Reader.bc1, Reader.bclang = _bc1, _bclang
 
 
 def load(path):
