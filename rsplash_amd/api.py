@@ -103,13 +103,17 @@ def splash_point(sw_in, tc, pn, lat, elev, slop=0.0, asp=0.0, soil_data=None, Au
 # ---------------------------------------------------------------------------- splash.grid
 def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=250.0,
                 time_index=None, sim_control=None, outputs=OUT_NAMES, device=0,
-                max_cells_per_launch=0, want_aux=False, want_diag=False):
+                max_cells_per_launch=0, want_aux=False, want_diag=False, outdir=None, lon=None):
     """R/splash.grid.R:28 on arrays.  sw_in/tc/pn: [nt, ncell] (or [nt, H, W]) daily rasters;
     elev/lat/slop/asp: [ncell]; soil: [6, ncell]; Au: [3, ncell] (area, ncellin, ncellout) or
     None.  The static rasters the reference derives with raster/GDAL/TauDEM (lat, slope, aspect,
     upslope area, resolution: R/splash.grid.R:76-110) are inputs here.  sim_control =
     dict(monthly_out=True) mirrors sim.control (monthly is the reference's default).
-    Returns dict of [nt_out, ...] arrays named as R/splash.grid.R:449 (netr is 'netrad' there)."""
+    Returns dict of [nt_out, ...] arrays named as R/splash.grid.R:449 (netr is 'netrad' there).
+    With `outdir` (and [nt, H, W] rasters) the bricks are also written as NetCDF files named, and
+    with variables named, as the reference names them (sim.control$inmem = FALSE,
+    R/splash.grid.R:186-216; rsplash_amd/io.py); `lon` [W] gives the x axis (default: column index),
+    the y axis is the latitude raster's first column.  Paths come back under "files"."""
     if time_index is None:
         raise ValueError("time_index is required")
     monthly = True if sim_control is None else bool(sim_control.get("monthly_out", True))
@@ -154,6 +158,13 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     rc = lib.splash_grid_run(C.byref(gin), C.byref(opt), C.byref(gout), err, 512)
     if rc:
         raise SplashError(f"splash_grid_run failed ({rc}): {err.value.decode()}")
+    if outdir is not None:
+        if len(shp) != 2:
+            raise ValueError("outdir needs [nt, H, W] rasters")
+        from . import io as _io
+        latr = np.asarray(lat, dtype=np.float64).reshape(shp)[:, 0]
+        lonv = np.arange(shp[1], dtype=np.float64) if lon is None else np.asarray(lon, dtype=np.float64)
+        res["files"] = _io.write_bricks(outdir, res, lonv, latr, time_index, monthly)
     res["state_end"] = state_end
     if want_aux:
         res["aux"] = dict(Tt=aux[0], AI=aux[1], passes1=aux[2], passes2=aux[3])

@@ -5,6 +5,8 @@ reference, written as  |x - ref| <= 1e-5*|ref| + 1e-9  (1e-9 mm of water is the 
 entries that are ~0 by cancellation or clamping).  Index-like quantities (spin-up pass counts, snow
 age, NaN patterns, viscosity float bit patterns) must match exactly.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -295,6 +297,24 @@ def test_splash_grid_synthetic(api, oracle, terrain, monthly):
         last = np.array([np.where(d["mid"] == m)[0][-1] for m in range(d["nm"])])
         assert np.allclose(g["diag"]["wn"], o["wn"][last].sum(1), rtol=1e-10)
         assert np.allclose(g["diag"]["snow"], o["snow"][last].sum(1), rtol=1e-9, atol=1e-9)
+
+
+def test_splash_grid_writes_reference_named_bricks(api, oracle, tmp_path):
+    """sim.control$inmem = FALSE (R/splash.grid.R:186-216): [nt, H, W] rasters in, NetCDF bricks out"""
+    from scipy.io import netcdf_file
+    H, W, nt = 6, 16, 730
+    d = _synth(oracle, H, W, nt, 1)
+    st = d["st"]
+    r3 = lambda a: a.reshape(nt, H, W)
+    g = api.splash_grid(r3(d["sw"]), r3(d["tc"]), r3(d["pn"]), st["elev"], st["soil"], st["lat"],
+                        st["slop"], st["asp"], st["au"], st["resolution"], time_index=d["dates"],
+                        sim_control=dict(monthly_out=True, inmem=False), outdir=str(tmp_path))
+    assert len(g["files"]) == 9 and g["wn"].shape == (24, H, W)
+    assert os.path.basename(g["files"]["wn"]) == "SPLASH_v2.0_swc_monthly_2001-2002.nc"
+    with netcdf_file(g["files"]["aet"], "r", mmap=False) as f:
+        a = f.variables["aet"][:].astype(np.float64)
+        assert a.shape == (24, H, W) and np.allclose(a, g["aet"], rtol=1e-6, atol=1e-30)
+        assert np.allclose(f.variables["lat"][:], st["lat"].reshape(H, W)[:, 0])
 
 
 def test_splash_grid_na_cells_and_blocking(api, oracle):
