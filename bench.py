@@ -193,13 +193,14 @@ def main():
     avg_launch_s = float(k_ms[full].mean()) / 1e3
     units_per_launch = float(k_cells.max()) * nt
     achieved = ALG_BYTES_PER_CELL_DAY * units_per_launch / avg_launch_s / 1e9
-    traffic = None
+    traffic = valu_busy = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             key = f"{min(args.block_rows, H)}x{W}x{nt}"
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            valu_busy = tj.get(key, {}).get("valu_busy_frac")
         except Exception:
             traffic = None
 
@@ -224,7 +225,10 @@ def main():
                      "kernel": "k_run_all<daily,diag>", "avg_launch_ms": avg_launch_s * 1e3,
                      "units_per_launch": units_per_launch,
                      "alg_bytes_per_unit": ALG_BYTES_PER_CELL_DAY,
-                     "note": "FP64 VALU-bound: ~25 transcendentals per cell-day; see DESIGN.md"},
+                     "valu_busy_frac": valu_busy,
+                     "note": "the launch is FP64-VALU-issue bound, not HBM bound (~1.9k vector "
+                             "instructions per wavefront-day); valu_busy_frac = share of SIMD cycles "
+                             "issuing vector instructions, from the PMC pass in profiles/; see DESIGN.md"},
         "spinup": {"seconds": spinup_s, "cells": n,
                    "note": "both spin-ups of every cell (2..1000 passes of 365 days each, data "
                            "dependent); untimed setup, not part of value"},

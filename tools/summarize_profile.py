@@ -105,7 +105,13 @@ def main():
                "* reading: the launch is FP64-VALU-issue bound (pointwise transcendental stream), "
                "as SURVEY.md 8(d) predicted; HBM is at a few percent of its rate"]
     open(os.path.join(out, f"{tag}_summary.md"), "w").write("\n".join(md) + "\n")
-    tj = {f"{rows_blk}x{W}x{nt}": {"hbm_bytes_per_launch": traffic, "fetch_bytes_corrected": ra_fetch,
+    valu = {}
+    if sq:
+        # 2 waves per SIMD: the vector pipe is busy when either wave issues a VALU instruction
+        valu = {"valu_busy_frac": 2.0 * sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"],
+                "valu_insts_per_wave_day": sq["SQ_INSTS_VALU"] / waves / nt,
+                "salu_insts_per_wave_day": sq["SQ_INSTS_SALU"] / waves / nt}
+    tj = {f"{rows_blk}x{W}x{nt}": {**valu, "hbm_bytes_per_launch": traffic, "fetch_bytes_corrected": ra_fetch,
                                     "write_bytes": ra_write, "fetch_size_calibration": factor,
                                     "algorithmic_bytes": alg_read + alg_write, "source": f"profiles/{tag}_summary.md"}}
     json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
