@@ -166,6 +166,21 @@ __device__ const uint64_t kExp2fTab[32] = {
     0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
     0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL};
 
+// The table is read from LDS, not from global memory: vector-memory loads return in order
+// (vmcnt), so a table load in the middle of the day step would make its s_waitcnt also wait for
+// the next day's forcing, which the kernels prefetch a whole day ahead so that its HBM (and TLB
+// miss) latency stays off the critical path.  LDS reads are counted separately (lgkmcnt).
+// Every kernel that reaches expf_glibc calls lds_tables_init() first, with all threads of the block.
+__shared__ uint64_t s_exp2f_tab[32];
+
+__device__ __forceinline__ void lds_tables_init()
+{
+    if (threadIdx.x < 32) s_exp2f_tab[threadIdx.x] = kExp2fTab[threadIdx.x];
+    if (blockDim.x < 32 && threadIdx.x == 0)
+        for (int i = (int)blockDim.x; i < 32; i++) s_exp2f_tab[i] = kExp2fTab[i];
+    __syncthreads();
+}
+
 __device__ __forceinline__ float expf_glibc(float x)
 {
     constexpr double N = 32.0;
@@ -187,7 +202,7 @@ __device__ __forceinline__ float expf_glibc(float x)
     uint64_t ki = (uint64_t)__double_as_longlong(kd);
     kd -= Shift;
     double r = z - kd;
-    uint64_t t = kExp2fTab[ki & 31];
+    uint64_t t = s_exp2f_tab[ki & 31];
     t += ki << 47;
     double s = __longlong_as_double((long long)t);
     double zz = C0 * r + C1;

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
 {
     const size_t nin = a.n_in ? (size_t)*a.n_in : a.ncell;
     if ((size_t)blockIdx.x * kBlock >= nin) return; // whole workgroup past the list
+    lds_tables_init();
     const size_t slot = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool valid = slot < nin;
     const size_t sl = valid ? slot : nin - 1;
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
 __global__ __launch_bounds__(64) void k_spin_up_mod(SpinArgs a, double* const* series, size_t sld,
                                                    const double* snowfall)
 {
+    lds_tables_init();
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const size_t ci = 0;
     Forcing f{a.sw, a.tc, a.pn, snowfall, a.ldf, 0.0, 0.0, ci};
@@ -320,6 +322,7 @@ __device__ __forceinline__ double wave_sum(double v)
 template <bool MONTHLY, bool DIAG>
 __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a)
 {
+    lds_tables_init();
     __shared__ double red[DIAG ? 4 * SPLASH_NDIAG_K : 1];
     size_t cell = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool valid = cell < a.ncell;
@@ -435,6 +438,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
 // module mirror of run_all: daily series of all 11 outputs for a handful of cells
 __global__ __launch_bounds__(64) void k_run_all_mod(RunArgs a)
 {
+    lds_tables_init();
     size_t cell = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (cell >= a.ncell) return;
     Forcing f{a.sw, a.tc, a.pn, a.snowfall, a.ldf, 0.0, 0.0, cell};
@@ -561,6 +565,7 @@ __global__ __launch_bounds__(kBlock) void k_evap_batch(size_t m, const double* l
                                                       const double* asp, const double* snow,
                                                       const double* nd, double* out)
 {
+    lds_tables_init();
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
     CellConst c;
