@@ -77,7 +77,7 @@ struct CellConst {
     double d1000, inv_d1000; // depth*1000 and its inverse
     double depth;
     double theta_s, inv_theta_s, theta_r, dtheta, inv_dtheta; // dtheta = theta_s - theta_r
-    double inv_lambda, e3l1, e_uns; // 1/lambda, 3*lambda+1, (3*lambda+1)/lambda
+    double inv_lambda, e3l1; // 1/lambda, 3*lambda+1
     double lambda;
     double bub, bpr, z_bpr; // bubbling pressure [mm], [cm], 10 cm / bpr
     double Wmax, wm_th, inv_wr; // src/SPLASH.cpp:1029, Wmax/(depth*1000), 1/(Wmax-RES)
@@ -391,7 +391,6 @@ __device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, 
     const double sid_oct = sqrt(Ai / (2.0 * (1 + sqrt(2.0))));
     c.inv_lambda = 1 / lambda;
     c.e3l1 = 3.0 * lambda + 1.0;
-    c.e_uns = c.e3l1 * c.inv_lambda;
     c.kun_exp = 3.0 + (2.0 / lambda);
 
     // src/SPLASH.cpp:1027-1029
@@ -696,8 +695,10 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
     Acs_out = (c.depth - 0.5 * c.depth) * c.so_cellout;
     return Ksat_visc * 1e-3 * sm;
 #endif
-    const double L = flog(rel_saturation(c, sm));
-    const double psi_m = c.bub * fexp(-L * c.inv_lambda); // bub / Theta^(1/lambda)
+    const double Theta = rel_saturation(c, sm);
+    const double L = flog(Theta);
+    const double P = fexp(-L * c.inv_lambda); // Theta^(-1/lambda) in [1, +inf]
+    const double psi_m = c.bub * P;           // bub / Theta^(1/lambda)
     double wtd = ((c.bub - psi_m) * 1.0e-3);
     bool clamped = false;
     if (wtd < 0.0 || isnan(wtd)) {
@@ -709,7 +710,9 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
     }
     Acs_out = (c.depth - wtd) * c.so_cellout;
     const double w1000 = wtd * 1000.0;
-    const double A = fexp(L * c.e_uns);
+    // A = Theta^((3*lambda+1)/lambda) = Theta^3 * Theta^(1/lambda) = Theta^3 / P: a reciprocal instead
+    // of a second exponential (P = +inf for Theta = 0 gives A = 0, like the reference's pow(-0, e))
+    const double A = (P < 1.0e300) ? (Theta * Theta * Theta) * frcp(P) : 0.0;
     double diff; // A - B
     if (!clamped) {
         diff = A - 1.0; // bub/(psi_m + wtd*1000) is 1 +- 1 ulp: B = 1 to 1e-16
@@ -829,10 +832,20 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     double q_in_f = 0.0;
     td -= 1.0;
     if ((R > 0.0) && (sm > c.Wmax)) {
-        if (!have_kb) Kb = fexp(lkb_arg);
+        // log(Kb) with Kb = exp(lkb_arg) (:1326, :1470): the round trip returns lkb_arg up to the
+        // rounding of Kb, an ABSOLUTE 1e-16, i.e. relative 1e-16/|lkb_arg|.  Above 1e-7 that is
+        // < 1e-9 and the argument itself is used (one log, and the exp when Kb was not needed for
+        // the upslope inflow, saved per cell-day); exactly 0 (flat terrain: Kb = 1, log = 0, the
+        // sticky-NaN drainage time of SURVEY trap 3) is exact either way; the sliver in between,
+        // and an underflowing Kb, go the reference's way.
+        const double ax = fabs(lkb_arg);
+        double lkb = lkb_arg;
+        if (!(ax == 0.0 || (ax >= 1.0e-7 && ax <= 700.0))) {
+            if (!have_kb) Kb = fexp(lkb_arg);
+            lkb = flog(Kb);
+        }
         const double Q = (T * c.Ai) * 1.0e-3; // :1456
         const double Qt = (Ksat_visc * c.qt_coef) * hyd_grad_out; // :1360
-        const double lkb = flog(Kb);
         t_drain = -1.0 * flog(1.0 - (lkb * (c.Au * R / Q))) / lkb;
         q_in_f = (Qt - c.Au * R * lkb) * c.inv_Ai;
     }

@@ -124,6 +124,9 @@ SPL_HD double fsqrt(double x)
 // Branch-free: the series runs for every argument and special values are patched by selects.
 SPL_HD double flog(double x)
 {
+#if defined(SPL_ABLATE) && SPL_ABLATE == 7
+    return x - 1.0;
+#endif
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
                  Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
@@ -151,6 +154,9 @@ SPL_HD double flog(double x)
 // exponential, < 1 ulp; exp(-inf) = 0, overflow -> +inf, NaN -> NaN.  Branch-free.
 SPL_HD double fexp(double x)
 {
+#if defined(SPL_ABLATE) && SPL_ABLATE == 8
+    return 1.0 + x * 1e-3;
+#endif
     const double log2e = 1.44269504088896338700e+00;
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double xc = fmin(fmax(x, -746.0), 710.0); // ldexp saturates to 0 / inf at the ends
@@ -179,6 +185,9 @@ SPL_HD double fpow(double x, double y) { return fexp(y * flog(x)); }
 // does not run two copies of the polynomial.
 SPL_HD double facos(double x)
 {
+#if defined(SPL_ABLATE) && SPL_ABLATE == 9
+    return 1.5707963267948966 - x;
+#endif
     const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
     const double pi = 3.14159265358979311600e+00;
     const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
