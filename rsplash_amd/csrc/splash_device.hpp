@@ -170,11 +170,13 @@ __device__ const uint64_t kExp2fTab[32] = {
 // (vmcnt), so a table load in the middle of the day step would make its s_waitcnt also wait for
 // the next day's forcing, which the kernels prefetch a whole day ahead so that its HBM (and TLB
 // miss) latency stays off the critical path.  LDS reads are counted separately (lgkmcnt).
-// Every kernel that reaches expf_glibc calls lds_tables_init() first, with all threads of the block.
+// Every kernel that reaches expf_glibc or flog calls lds_tables_init() first, with all threads of
+// the block (it also fills the logarithm's table, splash_math.hpp).
 __shared__ uint64_t s_exp2f_tab[32];
 
 __device__ __forceinline__ void lds_tables_init()
 {
+    math_tables_init();
     if (threadIdx.x < 32) s_exp2f_tab[threadIdx.x] = kExp2fTab[threadIdx.x];
     if (blockDim.x < 32 && threadIdx.x == 0)
         for (int i = (int)blockDim.x; i < 32; i++) s_exp2f_tab[i] = kExp2fTab[i];

@@ -491,6 +491,7 @@ __global__ __launch_bounds__(kBlock) void k_unswc(size_t ncell, int nt,
                                                  double* __restrict__ wtd_o,
                                                  double* __restrict__ theta_o, size_t ldo)
 {
+    lds_tables_init();
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= ncell) return;
     const double sand = soil[i], clay = soil[ncell + i], OM = soil[2 * ncell + i];
@@ -604,6 +605,7 @@ __global__ __launch_bounds__(kBlock) void k_evap_batch(size_t m, const double* l
 __global__ __launch_bounds__(kBlock) void k_math_probe(size_t n, const double* x, const double* y,
                                                       double* out)
 {
+    lds_tables_init();
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     out[i] = flog(x[i]);
@@ -617,6 +619,7 @@ __global__ __launch_bounds__(kBlock) void k_math_probe(size_t n, const double* x
 __global__ void k_moist_surf(double depth, double z, double bub_p, double wn, double SAT,
                              double RES, double lambda, double* out)
 {
+    lds_tables_init();
     double theta_r = RES / (depth * 1000.0);
     double theta_s = SAT / (depth * 1000.0);
     double bubbling_pr = bub_p / 10;
@@ -637,6 +640,7 @@ __global__ void k_moist_surf(double depth, double z, double bub_p, double wn, do
 __global__ void k_inf_GA(double bub_press, double theta_i, double Ksat, double theta_s,
                          double lambda, double P, double tdur, double slop, double* out)
 {
+    lds_tables_init();
     double r = P / tdur;
     double h_f = ((2 + 3 * lambda) / (1 + 3 * lambda)) * (bub_press / 2);
     double delta_head = h_f;

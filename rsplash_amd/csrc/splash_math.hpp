@@ -120,35 +120,58 @@ SPL_HD double fsqrt(double x)
 #endif
 }
 
-// natural logarithm, < 1 ulp for normal positive x; log(0) = -inf, log(x<0) = NaN.
-// Branch-free: the series runs for every argument and special values are patched by selects.
+// natural logarithm, table driven (Tang / glibc scheme), <~ 2 ulp; log(0) = -inf, log(x<0) = NaN.
+//   x = 2^k * z, z in [0.6875, 1.375);  log x = k*ln2 + log c_i + log1p(z/c_i - 1)
+// with (1/c_i, log c_i) from a 128-entry table indexed by the top 7 mantissa bits (offset so that
+// the interval is centred on 1: no cancellation between k*ln2 and the rest), r = z/c_i - 1 formed
+// exactly enough by one FMA (|r| < 0.0079) and log1p(r) by its series to r^8.  The two intervals
+// that touch 1 have c = 1: log(1) = 0 exactly (the water balance relies on it: Kb = 1 on flat
+// terrain) and full relative accuracy around 1 (near saturation log(Theta) -> 0).
+// Against the division-based fdlibm form this saves the reciprocal (a quarter-rate seed and two
+// Newton steps) and half of the polynomial: ~20 of ~56 issue slots per call, and the day step
+// spends a sixth of its time in log().  On the device the table is read from LDS (filled by
+// math_tables_init(), which every kernel that reaches flog calls first).
+// Branch-free: special values are patched by selects.
+#include "splash_log_table.hpp"
+#if defined(__HIPCC__)
+__device__ const double kLogTabDev[256] = {SPL_LOG_TABLE_VALUES};
+__shared__ double s_log_tab[256];
+__device__ __forceinline__ void math_tables_init()
+{
+    for (unsigned i = threadIdx.x; i < 256; i += blockDim.x) s_log_tab[i] = kLogTabDev[i];
+}
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SPL_LOG_TAB(i) s_log_tab[i]
+#else
+static const double kLogTabHost[256] = {SPL_LOG_TABLE_VALUES};
+#define SPL_LOG_TAB(i) kLogTabHost[i]
+#endif
+
 SPL_HD double flog(double x)
 {
-#if defined(SPL_ABLATE) && SPL_ABLATE == 7
-    return x - 1.0;
-#endif
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                 Lg7 = 1.479819860511658591e-01;
     int e;
-    double m = frexp(x, &e); // [0.5, 1)
-    const bool lo = m < 0.70710678118654752440;
-    m = lo ? m + m : m;
-    e = lo ? e - 1 : e;
-    const double f = m - 1.0; // exact
-    const double s = f * frcp(2.0 + f); // 2+f in [1.7, 2.42]
-    const double z = s * s, w = z * z;
-    const double t1 = w * horner2(Lg6, w, Lg4, Lg2);
-    const double t2 = z * horner3(Lg7, w, Lg5, Lg3, Lg1);
-    const double R = t2 + t1;
-    const double hfsq = 0.5 * f * f;
-    const double dk = (double)e;
-    double r = dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
-    r = (x < HUGE_VAL) ? r : x;                 // +inf (NaN falls through to the next line)
-    r = (x > 0.0) ? r : ((x == 0.0) ? -HUGE_VAL : (x - x) / (x - x) + x); // 0 -> -inf, <0/NaN -> NaN
-    return r;
+    const double m = frexp(x, &e); // [0.5, 1); handles subnormal x
+    const unsigned long long bm = __builtin_bit_cast(unsigned long long, m);
+    const unsigned hi = (unsigned)(bm >> 32);
+    const int tmp = (int)(hi - 0x3FE60000u);
+    const int i = (tmp >> 13) & 127;
+    const int kk = tmp >> 20; // -1 for m < 0.6875 (then z = 2m), else 0
+    const unsigned zhi = hi - ((unsigned)tmp & 0xFFF00000u);
+    const double z = __builtin_bit_cast(double, ((unsigned long long)zhi << 32) | (bm & 0xFFFFFFFFull));
+    const double invc = SPL_LOG_TAB(2 * i), logc = SPL_LOG_TAB(2 * i + 1);
+    const double r = fma(z, invc, -1.0);
+    const double kd = (double)(e + kk);
+    const double r2 = r * r;
+    double p = horner5(-1.0 / 8.0, r, 1.0 / 7.0, -1.0 / 6.0, 1.0 / 5.0, -1.0 / 4.0, 1.0 / 3.0);
+    p = fma(p, r, -0.5); // log1p(r) = r + r^2 * p
+    const double hi_ = fma(kd, ln2_hi, logc);
+    const double lo_ = fma(kd, ln2_lo, r2 * p);
+    double res = (hi_ + r) + lo_;
+    res = (x < HUGE_VAL) ? res : x;                 // +inf (NaN falls through to the next line)
+    res = (x > 0.0) ? res : ((x == 0.0) ? -HUGE_VAL : (x - x) / (x - x) + x); // 0 -> -inf, <0/NaN -> NaN
+    return res;
 }
 
 // exponential, < 1 ulp; exp(-inf) = 0, overflow -> +inf, NaN -> NaN.  Branch-free.

@@ -76,7 +76,7 @@ def test_device_math_vs_libm(api):
     y = rng.uniform(0.3, 12, n)
     out = api.math_probe(x, y)
     ulp = lambda a, b: np.abs(a - b) / np.spacing(np.abs(b))
-    assert ulp(out[0], np.log(x)).max() <= 1.5
+    assert ulp(out[0], np.log(x)).max() <= 2.5  # table-driven log: <~ 2 ulp
     assert ulp(out[4], np.sqrt(x)).max() <= 1.5
     xe = np.r_[rng.uniform(-40, 40, n // 2), rng.uniform(-740, 700, n // 2)]
     oe = api.math_probe(xe, y)[1]
