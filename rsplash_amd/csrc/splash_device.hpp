@@ -25,6 +25,29 @@
 
 namespace splash {
 
+// ---- call-site counters: profiling build only (-DSPL_SITES, tools/site_profile.sh) ------------
+// How often each transcendental call site / rare branch of the day step runs inside k_run_all, per
+// lane and per wavefront; printed to stderr after every run_all launch.  Expands to nothing in the
+// product build.
+#ifdef SPL_SITES
+__device__ unsigned long long g_site_hits[2048][2];
+__shared__ int s_site_on;
+__device__ __forceinline__ void site_hit(int line)
+{
+    if (!s_site_on) return;
+    atomicAdd(&g_site_hits[line & 2047][0], 1ull);
+    const unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&g_site_hits[line & 2047][1], 1ull);
+}
+#define flog(x) (site_hit(__LINE__), flog(x))
+#define fexp(x) (site_hit(__LINE__), fexp(x))
+#define facos(x) (site_hit(__LINE__), facos(x))
+#define fpow(x, y) (site_hit(__LINE__), fpow(x, y))
+#define SPL_SITE() site_hit(__LINE__)
+#else
+#define SPL_SITE() ((void)0)
+#endif
+
 // ---- src/global.cpp:49-83 ------------------------------------------------------------------
 constexpr double kA = 91.86328;
 constexpr double kAlbSw = 0.30;
@@ -176,6 +199,9 @@ __shared__ uint64_t s_exp2f_tab[32];
 
 __device__ __forceinline__ void lds_tables_init()
 {
+#ifdef SPL_SITES
+    if (threadIdx.x == 0) s_site_on = 0;
+#endif
     math_tables_init();
     if (threadIdx.x < 32) s_exp2f_tab[threadIdx.x] = kExp2fTab[threadIdx.x];
     if (blockDim.x < 32 && threadIdx.x == 0)
@@ -562,7 +588,10 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     const double econ = s * sg2 * inv_e;
     double visc = c.visc0;                                            // :100-105, :120
 #if !(defined(SPL_ABLATE) && SPL_ABLATE == 1)
-    if (!(tc < 0.0)) visc = (double)viscosity_h2o((float)tc, c.patm_f);
+    if (!(tc < 0.0)) {
+        SPL_SITE();
+        visc = (double)viscosity_h2o((float)tc, c.patm_f);
+    }
 #endif
     const double cn = (1.0e3) * econ * fabs(rnn_d) * 0.1;             // :124
     const double eet_d = (1.0e3) * (s * sg1 * inv_e) * rn_d;          // :129
@@ -657,6 +686,7 @@ __device__ __forceinline__ double inf_GA(const CellConst& c, double wn, double K
     const double r = P * (1.0 / 6.0); // P/tdur
     double I = P;
     if (!(r <= Ksat)) {
+        SPL_SITE();
         const double theta_i = moist_surf(c, wn);
         const double delta_theta = (c.theta_s - theta_i);
         if (delta_theta <= 0.0) {
@@ -809,10 +839,12 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
 
     // :1406-1457 transmittance after recharge
     double Acs_out;
+    SPL_SITE();
     const double T_uns1 = transmittance_uns(c, Ksat_visc, sm, Acs_out);
     const double sm1 = sm;
     double T_uns = T_uns1, T_sat;
     if (c.deep) { // depth >= 2.0: vertical drainage corrections :1433-1450
+        SPL_SITE();
         // :984-990 clamp of the start-of-day volumetric content, :1267 theta_m
         double theta_i = wn * c.inv_d1000;
         if (wn >= c.SAT) { // theta_i >= theta_s (division by depth*1000 is monotone)
@@ -834,6 +866,7 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     double q_in_f = 0.0;
     td -= 1.0;
     if ((R > 0.0) && (sm > c.Wmax)) {
+        SPL_SITE();
         // log(Kb) with Kb = exp(lkb_arg) (:1326, :1470): the round trip returns lkb_arg up to the
         // rounding of Kb, an ABSOLUTE 1e-16, i.e. relative 1e-16/|lkb_arg|.  Above 1e-7 that is
         // < 1e-9 and the argument itself is used (one log, and the exp when Kb was not needed for
@@ -870,7 +903,10 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     // :1511-1547 transmittance after upslope inflow (no vertical-drainage correction here);
     // identical to the first evaluation whenever the inflow left sm unchanged
     double Acs2 = Acs_out, T_uns2 = T_uns1;
-    if (sm != sm1) T_uns2 = transmittance_uns(c, Ksat_visc, sm, Acs2);
+    if (sm != sm1) {
+        SPL_SITE();
+        T_uns2 = transmittance_uns(c, Ksat_visc, sm, Acs2);
+    }
     const double T2 = (Ksat_visc * 24.0 * (Acs2 * c.inv_Ai) + T_uns2) * hyd_grad_out;
 
     // :1552-1567

@@ -5,6 +5,8 @@
 // contiguous bytes per series per day; the per-day table is read through scalar loads (uniform
 // index).  Lanes past ncell stay alive (clamped index, masked stores) so wave-level votes and
 // reductions always see full waves.
+#include <cstdio>
+
 #include "splash_kernels.hpp"
 
 #include "splash_device.hpp"
@@ -323,6 +325,10 @@ template <bool MONTHLY, bool DIAG>
 __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a)
 {
     lds_tables_init();
+#ifdef SPL_SITES
+    if (threadIdx.x == 0) s_site_on = 1;
+    __syncthreads();
+#endif
     __shared__ double red[DIAG ? 4 * SPLASH_NDIAG_K : 1];
     size_t cell = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool valid = cell < a.ncell;
@@ -799,8 +805,24 @@ hipError_t launch_spin_up_mod(const SpinArgs& a, double* const* series_dev, size
     return hipGetLastError();
 }
 
+#ifdef SPL_SITES
+static void site_dump()
+{
+    static unsigned long long h[2048][2];
+    if (hipDeviceSynchronize() != hipSuccess) return;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(splash::g_site_hits), sizeof h) != hipSuccess) return;
+    std::fprintf(stderr, "SITE ---- cumulative\n");
+    for (int i = 0; i < 2048; i++)
+        if (h[i][0])
+            std::fprintf(stderr, "SITE splash_device.hpp:%d lanes %llu waves %llu\n", i, h[i][0], h[i][1]);
+}
+#endif
+
 hipError_t launch_run_all(const RunArgs& a, hipStream_t s)
 {
+#ifdef SPL_SITES
+    struct Dump { ~Dump() { site_dump(); } } dump_after_launch;
+#endif
     if (a.ncell == 0 || a.nt == 0) return hipSuccess;
     dim3 g(nblk(a.ncell, kBlock)), b(kBlock);
     const bool diag = a.diag_part != nullptr;
