@@ -700,3 +700,43 @@ def test_config4_cru_shaped_land_mask_with_grid_totals(api, oracle):
     if (ok == land).all():
         for k in ("aet", "ro", "bflow"):
             assert np.allclose(g["diag"][k], np.nansum(o[k], axis=1), rtol=1e-9)
+
+
+# ---------------------------------------------------------------- error behaviour of the boundary
+def test_boundary_rejects_bad_arguments(api, oracle, bourne):
+    """errors are codes + messages (never a crash, never a silent NaN grid): too-short series
+    (R/splash.point.R:141-144 needs 365 days), malformed Au, mismatched time axis, bad leading
+    dimensions and NULL pointers at the device-level entry points"""
+    import ctypes as C
+    import torch
+    b, s = bourne, bourne["site"]
+    with pytest.raises(api.SplashError, match="365"):
+        api.splash_point(b["sw_in"][:200], b["Ta"][:200], b["P"][:200], s["latitude"], s["elev_m"], 0.0,
+                         0.0, b["soil"], 0.0, 250.0, time_index=b["dates"][:200])
+    with pytest.raises(api.SplashError, match="1 or 3"):
+        api.splash_point(b["sw_in"], b["Ta"], b["P"], s["latitude"], s["elev_m"], 0.0, 0.0, b["soil"],
+                         [1.0, 2.0], 250.0, time_index=b["dates"])
+    with pytest.raises(ValueError, match="time_index"):
+        api.splash_point(b["sw_in"], b["Ta"], b["P"], s["latitude"], s["elev_m"], 0.0, 0.0, b["soil"],
+                         0.0, 250.0, time_index=b["dates"][:-3])
+    d = _synth(oracle, 4, 16, 365, 1)
+    st = d["st"]
+    with pytest.raises(api.SplashError, match="365"):
+        api.splash_grid(d["sw"][:100], d["tc"][:100], d["pn"][:100], st["elev"], st["soil"], st["lat"],
+                        st["slop"], st["asp"], st["au"], st["resolution"], time_index=d["dates"][:100])
+    lib = api.lib
+    err = C.create_string_buffer(256)
+    assert lib.splash_grid_run(None, None, None, err, 256) < 0 and b"NULL" in err.value
+    # device-level entry points: leading dimension smaller than ncell, day range outside the calendar
+    cal = api.Calendar.from_dates(d["dates"])
+    n = 64
+    f64 = dict(dtype=torch.float64, device="cuda")
+    tc = torch.zeros(365, n, **f64)
+    par, Tt, state = torch.zeros(api.NPAR, n, **f64), torch.zeros(n, **f64), torch.zeros(api.NSTATE, n, **f64)
+    with pytest.raises(api.SplashError, match="leading dimension"):
+        api.dev_snow_threshold(n, 365, tc, n - 1, par, n, Tt)
+    outs = {k: torch.zeros(365, n, **f64) for k in ("wn",)}
+    with pytest.raises(api.SplashError, match="day range"):
+        api.dev_run_all(cal, 300, 100, n, tc, tc, tc, n, Tt, par, n, state, n, outs, n)
+    assert b"day range" in lib.splash_hip_last_error()
+    cal.close()
