@@ -214,6 +214,9 @@ extern "C" int splash_calendar_orbit(const splash_calendar* cal, double* dr, dou
 }
 
 // ------------------------------------------------------------------ device-resident stages
+// the kernels address a launch's cells with 32-bit byte offsets from uniform row bases
+static const size_t kMaxCellsPerLaunch = (1ull << 29) - 1;
+
 #define REQ(cond, msg)                                                   \
     do {                                                                 \
         if (!(cond)) return fail(SPLASH_EINVAL, nullptr, 0, "%s", msg);  \
@@ -274,7 +277,7 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
     REQ(cal && sw_in && tc && pn && Tt && cellpar && state && work, "spin_up: NULL argument");
     REQ(cal->nt >= 365, "spin_up: needs at least 365 days (R/splash.point.R:141-144)");
     REQ(ldf >= ncell && ldp >= ncell && lds >= ncell, "spin_up: leading dimension < ncell");
-    REQ(ncell < 0xFFFFFFFFull, "spin_up: more than 2^32-1 cells in one call");
+    REQ(ncell <= kMaxCellsPerLaunch, "spin_up: more than 2^29-1 cells in one call (32-bit lane byte offsets)");
     if (int rc = need_device(nullptr, 0)) return rc;
     if (ncell == 0) return SPLASH_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -332,6 +335,7 @@ extern "C" int splash_dev_run_all(const splash_calendar* cal, int t0, int nt, si
     REQ(ldf >= ncell && ldp >= ncell && lds >= ncell && out->ldo >= ncell,
         "run_all: leading dimension < ncell");
     REQ(!out->diag || out->diag_work, "run_all: diag requested without diag_work");
+    REQ(ncell <= kMaxCellsPerLaunch, "run_all: more than 2^29-1 cells in one call (32-bit lane byte offsets)");
     if (int rc = need_device(nullptr, 0)) return rc;
     if (nt == 0 || ncell == 0) return SPLASH_OK;
     RunArgs a{};
@@ -546,6 +550,7 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
     if (opt && opt->max_cells_per_launch) nb_max = std::min(nb_max, opt->max_cells_per_launch);
     if (nb_max == 0) return fail(SPLASH_ENOMEM, err, errlen, "grid_run: not enough device memory");
     nb_max = std::min(nb_max, nv);
+    nb_max = std::min(nb_max, kMaxCellsPerLaunch);
     if (nb_max > 256) nb_max -= nb_max % 256;
 
     DevBuf d_force, d_out, d_par, d_state, d_stat, d_tt, d_pass, d_diag, d_dwork, d_swork;

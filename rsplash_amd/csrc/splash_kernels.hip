@@ -116,30 +116,60 @@ __global__ __launch_bounds__(kBlock) void k_snow_threshold(size_t ncell, int nt,
 }
 
 // ================================================================ forcing access ==============
+// One lane's view of the forcing rasters.  The row base (array + t*ld) is uniform and stays in
+// scalar registers; the lane adds a 32-bit byte offset, so a load is one global_load with an SGPR
+// base and no 64-bit vector address arithmetic (callers keep ncell*8 below 4 GiB per launch).
 struct Forcing {
     const double *sw, *tc, *pn, *snowfall; // snowfall != NULL => explicit rain/snow series
     size_t ld;
     double Tt, snow_term;
-    size_t cell;
+    unsigned off; // cell * sizeof(double)
+    static __device__ __forceinline__ double at(const double* row, unsigned off_bytes)
+    {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(row) + off_bytes);
+    }
     __device__ __forceinline__ void raw(int t, double& a, double& b, double& c_) const
     {
-        size_t k = (size_t)t * ld + cell;
-        a = sw[k];
-        b = tc[k];
-        c_ = pn[k];
+        const size_t r = (size_t)t * ld;
+        a = at(sw + r, off);
+        b = at(tc + r, off);
+        c_ = at(pn + r, off);
     }
     __device__ __forceinline__ void split(const DayRec& d, int t, double tcv, double pnv,
                                           double& rain, double& snowf) const
     {
         if (snowfall) {
             rain = pnv;
-            snowf = snowfall[(size_t)t * ld + cell];
+            snowf = at(snowfall + (size_t)t * ld, off);
         } else {
             DayConst dc{d.dr, d.sd, d.cd, d.ttm_s, d.trm14};
             rain_snow_split(dc, tcv, pnv, Tt, snow_term, rain, snowf);
         }
     }
 };
+
+// The per-day table is read-only for the whole launch: going through the constant address space
+// lets the (uniform) loads be scalar loads into SGPRs instead of 64-lane vector loads followed by
+// v_readfirstlane.
+typedef const __attribute__((address_space(4))) DayRec* DayTable;
+__device__ __forceinline__ DayTable day_table(const DayRec* p)
+{
+    return (DayTable)(unsigned long long)p;
+}
+__device__ __forceinline__ DayRec day_rec(DayTable tab, int t)
+{
+    DayRec d;
+    d.dr = tab[t].dr;
+    d.sd = tab[t].sd;
+    d.cd = tab[t].cd;
+    d.ttm_s = tab[t].ttm_s;
+    d.trm14 = tab[t].trm14;
+    d.month_id = tab[t].month_id;
+    d.mdays = tab[t].mdays;
+    d.flags = tab[t].flags;
+    d.doy = tab[t].doy;
+    return d;
+}
 
 __device__ __forceinline__ DayConst day_const(const DayRec& d)
 {
@@ -168,8 +198,9 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
 
     Forcing f{a.sw, a.tc, a.pn, nullptr, a.ldf, a.Tt[ci],
               a.par[P_ELV * a.ldp + ci] * 0.0004596581 + fabs(a.par[P_LAT * a.ldp + ci]) * 0.0110592101,
-              ci};
-    const DayRec d0 = a.days[0];
+              (unsigned)(ci * sizeof(double))};
+    const DayTable days = day_table(a.days);
+    const DayRec d0 = day_rec(days, 0);
     double sw0, tc0, pn0, rain0, snf0;
     f.raw(0, sw0, tc0, pn0);
     f.split(d0, 0, tc0, pn0, rain0, snf0);
@@ -204,7 +235,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         for (int i = 1; i < a.n; i++) {
             double swn = swv, tcn = tcv, pnn = pnv;
             if (i + 1 < a.n) f.raw(i + 1, swn, tcn, pnn);
-            const DayRec d = a.days[i];
+            const DayRec d = day_rec(days, i);
             double rain, snf;
             f.split(d, i, tcv, pnv, rain, snf);
             day_step(c, day_const(d), swv, tcv, rain, snf, cur, o);
@@ -273,7 +304,7 @@ __global__ __launch_bounds__(64) void k_spin_up_mod(SpinArgs a, double* const* s
     lds_tables_init();
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const size_t ci = 0;
-    Forcing f{a.sw, a.tc, a.pn, snowfall, a.ldf, 0.0, 0.0, ci};
+    Forcing f{a.sw, a.tc, a.pn, snowfall, a.ldf, 0.0, 0.0, (unsigned)(ci * sizeof(double))};
     CellConst c;
     cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci]);
     State w{c.RES, 0.0, 0.0, 0.0, 0.0}; // wn_vec(n,RES), others 0: read at [n-1] on day 1
@@ -321,7 +352,10 @@ __device__ __forceinline__ double wave_sum(double v)
 
 // SPLASH::run_all, src/SPLASH.cpp:1833-1916 (+ sm_lim and monthly aggregation of
 // R/splash.point.R:197-214, + monthly grid totals for the water-balance diagnostics).
-template <bool MONTHLY, bool DIAG>
+// outputs in order: wn, ro, pet, aet, snow, cond, bflow, netr, sm_lim
+constexpr unsigned kOutMaskFive = 0x1Fu;
+
+template <bool MONTHLY, bool DIAG, unsigned OUTMASK>
 __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a)
 {
     lds_tables_init();
@@ -335,13 +369,23 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
     const size_t ci = valid ? cell : a.ncell - 1;
     Forcing f{a.sw, a.tc, a.pn, a.snowfall, a.ldf, a.Tt ? a.Tt[ci] : 0.0,
               a.par[P_ELV * a.ldp + ci] * 0.0004596581 + fabs(a.par[P_LAT * a.ldp + ci]) * 0.0110592101,
-              ci};
+              (unsigned)(ci * sizeof(double))};
+    const DayTable days = day_table(a.days);
     CellConst c;
     cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci]);
     const double wmax_r = a.par[P_WMAXR * a.ldp + ci];
     const double lim_den = wmax_r - c.RES;
     State st{a.state[ci], a.state[a.lds + ci], a.state[2 * a.lds + ci], a.state[3 * a.lds + ci],
              a.state[4 * a.lds + ci]};
+
+    // which outputs are requested: known at compile time for the two common sets (OUTMASK != 0),
+    // otherwise tested at run time (nine uniform booleans that the compiler keeps as 64-bit lane
+    // masks, most of them spilled: ~4 issue slots per output and day)
+    unsigned omask = OUTMASK;
+    if (OUTMASK == 0) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) omask |= (a.out[q] != nullptr ? 1u : 0u) << q;
+    }
 
     double acc[9]; // monthly accumulators in output order
     double dg[4];  // monthly flux totals: precip, aet, ro, bflow
@@ -353,7 +397,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
     double swv, tcv, pnv;
     f.raw(0, swv, tcv, pnv);
     for (int t = 0; t < a.nt; t++) {
-        const DayRec d = a.days[t];
+        const DayRec d = day_rec(days, t);
         double swn = swv, tcn = tcv, pnn = pnv;
         if (t + 1 < a.nt) f.raw(t + 1, swn, tcn, pnn); // next day's forcing in flight
         double rain, snf;
@@ -362,7 +406,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
         day_step(c, day_const(d), swv, tcv, rain, snf, st, o);
 
         double lim = 0.0;
-        if (a.out[8]) { // R/splash.point.R:197-200 (only when sm_lim is requested)
+        if (omask & (1u << 8)) { // R/splash.point.R:197-200 (only when sm_lim is requested)
             lim = (st.wn - c.RES) / lim_den;
             if (lim < 0) lim = 0.0;
             if (lim > 1) lim = 1.0;
@@ -370,14 +414,15 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
         const double v[9] = {st.wn, o.ro, o.pet, o.aet, st.snow, o.cond, o.bflow, o.netr, lim};
 
         if (!MONTHLY) {
-            size_t k = (size_t)t * a.ldo + ci;
+            // lanes past the last cell carry a copy of the last cell and store the same values to
+            // the same addresses, so the stores need no per-lane predicate (only the uniform test
+            // for a requested output)
+            const size_t row = (size_t)t * a.ldo;
 #pragma unroll
             for (int q = 0; q < 9; q++)
-#if defined(SPL_ABLATE) && SPL_ABLATE == 6
-                if (a.out[q] && valid && v[q] == -12345.678) __builtin_nontemporal_store(v[q], &a.out[q][k]);
-#else
-                if (a.out[q] && valid) __builtin_nontemporal_store(v[q], &a.out[q][k]);
-#endif
+                if (omask & (1u << q))
+                    __builtin_nontemporal_store(
+                        v[q], reinterpret_cast<double*>(reinterpret_cast<char*>(a.out[q] + row) + f.off));
         } else {
 #pragma unroll
             for (int q = 0; q < 9; q++) acc[q] += v[q];
@@ -399,7 +444,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
                 size_t k = (size_t)m * a.ldo + ci;
 #pragma unroll
                 for (int q = 0; q < 9; q++) {
-                    if (a.out[q] && valid) {
+                    if ((omask & (1u << q)) && valid) {
                         double x = (q == 0 || q == 4 || q == 8) ? acc[q] * inv_n : acc[q];
                         if (partial_head) x += a.out[q][k];
                         a.out[q][k] = x;
@@ -447,7 +492,7 @@ __global__ __launch_bounds__(64) void k_run_all_mod(RunArgs a)
     lds_tables_init();
     size_t cell = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (cell >= a.ncell) return;
-    Forcing f{a.sw, a.tc, a.pn, a.snowfall, a.ldf, 0.0, 0.0, cell};
+    Forcing f{a.sw, a.tc, a.pn, a.snowfall, a.ldf, 0.0, 0.0, (unsigned)(cell * sizeof(double))};
     CellConst c;
     cell_setup(c, a.par, a.ldp, cell, a.par[P_CELLOUT * a.ldp + cell]);
     State st{a.state[cell], a.state[a.lds + cell], a.state[2 * a.lds + cell],
@@ -826,16 +871,28 @@ hipError_t launch_run_all(const RunArgs& a, hipStream_t s)
     if (a.ncell == 0 || a.nt == 0) return hipSuccess;
     dim3 g(nblk(a.ncell, kBlock)), b(kBlock);
     const bool diag = a.diag_part != nullptr;
+    unsigned mask = 0;
+    for (int q = 0; q < 9; q++) mask |= (a.out[q] != nullptr ? 1u : 0u) << q;
     if (a.monthly) {
         if (diag)
-            hipLaunchKernelGGL((k_run_all<true, true>), g, b, 0, s, a);
+            hipLaunchKernelGGL((k_run_all<true, true, 0>), g, b, 0, s, a);
         else
-            hipLaunchKernelGGL((k_run_all<true, false>), g, b, 0, s, a);
+            hipLaunchKernelGGL((k_run_all<true, false, 0>), g, b, 0, s, a);
+    } else if (mask == kOutMaskFive) { // wn, ro, pet, aet, snow: the BASELINE output set
+        if (diag)
+            hipLaunchKernelGGL((k_run_all<false, true, kOutMaskFive>), g, b, 0, s, a);
+        else
+            hipLaunchKernelGGL((k_run_all<false, false, kOutMaskFive>), g, b, 0, s, a);
+    } else if (mask == 0x1FFu) { // all nine (splash.grid)
+        if (diag)
+            hipLaunchKernelGGL((k_run_all<false, true, 0x1FFu>), g, b, 0, s, a);
+        else
+            hipLaunchKernelGGL((k_run_all<false, false, 0x1FFu>), g, b, 0, s, a);
     } else {
         if (diag)
-            hipLaunchKernelGGL((k_run_all<false, true>), g, b, 0, s, a);
+            hipLaunchKernelGGL((k_run_all<false, true, 0>), g, b, 0, s, a);
         else
-            hipLaunchKernelGGL((k_run_all<false, false>), g, b, 0, s, a);
+            hipLaunchKernelGGL((k_run_all<false, false, 0>), g, b, 0, s, a);
     }
     return hipGetLastError();
 }
