@@ -165,7 +165,7 @@ extern "C" int splash_calendar_create(int nt, const int* doy, const int* year, c
         orbit_day(doy[t], year[t], d.dr, d.sd, d.cd);
         const int m = month[t];
         d.ttm_s = sind((m + 2) / 1.91);                      // R/splash.point.R:549
-        d.trm14 = 1.4 * (13.3 * (0.55 + sind(m + 4)) * 0.6); // :550, :553
+        d.inv_trm14 = 1.0 / (1.4 * (13.3 * (0.55 + sind(m + 4)) * 0.6)); // :550, :553
         d.month_id = mid;
         d.doy = doy[t];
         d.flags = 0;
@@ -779,7 +779,7 @@ extern "C" int splash_mod_spin_up(double lat, double elv, int n, int y, const do
         DayRec& d = days[i];
         orbit_day(i + 1, y, d.dr, d.sd, d.cd); // quick_run((i+1), y, ...) :1658
         d.ttm_s = 0.0;
-        d.trm14 = 1.0;
+        d.inv_trm14 = 1.0;
         d.month_id = 0;
         d.mdays = n;
         d.flags = (i == n - 1);
@@ -844,7 +844,7 @@ extern "C" int splash_mod_run_all(double lat, double elv, int nt, const int* doy
         DayRec& d = days[i];
         orbit_day(doys[i], yrs[i], d.dr, d.sd, d.cd);
         d.ttm_s = 0.0;
-        d.trm14 = 1.0;
+        d.inv_trm14 = 1.0;
         d.month_id = 0;
         d.mdays = nt;
         d.flags = (i == nt - 1);

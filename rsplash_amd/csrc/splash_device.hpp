@@ -79,7 +79,7 @@ struct DayConst { // per-calendar-day terms (host table): orbit, src/SOLAR.cpp:9
                   // month-dependent factors of frain_func, R/splash.point.R:549-550
     double dr, sd, cd;  // distance factor, sin(delta), cos(delta)
     double ttm_s;       // dsin((m+2)/1.91)
-    double trm14;       // 1.4 * (13.3*(0.55+dsin(m+4))*0.6)
+    double inv_trm14;   // 1 / (1.4 * (13.3*(0.55+dsin(m+4))*0.6))
 };
 
 struct DayOut {
@@ -949,7 +949,7 @@ __device__ __forceinline__ void rain_snow_split(const DayConst& d, double tc, do
     double f_rain = 1.0;
     if (x <= 0.0) {
         double Ttm = Tt + (Tt * d.ttm_s);
-        double q = ((tc - Ttm) / d.trm14);
+        double q = ((tc - Ttm) * d.inv_trm14); // the divisor is a per-day constant: reciprocal from the host table
         double q2 = q * q, q3 = q2 * q;
         double fr;
         if (tc <= Ttm) {

@@ -142,7 +142,7 @@ struct Forcing {
             rain = pnv;
             snowf = at(snowfall + (size_t)t * ld, off);
         } else {
-            DayConst dc{d.dr, d.sd, d.cd, d.ttm_s, d.trm14};
+            DayConst dc{d.dr, d.sd, d.cd, d.ttm_s, d.inv_trm14};
             rain_snow_split(dc, tcv, pnv, Tt, snow_term, rain, snowf);
         }
     }
@@ -163,7 +163,7 @@ __device__ __forceinline__ DayRec day_rec(DayTable tab, int t)
     d.sd = tab[t].sd;
     d.cd = tab[t].cd;
     d.ttm_s = tab[t].ttm_s;
-    d.trm14 = tab[t].trm14;
+    d.inv_trm14 = tab[t].inv_trm14;
     d.month_id = tab[t].month_id;
     d.mdays = tab[t].mdays;
     d.flags = tab[t].flags;
@@ -173,7 +173,7 @@ __device__ __forceinline__ DayRec day_rec(DayTable tab, int t)
 
 __device__ __forceinline__ DayConst day_const(const DayRec& d)
 {
-    return DayConst{d.dr, d.sd, d.cd, d.ttm_s, d.trm14};
+    return DayConst{d.dr, d.sd, d.cd, d.ttm_s, d.inv_trm14};
 }
 
 // ================================================================ K4 spin-up ===================

@@ -19,7 +19,7 @@ enum {
 // one calendar day of the shared per-day table (uniform index => scalar loads)
 struct DayRec {
     double dr, sd, cd;   // orbit: distance factor, sin/cos of declination (src/SOLAR.cpp:114-124)
-    double ttm_s, trm14; // month factors of frain_func (R/splash.point.R:549-550)
+    double ttm_s, inv_trm14; // month factors of frain_func (R/splash.point.R:549-550): sin term of Ttm, 1/(1.4 Trm)
     int month_id;        // running month number since the first day of the calendar
     int mdays;           // days of that month present in the calendar
     int flags;           // bit0: last calendar day of its month

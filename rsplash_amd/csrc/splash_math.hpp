@@ -170,7 +170,7 @@ SPL_HD double flog(double x)
     const double lo_ = fma(kd, ln2_lo, r2 * p);
     double res = (hi_ + r) + lo_;
     res = (x < HUGE_VAL) ? res : x;                 // +inf (NaN falls through to the next line)
-    res = (x > 0.0) ? res : ((x == 0.0) ? -HUGE_VAL : (x - x) / (x - x) + x); // 0 -> -inf, <0/NaN -> NaN
+    res = (x > 0.0) ? res : ((x == 0.0) ? -HUGE_VAL : __builtin_nan("")); // 0 -> -inf, <0/NaN -> NaN
     return res;
 }
 
