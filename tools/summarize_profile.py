@@ -75,7 +75,7 @@ def main():
            "| kernel | calls | avg ms | % |", "|---|---|---|---|"]
     for r in stats[:7]:
         md.append(f"| `{r['Name'][:60]}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | {float(r['Percentage']):.2f} |")
-    ra = next(r for r in stats if "k_run_all<false, true>" in r["Name"])
+    ra = next(r for r in stats if "k_run_all<false, true" in r["Name"])
     avg_ms = float(ra["AverageNs"]) / 1e6
     md += ["", f"Dominant kernel of the timed region: `k_run_all<false,true>` — {avg_ms:.2f} ms per launch of "
            f"{rows_blk}x{W} cells x {nt} days = {cells_launch*nt:.3e} cell-days "
