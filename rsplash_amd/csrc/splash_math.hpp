@@ -3,9 +3,9 @@
 // The day step needs ~10 pow() per cell-day in the reference's formulation; the general-purpose
 // library pow costs ~230 VALU instructions on gfx950 because it carries a double-double
 // logarithm to stay below 1 ulp for every (x, y).  The water-balance terms only need
-// |y*log x| <~ 40 at 1e-14 relative, so the pows are rebuilt from one short log (fdlibm-style:
-// 7-term series in s = f/(2+f), < 1 ulp) and one short exp (Cody-Waite reduction by ln2 and a
-// degree-13 series, < 1 ulp), and logs are shared between powers of the same base.
+// |y*log x| <~ 40 at 1e-14 relative, so the pows are rebuilt from one short log (table driven:
+// 128 x (1/c, log c), series to r^8, <~ 2 ulp) and one short exp (Cody-Waite reduction by ln2 and
+// a degree-13 series, < 1 ulp), and logs are shared between powers of the same base.
 //
 // The file is plain C++ (frexp/ldexp/rint/fma/sqrt map to single VALU instructions on the
 // device), so tests/ compile it with g++ too and check it against libm on the host.
