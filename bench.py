@@ -34,8 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_CELL_DAY = 64.0   # 3 forcing reads + 5 output writes, FP64
-HBM_PEAK_GBS = 8000.0
-HBM_COPY_GBS = 6290.0  # measured copy rate, /opt/skills/guides/MI355X_MICROARCH.md           # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_COPY_GBS = 6290.0           # same guide: measured copy rate
 SEED = 20221130
 OUT5 = ("wn", "snow", "ro", "aet", "pet")
 
