@@ -14,6 +14,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "splash_kernels.hpp"
@@ -484,6 +485,26 @@ extern "C" int splash_dev_math_probe(size_t n, const double* x, const double* y,
     return SPLASH_OK;
 }
 
+// first touch of the output arrays by a few host threads (one write per 4 KiB page)
+static void prefault_outputs(double* const* bufs, int nbuf, size_t elems)
+{
+    const size_t step = 4096 / sizeof(double);
+    if (elems < (size_t)(64u << 20) / sizeof(double)) return; // small arrays: not worth threads
+    unsigned nthr = std::thread::hardware_concurrency();
+    nthr = nthr == 0 ? 4 : (nthr > 8 ? 8 : nthr);
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < nthr; w++)
+        pool.emplace_back([=]() {
+            for (int k = 0; k < nbuf; k++) {
+                if (!bufs[k]) continue;
+                const size_t lo = elems / nthr * w, hi = (w + 1 == nthr) ? elems : elems / nthr * (w + 1);
+                volatile double* p = bufs[k];
+                for (size_t i = lo; i < hi; i += step) p[i] = 0.0;
+            }
+        });
+    for (auto& t : pool) t.join();
+}
+
 // ------------------------------------------------------------------ splash.grid / splash.point
 extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
                                const splash_grid_out* out, char* err, size_t errlen)
@@ -629,6 +650,10 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
         dout.diag_work = out->diag ? d_dwork.as<double>() : nullptr;
         rc = splash_dev_run_all(cal, 0, nt, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, &dout, s);
         if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
+        // The kernels of this block are queued; while they run, map the caller's (typically
+        // freshly allocated) output arrays: the first touch of tens of GB is otherwise paid page
+        // by page inside the device-to-host copies.
+        if (dense && b0 == 0) prefault_outputs(out->out, SPLASH_NOUT, (size_t)nt_out * N);
         HIP_TRY(hipStreamSynchronize(s), err, errlen);
 
         for (int k = 0; k < SPLASH_NOUT; k++) {
