@@ -81,6 +81,13 @@ def sa_cru():
 
 
 @pytest.fixture(scope="session")
+def minigrid():
+    """committed whole-pipeline anchor (tools/make_minigrid_golden.py): the oracle's splash.grid
+    outputs on a 64-cell x 730-day synthetic terrain grid, monthly"""
+    return dict(np.load(os.path.join(GOLD, "minigrid_monthly.npz")))
+
+
+@pytest.fixture(scope="session")
 def kat():
     return dict(np.load(os.path.join(GOLD, "ref_evap_kat.npz")))
 

@@ -702,6 +702,34 @@ def test_config4_cru_shaped_land_mask_with_grid_totals(api, oracle):
             assert np.allclose(g["diag"][k], np.nansum(o[k], axis=1), rtol=1e-9)
 
 
+def test_minigrid_against_committed_golden(api, oracle, minigrid):
+    """whole pipeline on device-generated inputs against COMMITTED vectors (no live oracle run in
+    the comparison): 64 cells x 730 days, monthly outputs of all nine series"""
+    import torch
+    g = minigrid
+    H, W, nt, seed = int(g["H"]), int(g["W"]), int(g["nt"]), int(g["seed"])
+    n = H * W
+    dates = np.datetime64("2001-01-01") + np.arange(nt)
+    cal = api.Calendar.from_dates(dates)
+    f64 = dict(dtype=torch.float64, device="cuda")
+    lat, elev, slop, asp, res = (torch.empty(n, **f64) for _ in range(5))
+    soil, au = torch.empty(6, n, **f64), torch.empty(3, n, **f64)
+    api.dev_synth_statics(seed, H, W, 0, n, 1, lat, elev, slop, asp, res, soil, au)
+    sw, tc, pn = (torch.empty(nt, n, **f64) for _ in range(3))
+    api.dev_synth_forcing(seed, cal, 0, nt, 0, n, lat, elev, sw, tc, pn, n)
+    torch.cuda.synchronize()
+    cal.close()
+    h = lambda t: t.cpu().numpy()
+    out = api.splash_grid(h(sw), h(tc), h(pn), h(elev), h(soil), h(lat), h(slop), h(asp), h(au), h(res),
+                          time_index=dates, sim_control=dict(monthly_out=True), want_aux=True)
+    ok = g["well_conditioned"]
+    assert ok.sum() >= 50
+    assert np.array_equal(out["aux"]["passes2"][ok], g["passes2"][ok])
+    for k in ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "sm_lim"):
+        close(out[k][:, ok], g[k][:, ok], "minigrid." + k)
+    close(out["state_end"][:3][:, ok], g["state_end"][:3][:, ok], "minigrid.state_end")
+
+
 # ---------------------------------------------------------------- error behaviour of the boundary
 def test_boundary_rejects_bad_arguments(api, oracle, bourne):
     """errors are codes + messages (never a crash, never a silent NaN grid): too-short series

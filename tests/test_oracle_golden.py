@@ -267,3 +267,19 @@ def test_atneu_point_oracle_sanity(oracle, atneu):
     assert 2 <= aux["passes2"] <= 1000
     assert 0 < res["aet"].mean() < res["pet"].mean() < 10
     assert res["snow"].max() > 10  # alpine valley: a seasonal snow pack builds up
+
+
+def test_minigrid_golden_is_reproduced_by_the_oracle(oracle, minigrid):
+    """guards the oracle (and the synthetic generator) against drift: today's build must reproduce
+    the committed whole-pipeline vectors bit for bit"""
+    g = minigrid
+    H, W, nt, seed = int(g["H"]), int(g["W"]), int(g["nt"]), int(g["seed"])
+    doy, year, month, mid, nm = oracle.calendar(2001, nt)
+    st = oracle.synth_statics(seed, H, W, 0, H * W, 1)
+    sw, tc, pn = oracle.synth_forcing(seed, H, W, 0, H * W, 0, doy, st["lat"], st["elev"])
+    assert np.array_equal(g["input_checksum"], [sw.sum(), tc.sum(), pn.sum(), st["soil"].sum()])
+    res, aux = oracle.grid(doy, year, month, mid, nm, sw, tc, pn, st["lat"], st["elev"], st["slop"],
+                           st["asp"], st["soil"], st["au"], st["resolution"], monthly_out=True)
+    for k, v in res.items():
+        assert np.array_equal(v, g[k]), k
+    assert np.array_equal(aux["passes2"], g["passes2"]) and np.array_equal(aux["AI"], g["AI"])
