@@ -171,6 +171,11 @@ class Oracle:
         return ({k: getattr(s, k) for k, _ in Smr._fields_},
                 {k: getattr(e, k) for k, _ in Etr._fields_})
 
+    def fragile_events(self, reset=True):
+        """noise-denominator events (DESIGN "Conditioning") counted on this thread since the last reset"""
+        self.lib.orc_fragile_events.restype = C.c_long
+        return int(self.lib.orc_fragile_events(1 if reset else 0))
+
     def spin_up(self, lat, elv, n, y, sw_in, tair, pn, slop, asp, snowfall, soil_info):
         a = [_d(x) for x in (sw_in, tair, pn, snowfall, soil_info)]
         outs = {k: np.empty(n) for k in ("sm", "snow", "qin", "tdrain", "ro", "snwage", "pet")}
