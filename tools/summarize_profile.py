@@ -103,7 +103,7 @@ def main():
                f"SQ_WAIT_ANY {sq['SQ_WAIT_ANY']/sq['SQ_WAVE_CYCLES']:.2f}, "
                f"SQ_WAIT_INST_ANY {sq['SQ_WAIT_INST_ANY']/sq['SQ_WAVE_CYCLES']:.2f} of wave cycles",
                "* reading: the launch is FP64-VALU-issue bound (pointwise transcendental stream), "
-               "as SURVEY.md 8(d) predicted; HBM is at a few percent of its rate"]
+               f"as SURVEY.md 8(d) predicted; HBM runs at {64*cells_launch*nt/avg_ms/1e6/8000:.0%} of its peak rate"]
     open(os.path.join(out, f"{tag}_summary.md"), "w").write("\n".join(md) + "\n")
     valu = {}
     if sq:
