@@ -831,3 +831,33 @@ def test_boundary_rejects_bad_arguments(api, oracle, bourne):
         api.dev_run_all(cal, 300, 100, n, tc, tc, tc, n, Tt, par, n, state, n, outs, n)
     assert b"day range" in lib.splash_hip_last_error()
     cal.close()
+
+
+def test_bench_line_keeps_the_contract():
+    """bench.py prints ONE JSON line with the keys the driver and the judge read"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rows", "64", "--cols", "64",
+                        "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "cell-days/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0
+    assert d["value"] > 0 and abs(d["value"] - 64 * 64 * 365 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
