@@ -1,30 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- cell-days/s of the gridded SPLASH loop on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W] [--config 1|2|3|4]
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): a synthetic
-4096 x 4096 grid with slope/aspect/upslope area, 365 daily steps (calendar 2001), FP64.  With
-N > 1 every rank owns a 4096-row block of a (4096*N) x 4096 grid (weak scaling; cells are
-independent, so the only exchange is one all-reduce of the monthly water-balance totals).
+`--gpus N` with N > 1 launches itself: the parent (which never touches a GPU) starts N fresh rank
+processes -- one per device, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on 127.0.0.1 --
+and prints rank 0's JSON line.  Under `python -m torch.distributed.run ... bench.py --gpus N` the
+ranks already exist and nothing is spawned.
 
-One "step" = one pass of the hot path over the rank's whole block with all inputs resident in
-HBM: K2 (snowfall threshold pre-pass over tc) + K5 (SPLASH::run_all: rain/snow split, SOLAR, EVAP,
-infiltration, runoff, lateral flow, soil-water update for every cell and day, daily outputs wn,
-snow, ro, aet, pet written to HBM) + the diagnostics totals.  Setup outside the timed region:
-on-device input generation, K1 soil_hydro and K4 the two spin-ups (timed and reported separately
-as spinup_s).  The grid is processed in row blocks so that forcing (147 GB) + one block of
-outputs fit in 288 GB.
+Workloads (BASELINE.json configs; --config selects, default 2 = the configuration the metric is
+quoted on):
+  1  256 x 256 flat-terrain grid, 365 days, 1 GPU
+  2  4096 x 4096 grid with slope/aspect/upslope area, 365 days; with N ranks every rank owns a
+     4096-row block of a (4096*N)-row grid (weak scaling)
+  3  30 years of daily forcing with spin-up, one rank's share (512 x 4096 cells = 1/8 of 4096^2)
+     streamed one calendar year at a time through two forcing buffers (a 30-year raster cannot be
+     resident: 11.8 TB for the whole grid), state carried in HBM
+  4  0.5 degree global grid (360 x 720), ~26 % land by a hash mask (layout of data/SA_cru.RData:
+     NA ocean cells), 30 years, monthly water-balance totals per basin, summed over ranks with ONE
+     all-reduce of the exact integer limbs
+
+One "step" = one pass of the hot path over the rank's cells with the inputs resident in HBM:
+K2 (snowfall threshold pre-pass over tc) + K5 (SPLASH::run_all: rain/snow split, SOLAR, EVAP,
+infiltration, runoff, lateral flow, soil-water update for every cell and day, daily wn, snow, ro,
+aet, pet written to HBM) + K7 (monthly water-balance totals).  Setup outside the timed region:
+on-device input generation, K1 soil_hydro and K4 the two spin-ups (timed separately:
+`spinup.seconds`, and folded into `value_inclusive`).  Configs 3/4 also time the per-year input
+generation, which stands in for the stream of forcing a real 30-year run would have to be fed.
 
 The JSON line carries `roofline` (algorithmic 64 B per cell-day over the measured duration of the
 run_all kernel, against 8 TB/s) and `cpu_baseline` (the plain-C port of the reference's loop in
-oracle/, timed on this box's host cores on a bounded sample of the same workload, and used to
-check the GPU results on that sample).
+oracle/, timed on this box's host cores on a bounded sample of the same workload, which is also
+used to check the GPU results on that sample: `parity_sample`).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -58,32 +70,85 @@ def host_cores():
     return n
 
 
-def main():
+def cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rows", type=int, default=4096, help="grid rows per GPU")
-    ap.add_argument("--cols", type=int, default=4096)
-    ap.add_argument("--days", type=int, default=365)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4))
+    ap.add_argument("--rows", type=int, default=None, help="grid rows per GPU")
+    ap.add_argument("--cols", type=int, default=None)
+    ap.add_argument("--days", type=int, default=None)
+    ap.add_argument("--years", type=int, default=30, help="configs 3/4")
     ap.add_argument("--block-rows", type=int, default=512, help="rows per run_all launch")
-    ap.add_argument("--flat", action="store_true", help="flat-terrain config (configs[1] style)")
+    ap.add_argument("--flat", action="store_true", help="flat terrain (implied by --config 1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
 
+# ------------------------------------------------------------------------------------ launcher
+def launch_ranks(n, argv):
+    """Start n rank processes of this script (fresh interpreters: the parent has not touched the
+    GPU and never will), relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    if any(rcs) or len(lines) != 1:
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}; rank 0 printed {len(lines)} JSON line(s)\n")
+        sys.exit(1)
+    print(lines[0])
+
+
+# ------------------------------------------------------------------------------------ one rank
+def main():
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    if os.environ.get("SPLASH_BENCH_DRYRUN") == "1":
+        # launcher rehearsal for the CPU test suite: rendezvous + one collective, no GPU, no compute
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "sum_of_ranks": float(t.item())}))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # rehearsal knobs (not used by the driver): run N ranks on ONE GPU with gloo to exercise the
-    # multi-rank control flow, e.g.  SPLASH_BENCH_BACKEND=gloo SPLASH_BENCH_ONE_GPU=1 torchrun ...
+    # rehearsal knobs (not used by the driver): N ranks on ONE GPU with gloo to exercise the
+    # multi-rank control flow:  SPLASH_BENCH_BACKEND=gloo SPLASH_BENCH_ONE_GPU=1 python bench.py --gpus 2
     backend = os.environ.get("SPLASH_BENCH_BACKEND", "nccl")
     if os.environ.get("SPLASH_BENCH_ONE_GPU") == "1":
         local = 0
@@ -102,9 +167,95 @@ def main():
         dist.barrier()               # other ranks load the library only after rank 0 has built it
     from rsplash_amd import api
 
-    H, W, nt = args.rows, args.cols, args.days
+    ctx = dict(args=args, world=world, rank=rank, dev=dev, backend=backend, api=api, torch=torch, dist=dist)
+    line = run_resident(ctx) if args.config in (1, 2) else run_streamed(ctx)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def allreduce_(ctx, t, op=None):
+    """in-place all-reduce of a device tensor (RCCL), or through the host with the gloo rehearsal"""
+    dist, torch = ctx["dist"], ctx["torch"]
+    if ctx["world"] == 1:
+        return t
+    op = op or dist.ReduceOp.SUM
+    if ctx["backend"] == "nccl":
+        dist.all_reduce(t, op=op)
+    else:
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    return t
+
+
+def timed_region(ctx, step, steps, warmup):
+    """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks"""
+    torch, dist, world = ctx["torch"], ctx["dist"], ctx["world"]
+    for _ in range(warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=ctx["dev"])
+        allreduce_(ctx, tmax, dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return dt
+
+
+def base_line(ctx, value, steps, warmup, dt, workload, extra_cfg):
+    try:
+        metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        metric = "cell-days/sec on 4096x4096x365d synthetic grid; max |dwn| vs reference"
+    world = ctx["world"]
+    cfg = {"workload": workload, "baseline_config": ctx["args"].config, "parallelism": f"row-block x{world}"}
+    cfg.update(extra_cfg)
+    return {"metric": metric, "value": value, "unit": "cell-days/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg}
+
+
+def roofline(avg_launch_s, units_per_launch, key, kernel):
+    achieved = ALG_BYTES_PER_CELL_DAY * units_per_launch / avg_launch_s / 1e9
+    traffic = valu_busy = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            valu_busy = tj.get(key, {}).get("valu_busy_frac")
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS, "kernel": kernel,
+            "avg_launch_ms": avg_launch_s * 1e3, "units_per_launch": units_per_launch,
+            "alg_bytes_per_unit": ALG_BYTES_PER_CELL_DAY, "valu_busy_frac": valu_busy,
+            "note": "the launch is FP64-VALU-issue bound, not HBM bound (vector instructions per "
+                    "wavefront-day and valu_busy_frac from the PMC pass in profiles/; DESIGN.md)"}
+
+
+# ------------------------------------------------------------------------------------ configs 1, 2
+def run_resident(ctx):
+    args, world, rank, dev, api, torch = (ctx[k] for k in ("args", "world", "rank", "dev", "api", "torch"))
+    flat = args.flat or args.config == 1
+    H = args.rows or (256 if args.config == 1 else 4096)
+    W = args.cols or (256 if args.config == 1 else 4096)
+    nt = args.days or 365
+    steps = args.steps if args.steps is not None else 3
+    warmup = args.warmup if args.warmup is not None else 1
     n = H * W
-    terrain = 0 if args.flat else 1
+    terrain = 0 if flat else 1
     cell0 = rank * n
     Htot = H * world
     dates = np.datetime64("2001-01-01") + np.arange(nt)
@@ -141,15 +292,14 @@ def main():
     bn = min(args.block_rows, H) * W                       # cells per run_all launch
     blocks = [(c0, min(c0 + bn, n)) for c0 in range(0, n, bn)]
     outb = {k: torch.empty(nt, bn, **f64) for k in OUT5}
-    diag = torch.zeros(nm, api.NDIAG, **f64)
-    dwork = torch.empty(max(api.diag_work_size(bn, nm), 8), dtype=torch.uint8, device=dev)
+    acc = torch.zeros(1, nm, api.DIAG_REC, dtype=torch.int64, device=dev)
+    diag = torch.zeros(1, nm, api.NDIAG, **f64)
     setup_s = time.time() - t_setup
-
     ev = []  # (start, stop) events around every run_all launch of the timed steps
 
     def step(timed):
         state.copy_(state0)
-        diag.zero_()
+        acc.zero_()
         api.dev_snow_threshold(n, nt, tc, n, par, n, Tt, sp)                 # K2
         for c0, c1 in blocks:                                                # K5 (+K7)
             if timed:
@@ -157,148 +307,280 @@ def main():
                 a.record(stream)
             api.dev_run_all(cal, 0, nt, c1 - c0, sw[:, c0:], tc[:, c0:], pn[:, c0:], n, Tt[c0:],
                             par[:, c0:], n, state[:, c0:], n, outb, bn, monthly=False,
-                            diag=diag, diag_work=dwork, stream=sp)
+                            diag_acc=acc, stream=sp)
             if timed:
                 b.record(stream)
                 ev.append((a, b, c1 - c0))
-        if world > 1:  # global monthly water-balance totals, once per step (RCCL over xGMI)
-            if backend == "nccl":
-                dist.all_reduce(diag)
-            else:
-                h = diag.cpu()
-                dist.all_reduce(h)
-                diag.copy_(h)
+        # global monthly water-balance totals, once per step: exact integer limbs, so the sum over
+        # ranks (RCCL over xGMI) does not depend on the reduction order
+        allreduce_(ctx, acc)
+        api.dev_diag_finalize(acc, 1, nm, diag, stream=sp)
 
-    for _ in range(args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
+    dt = timed_region(ctx, step, steps, warmup)
     cell_days_step = float(n) * nt * world
-    value = cell_days_step * args.steps / dt
+    value = cell_days_step * steps / dt
     k_ms = np.array([a.elapsed_time(b) for a, b, _ in ev])
     k_cells = np.array([c for _, _, c in ev], dtype=np.float64)
     full = k_cells == k_cells.max()
     avg_launch_s = float(k_ms[full].mean()) / 1e3
     units_per_launch = float(k_cells.max()) * nt
-    achieved = ALG_BYTES_PER_CELL_DAY * units_per_launch / avg_launch_s / 1e9
-    traffic = valu_busy = None
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tfile):
-        try:
-            tj = json.load(open(tfile))
-            key = f"{min(args.block_rows, H)}x{W}x{nt}"
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-            valu_busy = tj.get(key, {}).get("valu_busy_frac")
-        except Exception:
-            traffic = None
 
-    try:
-        metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
-    except Exception:
-        metric = "cell-days/sec on 4096x4096x365d synthetic grid; max |dwn| vs reference"
-    line = {
-        "metric": metric,
-        "value": value, "unit": "cell-days/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {
-            "workload": f"{H}x{W} synthetic grid per GPU, {'flat' if args.flat else 'slope/aspect + lateral flow'}, "
-                        f"{nt} days, daily outputs wn/snow/ro/aet/pet, row blocks of {min(args.block_rows, H)}",
-            "grid_rows_per_gpu": H, "grid_cols": W, "days": nt, "block_rows": min(args.block_rows, H),
-            "timed": "K2 snow threshold + K5 run_all (+ monthly diagnostics), inputs resident in HBM",
-            "parallelism": f"row-block x{world}",
-        },
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS,
-                     "kernel": "k_run_all<daily,diag>", "avg_launch_ms": avg_launch_s * 1e3,
-                     "units_per_launch": units_per_launch,
-                     "alg_bytes_per_unit": ALG_BYTES_PER_CELL_DAY,
-                     "valu_busy_frac": valu_busy,
-                     "note": "the launch is FP64-VALU-issue bound, not HBM bound (~1.9k vector "
-                             "instructions per wavefront-day); valu_busy_frac = share of SIMD cycles "
-                             "issuing vector instructions, from the PMC pass in profiles/; see DESIGN.md"},
-        "spinup": {"seconds": spinup_s, "cells": n,
-                   "note": "both spin-ups of every cell (2..1000 passes of 365 days each, data "
-                           "dependent); untimed setup, not part of value"},
-        "setup_s": setup_s,
-    }
+    brows = min(args.block_rows, H)
+    line = base_line(ctx, value, steps, warmup, dt,
+                     f"{H}x{W} synthetic grid per GPU, {'flat' if flat else 'slope/aspect + lateral flow'}, "
+                     f"{nt} days, daily outputs wn/snow/ro/aet/pet, row blocks of {brows}",
+                     {"grid_rows_per_gpu": H, "grid_cols": W, "days": nt, "block_rows": brows,
+                      "timed": "K2 snow threshold + K5 run_all + K7 monthly water-balance totals "
+                               "(+ all-reduce), inputs resident in HBM"})
+    line["roofline"] = roofline(avg_launch_s, units_per_launch, f"{brows}x{W}x{nt}", "k_run_all<daily,diag>")
+    # both spin-ups of every cell + one transient pass: what a whole splash.grid call costs
+    sp_all = torch.tensor([spinup_s], dtype=torch.float64, device=dev)
+    allreduce_(ctx, sp_all, ctx["dist"].ReduceOp.MAX)
+    spinup_max = float(sp_all.item())
+    line["value_inclusive"] = cell_days_step / (spinup_max + dt / steps)
+    line["spinup"] = {"seconds": spinup_max, "cells": n,
+                      "note": "both spin-ups of every cell (2..1000 passes of 365 days each, data "
+                              "dependent), untimed setup; value_inclusive = cell-days of one step / "
+                              "(spin-up + one step)"}
+    line["setup_s"] = setup_s
+    line["water_balance"] = {"annual_precip_mm_per_cell": float(diag[0, :, 0].sum().item()) / (n * world),
+                             "annual_aet_mm_per_cell": float(diag[0, :, 1].sum().item()) / (n * world),
+                             "annual_runoff_mm_per_cell": float(diag[0, :, 2].sum().item()) / (n * world)}
 
-    # ---------------- CPU baseline + parity on a bounded sample (rank 0, N = 1 only)
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        from oracle.binding import Oracle
-        o = Oracle()
-        cores = host_cores()
-        doy, year, month = api.time_fields(dates)
-
-        def cpu_run(ns, threads):
-            sl = slice(0, ns)
-            hsw, htc, hpn = (x[:, sl].contiguous().cpu().numpy() for x in (sw, tc, pn))
-            hp = par[:, sl].cpu().numpy()
-            t1 = time.perf_counter()
-            out, st_end = o.grid_transient(doy, year, month, hsw, htc, hpn, hp[0], hp[1], hp[2],
-                                           hp[3], hp[4:16], Tt[sl].cpu().numpy(),
-                                           state0[:, sl].cpu().numpy(), n_threads=threads)
-            return time.perf_counter() - t1, out, o.fragile.copy()
-
-        ns = min(4096, n)
-        tp, _, _ = cpu_run(ns, cores)
-        rate = ns * nt / tp
-        ns2 = int(min(n, bn, max(ns, rate * args.cpu_seconds / nt)))
-        ns2 -= ns2 % 64 if ns2 > 64 else 0
-        tcpu, oref, frag = cpu_run(ns2, cores)
-        # the same cells on the GPU, for the parity figures
-        gs = {k: torch.empty(nt, ns2, **f64) for k in OUT5}
-        st = state0[:, :ns2].clone()
-        api.dev_run_all(cal, 0, nt, ns2, sw, tc, pn, n, Tt, par, n, st, ns2, gs, ns2, stream=sp)
-        torch.cuda.synchronize()
-        # cell-days on which the reference itself is ill-conditioned (sun grazing the slope:
-        # DESIGN.md "Conditioning"); a cell is set aside from the strict check once it has one
-        from oracle.binding import grazing_mask
-        hp = par[:, :ns2].cpu().numpy()
-        graz = grazing_mask(o, hp[0], hp[2], hp[3], doy, year)
-        okc = ~graz.any(0) & (frag == 0) & (hp[8] >= 0.01)
-        par_ok, frac_all = {}, {}
-        for i, k in enumerate(OUT5):
-            a, b = gs[k].cpu().numpy(), oref[i]
-            err = np.abs(a - b)
-            exc = np.maximum(err - 1e-9, 0.0)  # |x-ref| <= tol*|ref| + 1e-9
-            rel = exc / np.maximum(np.abs(b), 1e-300)
-            par_ok[k] = float(rel[:, okc].max())
-            frac_all[k] = float((err <= 1e-5 * np.abs(b) + 1e-9).mean())
-        dwn = np.abs(gs["wn"].cpu().numpy() - oref[0])
-        line["cpu_baseline"] = {
-            "value": ns2 * nt / tcpu, "unit": "cell-days/s", "cores": cores, "kind": "port",
-            "sample": f"first {ns2} cells x {nt} days of the same grid (run_all + rain/snow split "
-                      f"from the GPU's spun-up state), OpenMP over cells, {tcpu:.1f} s",
-        }
-        line["parity_sample"] = {
-            "cells": ns2, "tolerance": 1e-5,
-            "well_conditioned_cells": int(okc.sum()),
-            "max_rel_err": par_ok, "max_abs_dwn_mm": float(dwn[:, okc].max()),
-            "ill_conditioned_cells": {"grazing_sun": int(graz.any(0).sum()),
-                                      "noise_drainage_denominator": int((frag > 0).sum()),
-                                      "pore_size_index_below_0.01": int((hp[8] < 0.01).sum())},
-            "fraction_of_all_cell_days_within_tolerance": frac_all,
-        }
-    if rank == 0:
-        print(json.dumps(line))
+        cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp)
     cal.close()
-    if world > 1:
-        dist.destroy_process_group()
+    return line
+
+
+def cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp):
+    """CPU baseline (the oracle's transient loop on the host cores) on a bounded sample of the same
+    workload, and the parity figures of the GPU results on that sample (rank 0, N = 1 only)."""
+    api, torch, args = ctx["api"], ctx["torch"], ctx["args"]
+    from oracle.binding import Oracle
+    from oracle.parity import SERIES11, trajectory_summary
+    o = Oracle()
+    cores = host_cores()
+    doy, year, month = api.time_fields(dates)
+
+    def cpu_run(ns, threads, store=True):
+        sl = slice(0, ns)
+        hsw, htc, hpn = (x[:, sl].contiguous().cpu().numpy() for x in (sw, tc, pn))
+        hp = par[:, sl].cpu().numpy()
+        t1 = time.perf_counter()
+        o.grid_transient(doy, year, month, hsw, htc, hpn, hp[0], hp[1], hp[2], hp[3], hp[4:16],
+                         Tt[sl].cpu().numpy(), state0[:, sl].cpu().numpy(), n_threads=threads, store=store)
+        return time.perf_counter() - t1
+
+    ns1 = min(1024, n)
+    t1 = cpu_run(ns1, 1)
+    rate1 = ns1 * nt / t1
+    nsn = min(n, max(ns1, 64 * cores))
+    tn = cpu_run(nsn, cores)
+    rate_n = nsn * nt / tn
+    ns2 = int(min(n, bn, max(nsn, rate_n * args.cpu_seconds / nt)))
+    ns2 -= ns2 % 64 if ns2 > 64 else 0
+    tcpu = cpu_run(ns2, cores)
+    line["cpu_baseline"] = {
+        "value": ns2 * nt / tcpu, "unit": "cell-days/s", "cores": cores, "kind": "port",
+        "single_thread_value": rate1, "threads_obtained": o.max_threads(), "cpu_model": cpu_model(),
+        "sample": f"first {ns2} cells x {nt} days of the same grid (run_all + rain/snow split from the "
+                  f"GPU's spun-up state), OpenMP over cells with {cores} threads, {tcpu:.1f} s; one thread: "
+                  f"{ns1} cells in {t1:.1f} s",
+    }
+    # the same cells on the GPU, all 11 series, checked on EVERY cell-day (oracle/parity.py)
+    f64 = dict(dtype=torch.float64, device=ctx["dev"])
+    gs = {k: torch.empty(nt, ns2, **f64) for k in SERIES11}
+    st = state0[:, :ns2].clone()
+    api.dev_run_all(cal, 0, nt, ns2, sw, tc, pn, n, Tt, par, n, st, ns2, gs, ns2, stream=sp)
+    torch.cuda.synchronize()
+    p = dict(doy=doy, year=year, month=month, sw=sw[:, :ns2].cpu().numpy(), tc=tc[:, :ns2].cpu().numpy(),
+             pn=pn[:, :ns2].cpu().numpy(), par=par[:, :ns2].cpu().numpy(), Tt=Tt[:ns2].cpu().numpy(),
+             state0=state0[:, :ns2].cpu().numpy(), out={k: v.cpu().numpy() for k, v in gs.items()})
+    r = trajectory_summary(o, p, n_threads=cores)
+    r["cells"] = ns2
+    line["parity_sample"] = r
+
+
+# ------------------------------------------------------------------------------------ configs 3, 4
+def run_streamed(ctx):
+    """30-year runs: spin-up on the first 365 days, then the transient loop one calendar year at a
+    time through two forcing buffers filled by the device generator on a second stream (the stand-in
+    for the forcing stream of a real run), the 5-double state carried in HBM, daily outputs of each
+    year written to one reused buffer (config 3) or monthly outputs + basin totals (config 4)."""
+    args, world, rank, dev, api, torch, dist = (ctx[k] for k in ("args", "world", "rank", "dev", "api",
+                                                                 "torch", "dist"))
+    cfg4 = args.config == 4
+    steps = args.steps if args.steps is not None else 1
+    warmup = args.warmup if args.warmup is not None else 0
+    years = args.years
+    dates = np.arange(np.datetime64("2001-01-01"), np.datetime64(f"{2001 + years}-01-01"))
+    nt = len(dates)
+    cal = api.Calendar.from_dates(dates)
+    doy, year, month = api.time_fields(dates)
+    ybounds = [0] + [int(i) + 1 for i in np.where(np.diff(year) != 0)[0]] + [nt]
+    nm = cal.nmonth
+    f64 = dict(dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream()
+    sp = stream.cuda_stream
+    gen_stream = torch.cuda.Stream(device=dev)
+
+    if cfg4:
+        Htot, W = args.rows or 360, args.cols or 720
+        # land mask by hash (~26 % valid); rows cut so that every rank gets the same land count
+        from rsplash_amd.dist import row_block_partition
+        rng = np.random.default_rng(SEED)
+        land_all = rng.random(Htot * W) < 0.26
+        part = row_block_partition(Htot, W, world, rank, land_all.reshape(Htot, W).sum(1))
+        cell0, nfull = part["cell0"], part["ncell"]
+        land_idx = np.where(land_all[cell0:cell0 + nfull])[0]
+        n = len(land_idx)
+        # basins: 30 x 30 degree tiles (6 x 12 = 72)
+        rr, cc = np.divmod(cell0 + land_idx, W)
+        basin_h = ((rr * 6 // Htot) * 12 + cc * 12 // W).astype(np.int32)
+        n_basin = 72
+        terrain = 1
+    else:
+        H, W = args.rows or 512, args.cols or 4096
+        Htot = H * world
+        n = nfull = H * W
+        cell0 = rank * n
+        land_idx, n_basin, terrain = None, 1, 1
+
+    # statics (generated for the contiguous range, compacted to the land cells for config 4)
+    stat = [torch.empty(nfull, **f64) for _ in range(5)]
+    soil_f, au_f = torch.empty(6, nfull, **f64), torch.empty(3, nfull, **f64)
+    api.dev_synth_statics(SEED, Htot, W, cell0, nfull, terrain, *stat, soil_f, au_f, sp)
+    if cfg4:
+        li = torch.tensor(land_idx, device=dev)
+        lat, elev, slop, asp, res = (x[li].contiguous() for x in stat)
+        soil, au = soil_f[:, li].contiguous(), au_f[:, li].contiguous()
+        basin = torch.tensor(basin_h, device=dev)
+    else:
+        lat, elev, slop, asp, res = stat
+        soil, au, basin = soil_f, au_f, None
+    par = torch.empty(api.NPAR, n, **f64)
+    api.dev_soil_hydro(n, lat, elev, slop, asp, res, soil, au, par, sp)
+    lat_f, elev_f = stat[0], stat[1]
+
+    bufs = [[torch.empty(366, n, **f64) for _ in range(3)] for _ in range(2)]
+    full = [torch.empty(366, nfull, **f64) for _ in range(3)] if cfg4 else None
+    ready = [torch.cuda.Event() for _ in range(2)]
+    freed = [torch.cuda.Event() for _ in range(2)]
+
+    def generate(t0, t1, slot):
+        """forcing of days [t0, t1) into buffer `slot`, on the generator stream"""
+        with torch.cuda.stream(gen_stream):
+            gen_stream.wait_event(freed[slot])
+            gp = gen_stream.cuda_stream
+            if cfg4:
+                api.dev_synth_forcing(SEED, cal, t0, t1 - t0, cell0, nfull, lat_f, elev_f, *full, nfull, gp)
+                for v in range(3):
+                    torch.index_select(full[v][:t1 - t0], 1, li, out=bufs[slot][v][:t1 - t0])
+            else:
+                api.dev_synth_forcing(SEED, cal, t0, t1 - t0, cell0, n, lat, elev, *bufs[slot], n, gp)
+            ready[slot].record(gen_stream)
+
+    # Tt needs the whole series: one streaming pass over tc, year by year (max of the yearly maxima)
+    Tt = torch.full((n,), -np.inf, **f64)
+    Ttc = torch.empty(n, **f64)
+    for f in freed:
+        f.record(stream)
+    t_setup = time.time()
+    for i, (t0, t1) in enumerate(zip(ybounds[:-1], ybounds[1:])):
+        generate(t0, t1, i & 1)
+        stream.wait_event(ready[i & 1])
+        api.dev_snow_threshold(n, t1 - t0, bufs[i & 1][1], n, par, n, Ttc, sp)
+        Tt = torch.maximum(Tt, Ttc)
+        freed[i & 1].record(stream)
+    # spin-up on the first 365 days
+    generate(0, 365, 0)
+    stream.wait_event(ready[0])
+    state = torch.empty(api.NSTATE, n, **f64)
+    work = torch.empty(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    api.dev_spin_up(cal, n, *bufs[0], n, Tt, par, n, state, n, work, stream=sp)
+    e1.record(stream)
+    freed[0].record(stream)
+    torch.cuda.synchronize()
+    spinup_s = e0.elapsed_time(e1) / 1e3
+    state0 = state.clone()
+    del work
+    setup_s = time.time() - t_setup
+
+    acc = torch.zeros(n_basin, nm, api.DIAG_REC, dtype=torch.int64, device=dev)
+    diag = torch.zeros(n_basin, nm, api.NDIAG, **f64)
+    if cfg4:
+        outs = {k: torch.zeros(nm, n, **f64) for k in OUT5}       # monthly, whole run
+    else:
+        outs = {k: torch.empty(366, n, **f64) for k in OUT5}      # daily, one year, reused
+    ev = []
+
+    def step(timed):
+        state.copy_(state0)
+        acc.zero_()
+        generate(ybounds[0], ybounds[1], 0)
+        for i, (t0, t1) in enumerate(zip(ybounds[:-1], ybounds[1:])):
+            if i + 1 < len(ybounds) - 1:
+                generate(ybounds[i + 1], ybounds[i + 2], (i + 1) & 1)  # next year in flight
+            stream.wait_event(ready[i & 1])
+            b = bufs[i & 1]
+            if timed:
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_.record(stream)
+            if cfg4:
+                o_ = {k: outs[k][int(cal.month_id[t0]):] for k in OUT5}
+                api.dev_run_all(cal, t0, t1 - t0, n, b[0], b[1], b[2], n, Tt, par, n, state, n, o_, n,
+                                monthly=True, diag_acc=acc, basin=basin, n_basin=n_basin, stream=sp)
+            else:
+                api.dev_run_all(cal, t0, t1 - t0, n, b[0], b[1], b[2], n, Tt, par, n, state, n, outs, n,
+                                monthly=False, diag_acc=acc, stream=sp)
+            if timed:
+                b_.record(stream)
+                ev.append((a_, b_, t1 - t0))
+            freed[i & 1].record(stream)
+        allreduce_(ctx, acc)  # ONE all-reduce for the whole 30-year run (exact integer limbs)
+        api.dev_diag_finalize(acc, n_basin, nm, diag, stream=sp)
+
+    dt = timed_region(ctx, step, steps, warmup)
+    ncell_all = torch.tensor([float(n)], dtype=torch.float64, device=dev)
+    allreduce_(ctx, ncell_all)
+    cells_total = float(ncell_all.item())
+    cell_days_step = cells_total * nt
+    value = cell_days_step * steps / dt
+    k_ms = np.array([a.elapsed_time(b) for a, b, _ in ev])
+    k_days = np.array([d for _, _, d in ev], dtype=np.float64)
+    avg_launch_s = float(k_ms.mean()) / 1e3
+    units_per_launch = float(n) * float(k_days.mean())
+    if cfg4:
+        workload = (f"{Htot}x{W} (0.5 degree) global grid, {int(cells_total)} land cells (hash mask, NA "
+                    f"elsewhere), {years} years daily, monthly outputs + monthly totals for {n_basin} basins")
+    else:
+        workload = (f"{n} cells per GPU ({args.rows or 512}x{W} = one rank's 1/8 share of 4096x4096), {years} "
+                    f"years ({nt} days) streamed in calendar-year chunks, daily outputs wn/snow/ro/aet/pet")
+    line = base_line(ctx, value, steps, warmup, dt, workload,
+                     {"days": nt, "years": years, "cells_per_gpu": n,
+                      "timed": "per year: forcing generation (second stream, overlapped) + K5 run_all + K7; "
+                               "one all-reduce of the totals at the end"})
+    line["roofline"] = roofline(avg_launch_s, units_per_launch, f"stream{n}", "k_run_all (one calendar year)")
+    if cfg4:
+        line["roofline"]["note"] = ("monthly outputs: algorithmic bytes are 24 B per cell-day, not 64; the "
+                                    "figure is kept on the 64 B convention for comparability. "
+                                    + line["roofline"]["note"])
+    sp_all = torch.tensor([spinup_s], dtype=torch.float64, device=dev)
+    allreduce_(ctx, sp_all, dist.ReduceOp.MAX)
+    line["value_inclusive"] = cell_days_step / (float(sp_all.item()) + dt / steps)
+    line["spinup"] = {"seconds": float(sp_all.item()), "cells": n}
+    line["setup_s"] = setup_s
+    d = diag.cpu().numpy()
+    line["water_balance"] = {"basins": n_basin,
+                             "mean_annual_precip_mm_per_cell": float(d[:, :, 0].sum() / cells_total / years),
+                             "mean_annual_aet_mm_per_cell": float(d[:, :, 1].sum() / cells_total / years),
+                             "mean_annual_runoff_mm_per_cell": float(d[:, :, 2].sum() / cells_total / years)}
+    cal.close()
+    return line
 
 
 if __name__ == "__main__":

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPLASH_ABI_VERSION 1
+#define SPLASH_ABI_VERSION 2
 
 enum {
     SPLASH_OK = 0,
@@ -51,6 +51,16 @@ enum {
 #define SPLASH_NSTATE 5 /* wn, snow, qin, td, nd : the carry of SPLASH::run_all, src/SPLASH.cpp:1878-1889 */
 #define SPLASH_NOUT 9   /* wn, ro, pet, aet, snow, cond, bflow, netr, sm_lim (R/splash.point.R:182,201) */
 #define SPLASH_NDIAG 6  /* precip(rain+snowfall), aet, ro, bflow, wn, snow : monthly totals over cells */
+#define SPLASH_NEXTRA 3 /* qin_prev, tdrain, snwage : the state series run_all also returns, src/SPLASH.cpp:1913-1915 */
+/* Water-balance totals are accumulated EXACTLY, as two 64-bit fixed-point limbs per total
+ * (value = limb0 / 2^16 + limb1 / 2^48; every cell's monthly figure is split without rounding
+ * above 2^-48 mm and added with integer atomics), so a total is bitwise identical for any
+ * launch blocking, any number of GPUs and any reduction order, and an all-reduce of the limbs
+ * over ranks is exact.  One accumulator record per (basin, calendar month):
+ *   int64 acc[n_basin][nmonth][SPLASH_NDIAG + 1][2]
+ * record SPLASH_NDIAG holds {cell-months added, values skipped because non-finite or >= 2^20}. */
+#define SPLASH_DIAG_LIMBS 2
+#define SPLASH_DIAG_REC ((SPLASH_NDIAG + 1) * SPLASH_DIAG_LIMBS)
 
 int splash_hip_abi_version(void);
 int splash_hip_device_count(void);            /* 0 when no device; never fails */
@@ -90,7 +100,9 @@ int splash_dev_snow_threshold(size_t ncell, int nt, const double* tc, size_t ldf
                               const double* cellpar, size_t ldp, double* Tt, void* stream);
 
 /* K4 the two spin-ups of splash.point (R/splash.point.R:141-152 -> SPLASH::spin_up,
- * src/SPLASH.cpp:1594-1749) on the first 365 days of the calendar: spin-up #1, aridity index
+ * src/SPLASH.cpp:1594-1749) on the first 365 records of the series, run as day-of-year 1..365 of
+ * the first year whatever date the series starts on (quick_run(i+1, y[1], ...), src/SPLASH.cpp:1658;
+ * the rain/snow split keeps the months of the real dates): spin-up #1, aridity index
  * AI = sum(pet)/sum(P), cellout := AI (written to cellpar row 15), spin-up #2.  Writes the state
  * handed to run_all.  passes (optional) [2][ncell] int: executed passes of each spin-up.
  * Spin-up #1 contributes nothing but the PET of its first pass (the reference iterates it to
@@ -108,11 +120,27 @@ typedef struct {
     size_t ldo;
     int monthly;              /* 0: one row per day; 1: one row per calendar month
                                  (mean of wn, snow, sm_lim; sum of the others) */
-    double* diag;             /* optional [nmonth_in_range][SPLASH_NDIAG] grid totals, or NULL */
-    double* diag_work;        /* scratch of splash_dev_diag_work_size() bytes when diag != NULL */
+    double* extra[SPLASH_NEXTRA]; /* daily mode only, optional: qin_prev, tdrain, snwage [nt][ldo] */
+    /* K7 water-balance diagnostics (optional): monthly totals of SPLASH_NDIAG quantities per
+     * basin, ADDED into diag_acc (the caller zeroes it once and may pass the same buffer to every
+     * row block, time chunk and -- after an integer all-reduce -- rank).  Month index = the
+     * calendar's running month number, so the buffer spans the whole calendar:
+     * int64 [n_basin][splash_calendar_nmonth][SPLASH_NDIAG+1][2].  basin: [ncell] ids in
+     * [0, n_basin) or NULL (= one basin, the whole grid; n_basin is then taken as 1).  Cells with
+     * an id outside the range are left out.  The reference only has a TODO here (src/smr.h:44-46). */
+    int64_t* diag_acc;
+    const int32_t* basin;
+    int n_basin;
 } splash_dev_out;
 
-size_t splash_dev_diag_work_size(size_t ncell, int nmonth);
+size_t splash_dev_diag_acc_size(int n_basin, int nmonth); /* bytes */
+/* limbs -> doubles: diag[n_basin][nmonth][SPLASH_NDIAG] (device pointers; exact up to the final
+ * rounding to double); counts (optional) [n_basin][nmonth][2] as doubles */
+int splash_dev_diag_finalize(const int64_t* diag_acc, int n_basin, int nmonth, double* diag,
+                             double* counts, void* stream);
+/* the same conversion on the host (e.g. after summing the limbs of several devices or ranks) */
+void splash_diag_finalize_host(const int64_t* diag_acc, int n_basin, int nmonth, double* diag,
+                               double* counts);
 
 /* K5 transient run: SPLASH::run_all (src/SPLASH.cpp:1833-1916) over days [t0, t0+nt) of the
  * calendar for ncell cells, with the rain/snow split (K2 part 2) fused into the loads.  Forcing
@@ -158,6 +186,15 @@ int splash_unswc_run(size_t ncell, int nt, const double* wn /*[nt][ncell]*/,
  * (host pointers): out [5][n] = flog(x), fexp(x), fpow(x,y), facos(x), fsqrt(x) */
 int splash_dev_math_probe(size_t n, const double* x, const double* y, double* out);
 
+/* test hook: the day loop's own forms of SPLASH::moist_surf (z = 10 cm, src/SPLASH.cpp:1265,
+ * 1921-1961) and SPLASH::inf_GA (tdur = 6 h, :1268, 1963-2023) for n independent rows (host
+ * pointers): cellpar [SPLASH_NPAR][n], column water wn, viscosity-corrected conductivity and
+ * inflow P -> surface moisture and infiltration.  (splash_mod_moist_surf / splash_mod_inf_GA are
+ * the literal general-argument mirrors of the module methods.) */
+int splash_dev_infiltration_probe(size_t n, const double* cellpar, const double* wn,
+                                  const double* ksat_visc, const double* P, double* theta_surf,
+                                  double* infiltration);
+
 /* ---------------------------------------------------------------- host-buffer entry points - */
 typedef struct {
     size_t ncell;
@@ -168,24 +205,40 @@ typedef struct {
     const double* resolution;                /* [ncell] m */
     const double* soil;                      /* [6][ncell] */
     const double* au;                        /* [3][ncell] or NULL */
+    const int32_t* basin;                    /* [ncell] basin ids in [0, n_basin) or NULL */
+    int n_basin;                             /* 0/1 without basin ids */
+    /* optional single-precision transport of the forcing (the reference's rasters are FLT4S:
+     * widening is lossless; arithmetic stays FP64).  When sw_in is NULL these are used instead. */
+    const float *sw_in_f32, *tc_f32, *pn_f32; /* [nt][ncell] */
 } splash_grid_in;
 
 typedef struct {
     int monthly_out;    /* sim.control$monthly_out, R/splash.grid.R:28 (default TRUE there) */
-    int device;         /* HIP device ordinal */
+    int device;         /* HIP device ordinal (used when n_devices <= 1 and devices == NULL) */
     size_t max_cells_per_launch; /* 0 = size blocks from free HBM */
+    /* Multi-GPU inside one call (replaces the SOCK-cluster block scheduler of
+     * R/splash.grid.R:260-314, 359-400): the valid cells are cut into n_devices contiguous ranges
+     * of equal valid-cell count, one host thread + stream set per device.  devices == NULL means
+     * ordinals 0..n_devices-1; the same ordinal may appear more than once (two workers on one
+     * GPU).  Results are independent of the split, bit for bit, totals included. */
+    int n_devices;
+    const int* devices;
 } splash_opts;
 
 typedef struct {
     double* out[SPLASH_NOUT]; /* caller-allocated [nt_out][ncell], NULL to skip */
     double* state_end;        /* optional [5][ncell] */
-    double* diag;             /* optional [nmonth][SPLASH_NDIAG] */
+    double* diag;             /* optional [n_basin][nmonth][SPLASH_NDIAG] (n_basin = 1 without ids) */
     double* aux;              /* optional [4][ncell]: Tt, AI, passes1, passes2 */
+    int64_t* diag_acc;        /* optional: the exact limbs behind diag, [n_basin][nmonth][SPLASH_NDIAG+1][2],
+                                 for callers that sum over several calls or ranks */
 } splash_grid_out;
 
 /* splash.grid's inner computation for a block of cells (R/splash.grid.R:277-308): every cell gets
  * what splash.point computes (R/splash.point.R:92-214).  Cells with NaN statics or NaN day-0
- * forcing are returned as NaN (R's NA cells). */
+ * forcing are returned as NaN (R's NA cells, e.g. ocean).  A gap (NaN) later in a series is not
+ * a mask: it propagates through the arithmetic as it does in R (Tt = NA, NA rain and snow on the
+ * days of possible snowfall, NaN state from the first such day). */
 int splash_grid_run(const splash_grid_in* in, const splash_opts* opt, const splash_grid_out* out,
                     char* err, size_t errlen);
 

@@ -61,21 +61,30 @@ class Opts(C.Structure):
 class CellAux(C.Structure):
     _fields_ = [("soil_info", C.c_double * 12), ("wmax_r", C.c_double), ("Tt", C.c_double),
                 ("AI", C.c_double), ("passes1", C.c_int), ("passes2", C.c_int),
-                ("state0", C.c_double * 5), ("state1", C.c_double * 5), ("fragile", C.c_int)]
+                ("state0", C.c_double * 5), ("state1", C.c_double * 5), ("fragile", C.c_int), ("critical", C.c_int)]
 
 
 AUX_DTYPE = np.dtype([("soil_info", "f8", 12), ("wmax_r", "f8"), ("Tt", "f8"), ("AI", "f8"),
                       ("passes1", "i4"), ("passes2", "i4"), ("state0", "f8", 5),
-                      ("state1", "f8", 5), ("fragile", "i4")], align=True)
+                      ("state1", "f8", 5), ("fragile", "i4"), ("critical", "i4")], align=True)
 assert AUX_DTYPE.itemsize == C.sizeof(CellAux)
 
 OUT_NAMES = ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "sm_lim")
 
+# Slope sunset angle below which a cell-day counts as "sun grazing the slope" (event bit 1 of
+# orc_grid_transient2): the reference's own daily radiation carries relative rounding noise
+# ~1e-16/hs^2 there.  The value comes from tools/conditioning_evidence.py (profiles/r02_conditioning.md).
+HS_LIM_DEG = 2e-3
+
 
 class Oracle:
-    def __init__(self):
-        build()
-        self.lib = L = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+    def __init__(self, lib_path=None):
+        """lib_path: an alternative build of splash_oracle.c (tools/conditioning_evidence.py);
+        default = the pinned parity oracle oracle/liboracle.so"""
+        if lib_path is None:
+            build()
+            lib_path = os.path.join(_HERE, "liboracle.so")
+        self.lib = L = C.CDLL(lib_path)
         L.orc_viscosity_h2o.restype = C.c_float
         L.orc_viscosity_h2o.argtypes = [C.c_float, C.c_float]
         for f in ("orc_density_h2o", "orc_moist_surf", "orc_inf_GA", "orc_get_wtd",
@@ -113,6 +122,8 @@ class Oracle:
             [C.POINTER(Opts), C.POINTER(_dp), C.c_void_p]
         L.orc_grid_transient.argtypes = [C.c_int, C.c_int, _ip, _ip, _ip] + [_dp] * 10 + \
             [C.POINTER(_dp), C.c_int, _ip]
+        L.orc_grid_transient2.argtypes = [C.c_int, C.c_int, _ip, _ip, _ip] + [_dp] * 10 + \
+            [_dp, C.POINTER(_dp), C.c_void_p, C.c_double, C.c_void_p, C.c_int]
         L.orc_synth_statics.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int] + \
             [_dp] * 7
         L.orc_synth_forcing.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
@@ -295,6 +306,35 @@ class Oracle:
                                     st.ctypes.data_as(_dp), ptrs, n_threads,
                                     self.fragile.ctypes.data_as(_ip))
         return out, st
+
+    SERIES11 = ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "qin_prev", "tdrain",
+                "snwage")
+
+    def grid_transient2(self, doy, year, month, sw_in, tc, pn, lat, elev, slop, asp, soil_info, Tt,
+                        state, prev=None, names=SERIES11, hs_lim_deg=HS_LIM_DEG, want_hs=False,
+                        n_threads=0):
+        """run_all for every cell from `state` with the per-cell-day conditioning events.
+        prev = [5, nt, ncell] state series (wn, snow, qin, td, nd after each day) switches to
+        one-step mode: day t starts from prev[:, t-1] (see orc_grid_transient2).
+        Returns (dict name -> [nt, ncell], state_end [5, ncell], events uint8 [nt, ncell], hs|None)."""
+        nt, ncell = sw_in.shape
+        ia = [_i(x) for x in (doy, year, month)]
+        fa = [_d(x) for x in (sw_in, tc, pn, lat, elev, slop, asp, soil_info, Tt)]
+        st = np.array(state, dtype=np.float64, order="C", copy=True)
+        pv = None
+        if prev is not None:
+            pv = np.ascontiguousarray(prev, dtype=np.float64)
+            assert pv.shape == (5, nt, ncell)
+        out = {k: np.empty((nt, ncell)) for k in names}
+        ptrs = (_dp * 11)(*[out[k].ctypes.data_as(_dp) if k in out else None for k in self.SERIES11])
+        ev = np.zeros((nt, ncell), np.uint8)
+        hs = np.empty((nt, ncell), np.float32) if want_hs else None
+        self.lib.orc_grid_transient2(ncell, nt, ia[0][1], ia[1][1], ia[2][1], *[x[1] for x in fa],
+                                     st.ctypes.data_as(_dp),
+                                     pv.ctypes.data_as(_dp) if pv is not None else None, ptrs,
+                                     ev.ctypes.data, float(hs_lim_deg),
+                                     hs.ctypes.data if want_hs else None, n_threads)
+        return out, st, ev, hs
 
     def synth_statics(self, seed, H, W, cell0, ncell, terrain):
         lat, elev, slop, asp, res = (np.empty(ncell) for _ in range(5))

@@ -18,6 +18,60 @@
 #include <omp.h>
 #endif
 
+/* ---- evidence builds only (tools/conditioning_evidence.py; never the parity oracle) ----------
+ * -DORC_PERTURB_LIBM wraps the libm calls of the FP64 path so that every result is moved by one
+ * ulp up or down (or left alone) by a hash of its arguments: "another correct libm", which is what
+ * any second implementation of the reference amounts to (the GPU's math library, glibc on another
+ * CPU).  Results that every implementation returns exactly (x == 0, integer and 0.5 powers,
+ * log(1), ...) are left alone, and so is the float viscosity routine together with the density
+ * polynomial it rounds to float (ORC_EXACT_BEGIN/END): those are reproduced bit for bit by the
+ * product and are not a source of disagreement. */
+#ifdef ORC_PERTURB_LIBM
+static inline double orc_pert(double r, double x, double y, unsigned salt)
+{
+    union { double d; uint64_t u; } a = {x}, b = {y};
+    uint64_t z = a.u * 0x9E3779B97F4A7C15ULL + (b.u ^ ((uint64_t)salt << 32));
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    if (!(r == r) || r == 0.0 || isinf(r) || x == 0.0) return r;
+    switch (z & 3) {
+    case 1: return nextafter(r, INFINITY);
+    case 2: return nextafter(r, -INFINITY);
+    default: return r;
+    }
+}
+static inline double p_pow(double x, double y)
+{
+    double r = pow(x, y);
+    if (x == 1.0 || y == 0.5 || (y == floor(y) && fabs(y) <= 8.0)) return r;
+    return orc_pert(r, x, y, 1);
+}
+static inline double p_exp(double x) { return orc_pert(exp(x), x, 0.0, 2); }
+static inline double p_log(double x) { return x == 1.0 ? 0.0 : orc_pert(log(x), x, 0.0, 3); }
+static inline double p_sin(double x) { return orc_pert(sin(x), x, 0.0, 4); }
+static inline double p_cos(double x) { return orc_pert(cos(x), x, 0.0, 5); }
+static inline double p_tan(double x) { return orc_pert(tan(x), x, 0.0, 6); }
+static inline double p_acos(double x) { return (x == 1.0) ? 0.0 : orc_pert(acos(x), x, 0.0, 7); }
+static inline double p_asin(double x) { return orc_pert(asin(x), x, 0.0, 8); }
+#define pow p_pow
+#define exp p_exp
+#define log p_log
+#define sin p_sin
+#define cos p_cos
+#define tan p_tan
+#define acos p_acos
+#define asin p_asin
+#define ORC_EXACT_BEGIN _Pragma("push_macro(\"pow\")") _Pragma("push_macro(\"exp\")")
+#define ORC_EXACT_END _Pragma("pop_macro(\"pow\")") _Pragma("pop_macro(\"exp\")")
+#else
+#define ORC_EXACT_BEGIN
+#define ORC_EXACT_END
+#endif
+/* the float viscosity routine and the density it rounds to float keep the pinned arithmetic in
+ * every build (no FMA contraction even under -ffp-contract=fast -march=native) */
+#define ORC_PINNED __attribute__((optimize("fp-contract=off")))
+
 /* std::max / std::min semantics (NaN-asymmetric; src/SPLASH.cpp:1267,1270,1483,1574;
  * src/EVAP.cpp:234,247): max(a,b) = (a<b)?b:a ; min(a,b) = (b<a)?b:a */
 #define STDMAX(a, b) (((a) < (b)) ? (b) : (a))
@@ -57,6 +111,11 @@ static NOINLINE double dsin(double x) { return sin(x * G_pir); } /* src/SOLAR.cp
 static NOINLINE double dtan(double x) { return tan(x * G_pir); } /* src/SPLASH.cpp:139-148 */
 
 /* ------------------------------------------------------------------ SOLAR */
+
+/* slope sunset angle hs [degrees] of the last orc_solar call on this thread (src/SOLAR.cpp:149-159):
+ * the conditioning monitor of the grazing-sun class (DESIGN.md "Conditioning") */
+static __thread double tl_last_hs = 0.0;
+double orc_last_hs(void) { return tl_last_hs; }
 
 /* src/SOLAR.cpp:352-374 (note the float jd) */
 int orc_julian_day(int y, int m, int i)
@@ -171,6 +230,8 @@ void orc_solar(double lat, double elv, int n, int y, double sw_in, double tc, do
         hs /= G_pir;
     }
 
+    tl_last_hs = hs;
+
     /* :164-165 */
     double ra_d = (86400.0 / G_PI) * dr * G_Gsc;
     ra_d *= (ru * hs * G_pir + rv * dsin(hs));
@@ -272,7 +333,12 @@ double orc_elv2pres(double z)
 }
 
 /* src/EVAP.cpp:338-389 */
-double orc_density_h2o(double tc, double p)
+ORC_EXACT_BEGIN
+#ifdef ORC_PERTURB_LIBM
+#undef pow
+#undef exp
+#endif
+ORC_PINNED double orc_density_h2o(double tc, double p)
 {
     double po = 0.99983952;
     po += (6.788260e-5) * tc;
@@ -313,7 +379,7 @@ double orc_density_h2o(double tc, double p)
 
 /* src/EVAP.cpp:405-462.  The reference computes this in `float` with C++'s usual
  * promotions; every cast below is one the C++ compiler inserts implicitly. */
-float orc_viscosity_h2o(float tc, float p)
+ORC_PINNED float orc_viscosity_h2o(float tc, float p)
 {
     float tk_ast = 647.096;
     float rho_ast = 322.0;
@@ -360,6 +426,7 @@ float orc_viscosity_h2o(float tc, float p)
     float mu = mu_bar * mu_ast;
     return mu;
 }
+ORC_EXACT_END
 
 /* src/EVAP.cpp:491-515 */
 static double specific_heat(double tc)
@@ -579,7 +646,10 @@ double orc_get_wtd(double wn, double depth, double bub_press, double theta_s, do
     return wtd;
 }
 
-double orc_debug[16]; /* intermediates of the last orc_run_one_day call (debugging aid) */
+/* intermediates of the last orc_run_one_day call on this thread (debugging aid; thread-local so
+ * that the OpenMP drivers do not fight over one cache line) */
+__thread double orc_debug[16];
+double* orc_debug_ptr(void) { return orc_debug; }
 
 /* Conditioning bookkeeping (not part of the restatement): number of day steps, on the calling
  * thread, in which the drainage time of src/SPLASH.cpp:1472 was computed from a transmittance
@@ -596,6 +666,45 @@ long orc_fragile_events(int reset)
 {
     long v = tl_fragile_events;
     if (reset) tl_fragile_events = 0;
+    return v;
+}
+/* The critical end of that band: the increment fl(psi_m + depth*1000) - psi_m is an ulp or two
+ * of psi_m.  Whether the two powers then come out equal (T_uns = 0 exactly, Q = 0, drainage time
+ * +inf, which is STICKY: src/SPLASH.cpp:1468, :1483 keep it infinite for the rest of the run and
+ * the upslope inflow of :1367-1371 never switches off) or one ulp apart (a finite drainage time of
+ * a few thousand days that halves every day) depends on the last bit of pow(): the reference built
+ * against another correct libm takes the other branch and ends the year millimetres apart
+ * (tools/conditioning_evidence.py, profiles/r02_conditioning.md).  Counted separately, by a
+ * local sensitivity test: psi_m itself is the quotient of a pow() and carries its last-bit
+ * uncertainty, so the two bases bub/psi_m and bub/(psi_m + depth*1000) are formed for psi_m and
+ * its two neighbouring doubles; the day is decided when all three give identical bases (T_uns = 0
+ * in any implementation) or bases at least 3 ulp apart in all three (T_uns > 0 in any
+ * implementation), critical otherwise. */
+static int64_t ulp_distance(double a, double b)
+{
+    int64_t ia, ib;
+    memcpy(&ia, &a, 8);
+    memcpy(&ib, &b, 8);
+    if (ia < 0) ia = INT64_MIN - ia;
+    if (ib < 0) ib = INT64_MIN - ib;
+    return ia > ib ? ia - ib : ib - ia;
+}
+static int zero_or_not_is_undecided(double bub_press, double psi_m, double w)
+{
+    int all_zero = 1, all_far = 1;
+    double cand[3] = {psi_m, nextafter(psi_m, INFINITY), nextafter(psi_m, -INFINITY)};
+    for (int i = 0; i < 3; i++) {
+        int64_t d = ulp_distance(bub_press / cand[i], bub_press / (cand[i] + w));
+        if (d != 0) all_zero = 0;
+        if (d < 3) all_far = 0;
+    }
+    return !(all_zero || all_far);
+}
+static __thread long tl_critical_events = 0;
+long orc_critical_events(int reset)
+{
+    long v = tl_critical_events;
+    if (reset) tl_critical_events = 0;
     return v;
 }
 
@@ -782,6 +891,9 @@ void orc_run_one_day(double lat, double elv, int n, int y, double wn, double sw_
         if (Au > 0.0 && wtd >= depth && fabs(psi_m) > 4.4e12 * (wtd * 1000.0) &&
             fabs(psi_m) < 2.6e16 * (wtd * 1000.0))
             tl_fragile_events++;
+        if (Au > 0.0 && wtd >= depth && isfinite(psi_m) &&
+            zero_or_not_is_undecided(bub_press, psi_m, wtd * 1000.0))
+            tl_critical_events++;
         t_drain = -1.0 * log(1.0 - (log(Kb) * (Au * R / Q))) / log(Kb);
         q_in_f = (Qt - Au * R * log(Kb)) / Ai;
     }
@@ -836,7 +948,7 @@ void orc_run_one_day(double lat, double elv, int n, int y, double wn, double sw_
     orc_debug[0] = Kb; orc_debug[1] = Q; orc_debug[2] = T; orc_debug[3] = t_drain;
     orc_debug[4] = q_in_f; orc_debug[5] = q_in_o; orc_debug[6] = R; orc_debug[7] = Ksat_visc;
     orc_debug[8] = hyd_grad_out; orc_debug[9] = Qt; orc_debug[10] = infi; orc_debug[11] = Wmax;
-    orc_debug[12] = surf_moist; orc_debug[13] = T_uns; orc_debug[14] = Acs_out; orc_debug[15] = log(Kb);
+    orc_debug[12] = surf_moist; orc_debug[13] = T_uns; orc_debug[14] = Acs_out; orc_debug[15] = Kb;
     dsoil->sm = sm;
     dsoil->ro = ro;
     dsoil->swe = snow;
@@ -1112,11 +1224,14 @@ static double frain_one(double tc, double Tt, double Tr, int m)
 
 static double snow_threshold(int nt, const double* tc, size_t stride, double lat, double elev)
 {
-    /* R/splash.point.R:120-122: Tt = max(tc[p_snow>=0.5]); max of nothing is -Inf */
+    /* R/splash.point.R:120-122: Tt = max(tc[p_snow>=0.5]); max of nothing is -Inf.  A missing
+     * temperature makes p_snow NA, the NA logical subscript selects an NA element and max() (no
+     * na.rm) returns NA: one gap in tc makes Tt NA for the whole series. */
     double Tt = -INFINITY;
     for (int t = 0; t < nt; t++) {
         double v = tc[(size_t)t * stride];
         double p = orc_snowfall_prob(v, lat, elev);
+        if (isnan(p)) return NAN;
         if (p >= 0.5 && v > Tt) Tt = v;
     }
     return Tt;
@@ -1127,7 +1242,8 @@ static void rain_snow_one(double tc, double pn, int month, double lat, double el
 {
     /* R/splash.point.R:124-128 */
     double p = orc_snowfall_prob(tc, lat, elev);
-    double f_rain = (p >= 0.5) ? frain_one(tc, Tt, 13.3, month) : 1.0;
+    /* ifelse(NA, ., .) is NA; frain[frain<0] <- 0 leaves NA entries alone */
+    double f_rain = isnan(p) ? NAN : ((p >= 0.5) ? frain_one(tc, Tt, 13.3, month) : 1.0);
     *snowfall = pn * (1 - f_rain);
     *rain = pn * f_rain;
 }
@@ -1201,6 +1317,7 @@ void orc_point(int nt, const int* doy, const int* year, const int* month, const 
     int monthly = opt ? opt->monthly_out : 0;
     double soil_info[12], wmax_r;
     orc_fragile_events(1);
+    orc_critical_events(1);
     orc_soil_info(soil_data, au, resolution, soil_info, &wmax_r); /* :96-115 */
 
     /* :120-128 */
@@ -1280,6 +1397,7 @@ void orc_point(int nt, const int* doy, const int* year, const int* month, const 
         aux->state0[4] = age[ns - 1];
         memcpy(aux->state1, state_end, sizeof(state_end));
         aux->fragile = (int)orc_fragile_events(0);
+        aux->critical = (int)orc_critical_events(0);
     }
 
     if (!monthly) {
@@ -1420,6 +1538,95 @@ void orc_grid_transient(int ncell, int nt, const int* doy, const int* year, cons
         state[3 * (size_t)ncell + c] = td;
         state[4 * (size_t)ncell + c] = nd;
         if (fragile) fragile[c] = (int)orc_fragile_events(0);
+    }
+}
+
+
+/* Transient loop with the conditioning monitors the parity tests need (TEST INFRASTRUCTURE).
+ *   out11   wn, ro, pet, aet, snow, cond, bflow, netr, qin_prev, tdrain, snwage : each [nt][ncell]
+ *           or NULL (the 11 series of SPLASH::run_all, src/SPLASH.cpp:1913-1915)
+ *   prev    NULL: the state is carried from day to day (a trajectory, as run_all does).
+ *           non-NULL [5][nt][ncell] (wn, snow, qin, td, nd AFTER day t, e.g. from another
+ *           implementation): day t starts from prev[.][t-1] (day 0 from `state`), i.e. every
+ *           cell-day is an independent one-day transition ("one-step" parity: a difference on
+ *           one day cannot propagate into the following days).
+ *   events  optional [nt][ncell] bit mask of the cell-days on which the reference's own result is
+ *           rounding noise (DESIGN.md "Conditioning"):
+ *             bit0 noise-level drainage denominator (src/SPLASH.cpp:1422, :1472)
+ *             bit1 sun grazing the slope: 0 < hs < hs_lim_deg (src/SOLAR.cpp:149-165, :223)
+ *             bit2 the bucket's overflow residual decides the drainage branch: 0 < |R| < 1e-10
+ *                  after `R -= ro_d` (src/SPLASH.cpp:1386-1390, :1470)
+ *             bit3 the critical end of bit0: zero-or-one-ulp transmittance, sticky infinite
+ *                  drainage time or not (see orc_critical_events)
+ *   hs_out  optional [nt][ncell] float: hs in degrees (evidence tables)                       */
+void orc_grid_transient2(int ncell, int nt, const int* doy, const int* year, const int* month,
+                         const double* sw_in, const double* tc, const double* pn,
+                         const double* lat, const double* elev, const double* slop,
+                         const double* asp, const double* soil_info, const double* Tt,
+                         double* state, const double* prev, double* const out11[11],
+                         unsigned char* events, double hs_lim_deg, float* hs_out, int n_threads)
+{
+    int nthreads = n_threads > 0 ? n_threads : orc_max_threads();
+    (void)nthreads;
+    const size_t N = (size_t)ncell, plane = (size_t)nt * N;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
+#endif
+    for (int c = 0; c < ncell; c++) {
+        double si[12];
+        for (int k = 0; k < 12; k++) si[k] = soil_info[(size_t)k * N + c];
+        double wn = state[c], swe = state[N + c], qin = state[2 * N + c];
+        double td = state[3 * N + c], nd = state[4 * N + c];
+        orc_smr ds;
+        orc_etr dv;
+        for (int t = 0; t < nt; t++) {
+            size_t k = (size_t)t * N + c;
+            if (prev && t > 0) {
+                size_t kp = k - N;
+                wn = prev[kp];
+                swe = prev[plane + kp];
+                qin = prev[2 * plane + kp];
+                td = prev[3 * plane + kp];
+                nd = prev[4 * plane + kp];
+            }
+            double rain, snf;
+            rain_snow_one(tc[k], pn[k], month[t], lat[c], elev[c], Tt[c], &rain, &snf);
+            orc_fragile_events(1);
+            orc_critical_events(1);
+            orc_run_one_day(lat[c], elev[c], doy[t], year[t], wn, sw_in[k], tc[k], rain, slop[c],
+                            asp[c] /* already asp-180 */, swe, snf, si, qin, td, nd, &ds, &dv);
+            if (events) {
+                unsigned char e = 0;
+                double hs = orc_last_hs(), R = orc_debug[6];
+                if (orc_fragile_events(0) > 0) e |= 1;
+                if (orc_critical_events(0) > 0) e |= 8;
+                if (hs > 0.0 && hs < hs_lim_deg) e |= 2;
+                if (R != 0.0 && fabs(R) < 1e-10) e |= 4;
+                events[k] = e;
+            }
+            if (hs_out) hs_out[k] = (float)orc_last_hs();
+            if (out11[0]) out11[0][k] = ds.sm;
+            if (out11[1]) out11[1][k] = ds.ro;
+            if (out11[2]) out11[2][k] = dv.pet;
+            if (out11[3]) out11[3][k] = dv.aet;
+            if (out11[4]) out11[4][k] = ds.swe;
+            if (out11[5]) out11[5][k] = dv.cond;
+            if (out11[6]) out11[6][k] = ds.bflow;
+            if (out11[7]) out11[7][k] = dv.rn_d / 1e6;
+            if (out11[8]) out11[8][k] = ds.sqout;
+            if (out11[9]) out11[9][k] = ds.tdr;
+            if (out11[10]) out11[10][k] = ds.nd;
+            wn = ds.sm;
+            swe = ds.swe;
+            qin = ds.sqout;
+            td = ds.tdr;
+            nd = ds.nd;
+        }
+        state[c] = wn;
+        state[N + c] = swe;
+        state[2 * N + c] = qin;
+        state[3 * N + c] = td;
+        state[4 * N + c] = nd;
     }
 }
 

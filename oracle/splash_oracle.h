@@ -123,10 +123,12 @@ typedef struct {
     double state0[5]; /* wn, snow, qin, td, nd handed to run_all */
     double state1[5]; /* state after the last transient day */
     int fragile;      /* day steps whose drainage time came from a rounding-noise transmittance */
+    int critical;     /* ... of which zero-or-one-ulp: sticky infinite drainage time or not */
 } orc_cell_aux;
 
 /* count of such steps on the calling thread since the last reset (see splash_oracle.c) */
 long orc_fragile_events(int reset);
+long orc_critical_events(int reset);
 
 /*
  * splash.point for one cell (R/splash.point.R:29-225).  Forcing is read with a stride
@@ -159,6 +161,18 @@ void orc_grid_transient(int ncell, int nt, const int* doy, const int* year, cons
                         const double* asp, const double* soil_info /*[12][ncell]*/,
                         const double* Tt, double* state /*[5][ncell] in/out*/,
                         double* const out5[5], int n_threads, int* fragile /*[ncell] or NULL*/);
+
+/* the same loop with all 11 series of SPLASH::run_all, per-cell-day conditioning events and an
+ * optional one-step mode (every day restarted from a given state series): see the definition */
+void orc_grid_transient2(int ncell, int nt, const int* doy, const int* year, const int* month,
+                         const double* sw_in, const double* tc, const double* pn,
+                         const double* lat, const double* elev, const double* slop,
+                         const double* asp, const double* soil_info, const double* Tt,
+                         double* state, const double* prev /*[5][nt][ncell] or NULL*/,
+                         double* const out11[11], unsigned char* events /*[nt][ncell] or NULL*/,
+                         double hs_lim_deg, float* hs_out /*[nt][ncell] or NULL*/, int n_threads);
+double orc_last_hs(void);
+double* orc_debug_ptr(void);
 
 /* ---- synthetic inputs (SURVEY.md 8d spec; splitmix64 counter RNG) ---- */
 double orc_synth_u(uint64_t seed, uint64_t stream, uint64_t cell, uint64_t day);

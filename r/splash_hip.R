@@ -31,25 +31,117 @@ splash.point <- function(sw_in, tc, pn, lat, elev, slop = 0, asp = 0, soil_data,
 
 # Replaces clFun + the send/receive loop of R/splash.grid.R:277-400: one .Call per row block.
 # `bs` is raster::blockSize(sw_in, ...) as in the reference; the static rasters (lat, terraines,
-# resolution, Au) are prepared exactly as R/splash.grid.R:76-110 does.
+# resolution, Au) are prepared exactly as R/splash.grid.R:76-110 does.  `devices`: HIP ordinals the
+# block is split over inside the call (this is what stands where the SOCK cluster stood).
 .splash_grid_block <- function(i, bs, sw_in, tc, pn, elev, lat, terraines, soil, resolution, Au,
-                               ztime, monthly_out, device = 0L) {
+                               ztime, monthly_out, devices = 0L) {
   gv <- function(x) raster::getValues(x, bs$row[i], bs$nrows[i])
   tf <- .time_fields(ztime)
   stat <- cbind(gv(lat), gv(elev), gv(terraines[[1]]), gv(terraines[[2]]), gv(resolution))
   .Call("C_splash_grid_run", gv(sw_in), gv(tc), gv(pn), stat, gv(soil), gv(Au),
-        tf$doy, tf$year, tf$month, monthly_out, as.integer(device))
+        tf$doy, tf$year, tf$month, monthly_out, as.integer(devices))
   # -> list(wn, ro, pet, aet, snow, cond, bflow, netr, sm_lim) of [ncell_blk x nl] matrices, which
   #    writeValues(brick, m, bs$row[i]) / matXX[startind[i]:endind[i], ] <- m consume unchanged
   #    (R/splash.grid.R:370-392)
 }
 
-# unSWC (R/unsSWC.R:14): same signature; the analytical integral runs in the HIP library
+# file stem, NetCDF variable, unit and long name of the nine result bricks, in the order
+# .splash_grid_block returns them (names as R/splash.grid.R:190-216 and :449)
+.splash_outputs <- data.frame(
+  key  = c("wn",  "ro", "pet", "aet", "snow", "cond", "bflow", "netr",   "sm_lim"),
+  stem = c("swc", "ro", "pet", "aet", "swe",  "cond", "bflow", "netrad", "sm_lim"),
+  var  = c("wm",  "ro", "pet", "aet", "swe",  "cond", "bflow", "netrad", "sm_lim"),
+  unit = c("mm",  "mm", "mm",  "mm",  "mm",   "mm",   "mm",    "MJ",     "mm"),
+  long = c("Soil water content", "surface runoff", "potential evapotranspiration",
+           "actual evapotranspiration", "snow water equivalent", "condensation", "drainage",
+           "daytime net radiation", "fraction of available water content"),
+  ret  = c("wn", "ro", "pet", "aet", "snow", "bflow", "cond", "netrad", "sm_lim"),  # names of :449
+  stringsAsFactors = FALSE)
+
+# splash.grid with the reference's signature (R/splash.grid.R:28).  Static preparation (upslope
+# area, latitude, slope/aspect, resolution: R/splash.grid.R:76-110) and the output time axis
+# (:145-181) are the package's own code and are reused through `prep`; what changes is the middle:
+# no cluster, no per-cell mapply -- every row block goes through ONE .Call into the HIP library,
+# which splits it over `devices` itself.  Blocks are sized by raster::blockSize as before, so
+# memory use on the R side is unchanged.
+splash.grid <- function(sw_in, tc, pn, elev, soil, outdir = getwd(),
+                        tmpdir = dirname(raster::rasterTmpFile()),
+                        sim.control = list(monthly_out = TRUE, inmem = FALSE), devices = 0L,
+                        prep = splash.grid.statics(elev, tmpdir)) {
+  raster::rasterOptions(tolerance = 0.5)
+  raster::compareRaster(sw_in, tc, pn, elev, soil, extent = TRUE, crs = TRUE, res = TRUE,
+                        orig = FALSE, rotation = FALSE, values = FALSE, stopiffalse = FALSE,
+                        showwarning = TRUE)
+  ztime <- raster::getZ(pn)
+  if (!methods::is(ztime[1], "Date")) stop("layer dates (setZ) of class Date are required")
+  yrs <- as.numeric(unique(format(ztime, "%Y")))
+  first <- as.Date(paste(yrs[1], 1, 1, sep = "-"))
+  last <- as.Date(paste(yrs[length(yrs)], 12, 31, sep = "-"))
+  monthly <- isTRUE(sim.control$monthly_out)
+  ztime_out <- seq(first, last, by = if (monthly) "month" else "day")   # :161-181
+  nl <- length(ztime_out)
+  if (!monthly && nl != length(ztime)) stop("daily output needs whole calendar years of input")
+  text <- if (monthly) "monthly" else "daily"
+  inmem <- isTRUE(sim.control$inmem)
+  bricks <- lapply(seq_len(nrow(.splash_outputs)), function(k) {
+    o <- .splash_outputs[k, ]
+    if (inmem) return(NULL)
+    b <- raster::brick(elev, values = FALSE, nl = nl, format = "CDF", overwrite = TRUE,
+                       filename = file.path(outdir, paste0("SPLASH_v2.0_", o$stem, "_", text, "_",
+                                                           yrs[1], "-", yrs[length(yrs)], ".nc")),
+                       varname = o$var, varunit = o$unit, longname = o$long, xname = "lon",
+                       yname = "lat", zname = "time")
+    raster::writeStart(raster::setZ(b, ztime_out), filename = raster::filename(b), overwrite = TRUE)
+  })
+  mats <- if (inmem) lapply(1:9, function(k) matrix(NA_real_, raster::ncell(elev), nl)) else NULL
+  bs <- raster::blockSize(sw_in, minblocks = 2)
+  pb <- utils::txtProgressBar(min = 0, max = bs$n, style = 3)
+  for (i in seq_len(bs$n)) {
+    res <- .splash_grid_block(i, bs, sw_in, tc, pn, elev, prep$lat, prep$terraines, soil,
+                              prep$resolution, prep$Au, ztime, monthly, devices)
+    for (k in 1:9) {
+      if (inmem) {
+        rows <- raster::cellFromRow(elev, bs$row[i]:(bs$row[i] + bs$nrows[i] - 1))
+        mats[[k]][rows, ] <- res[[k]]
+      } else {
+        bricks[[k]] <- raster::writeValues(bricks[[k]], res[[k]], bs$row[i])
+      }
+    }
+    utils::setTxtProgressBar(pb, i)
+  }
+  close(pb)
+  out <- lapply(1:9, function(k) {
+    if (inmem) {
+      b <- raster::brick(nrows = nrow(elev), ncols = ncol(elev), crs = raster::crs(elev), nl = nl)
+      raster::extent(b) <- raster::extent(elev)
+      raster::setZ(raster::setValues(b, mats[[k]]), ztime_out)
+    } else {
+      raster::writeStop(bricks[[k]])
+    }
+  })
+  names(out) <- .splash_outputs$ret
+  out[c("wn", "ro", "pet", "aet", "snow", "bflow", "cond", "netrad", "sm_lim")]      # :449
+}
+
+# the static rasters of R/splash.grid.R:76-110 with the package's own helpers (upslope_area,
+# raster::terrain, raster::area); NA slopes of valid cells are flats (:107)
+splash.grid.statics <- function(elev, tmpdir = tempdir()) {
+  resolution <- sqrt(raster::area(elev)) * 1000
+  Au <- upslope_area(elev, resolution)
+  lat <- raster::init(elev, "y")
+  lat[is.na(elev)] <- NA
+  terraines <- raster::terrain(elev, opt = c("slope", "aspect"), unit = "degrees")
+  terraines[is.na(terraines) & !is.na(elev)] <- 0
+  list(lat = lat, terraines = terraines, resolution = resolution, Au = Au)
+}
+
+# unSWC (R/unsSWC.R:14): same signature; the analytical integral runs in the HIP library.
+# One site = one "cell": wn is handed over as a [1 x nt] matrix, soil as [1 x 6].
 unSWC <- function(soil_data, uns_depth, wn) {
-  res <- .Call("C_splash_unswc_run", matrix(as.numeric(wn), ncol = 1), matrix(as.numeric(soil_data), nrow = 1),
-               as.numeric(uns_depth))
-  result <- list(wn_z = res$wn_z[, 1], wtd = res$wtd[, 1])
+  res <- .Call("C_splash_unswc_run", matrix(as.numeric(wn), nrow = 1),
+               matrix(as.numeric(soil_data), nrow = 1), as.numeric(uns_depth))
+  result <- list(wn_z = res$wn_z[1, ], wtd = res$wtd[1, ])
   if (xts::is.xts(wn)) result <- mapply(FUN = xts::xts, result, MoreArgs = list(order.by = time(wn)), SIMPLIFY = FALSE)
-  result$theta_i <- if (xts::is.xts(wn)) xts::xts(res$theta_i[, 1], time(wn)) else res$theta_i[, 1]
+  result$theta_i <- if (xts::is.xts(wn)) xts::xts(res$theta_i[1, ], time(wn)) else res$theta_i[1, ]
   result
 }

@@ -12,6 +12,8 @@
  *
  * Build inside the package:   PKG_LIBS = -L<dir> -lrsplash_hip   (src/Makevars)
  */
+#include <string.h>
+
 #include <R.h>
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
@@ -23,7 +25,7 @@
  * stat: numeric matrix [ncell x 5] = lat, elev, slop, asp, resolution; soil [ncell x 6];
  * au [ncell x 3] or NULL; doy/year/month: integer(nt); monthly: logical(1). */
 SEXP C_splash_grid_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP stat, SEXP soil, SEXP au, SEXP doy,
-                       SEXP year, SEXP month, SEXP monthly, SEXP device)
+                       SEXP year, SEXP month, SEXP monthly, SEXP devices)
 {
     SEXP dim = getAttrib(sw_in, R_DimSymbol);
     if (isNull(dim) || LENGTH(dim) != 2) error("sw_in must be a [ncell x nt] matrix");
@@ -34,7 +36,13 @@ SEXP C_splash_grid_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP stat, SEXP soil, SEXP 
     if ((size_t)XLENGTH(tc) != ncell * nt || (size_t)XLENGTH(pn) != ncell * nt)
         error("tc and pn must have the dimensions of sw_in");
 
+    if ((size_t)XLENGTH(stat) != 5 * ncell) error("stat must be a [ncell x 5] matrix");
+    if ((size_t)XLENGTH(soil) != 6 * ncell) error("soil must be a [ncell x 6] matrix");
+    if (!isNull(au) && (size_t)XLENGTH(au) != 3 * ncell) error("Au must be a [ncell x 3] matrix");
+    if (!isInteger(devices) || LENGTH(devices) < 1) error("devices must be integer(>= 1)");
+
     splash_grid_in in;
+    memset(&in, 0, sizeof in);
     in.ncell = ncell;
     in.nt = nt;
     in.doy = INTEGER(doy);
@@ -53,9 +61,11 @@ SEXP C_splash_grid_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP stat, SEXP soil, SEXP 
     in.au = isNull(au) ? NULL : REAL(au);
 
     splash_opts opt;
+    memset(&opt, 0, sizeof opt);
     opt.monthly_out = asLogical(monthly);
-    opt.device = asInteger(device);
-    opt.max_cells_per_launch = 0;
+    opt.device = INTEGER(devices)[0];
+    opt.n_devices = LENGTH(devices);   /* > 1: the block is split over these GPUs inside the call */
+    opt.devices = INTEGER(devices);
 
     /* number of output steps: months present in the calendar, or days */
     int nmonth = 1;
@@ -67,15 +77,13 @@ SEXP C_splash_grid_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP stat, SEXP soil, SEXP 
                                   "sm_lim", ""};
     SEXP res = PROTECT(mkNamed(VECSXP, names));
     splash_grid_out out;
+    memset(&out, 0, sizeof out); /* no state_end / diag / aux */
     for (int k = 0; k < SPLASH_NOUT; k++) {
         SEXP m = PROTECT(allocMatrix(REALSXP, (int)ncell, nt_out)); /* [ncell x nt_out] */
         out.out[k] = REAL(m);
         SET_VECTOR_ELT(res, k, m);
         UNPROTECT(1);
     }
-    out.state_end = NULL;
-    out.diag = NULL;
-    out.aux = NULL;
 
     char err[512];
     int rc = splash_grid_run(&in, &opt, &out, err, sizeof err);
@@ -125,13 +133,15 @@ SEXP C_splash_point_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP lat, SEXP elev, SEXP 
 }
 
 /* unSWC / unSWC.grid (R/unsSWC.R:14, R/unsSWC.grid.R:14): wn [ncell x nt] matrix (one column per
- * time step as getValues() gives it), soil [ncell x 6], uns_depth numeric(1) */
+ * time step as getValues() gives it; one site = [1 x nt]), soil [ncell x 6], uns_depth numeric(1) */
 SEXP C_splash_unswc_run(SEXP wn, SEXP soil, SEXP uns_depth)
 {
     SEXP dim = getAttrib(wn, R_DimSymbol);
     if (isNull(dim) || LENGTH(dim) != 2) error("wn must be a [ncell x nt] matrix");
     const size_t ncell = (size_t)INTEGER(dim)[0];
     const int nt = INTEGER(dim)[1];
+    if ((size_t)XLENGTH(soil) != 6 * ncell)
+        error("soil must be [ncell x 6]: %d cells in wn, %d soil values", (int)ncell, (int)XLENGTH(soil));
     static const char* names[] = {"wn_z", "wtd", "theta_i", ""};
     SEXP res = PROTECT(mkNamed(VECSXP, names));
     double* o[3];

@@ -4,32 +4,40 @@ import os
 
 from .build import library_path
 
-NPAR, NSTATE, NOUT, NDIAG = 17, 5, 9, 6
+NPAR, NSTATE, NOUT, NDIAG, NEXTRA = 17, 5, 9, 6, 3
+DIAG_REC = (NDIAG + 1) * 2  # int64 limbs per (basin, month) record, see include/splash_hip.h
+EXTRA_NAMES = ("qin_prev", "tdrain", "snwage")
 OUT_NAMES = ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "sm_lim")
 DIAG_NAMES = ("precip", "aet", "ro", "bflow", "wn", "snow")
 
 _dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
+_lp = C.POINTER(C.c_int64)
 _vp = C.c_void_p
 
 
 class GridIn(C.Structure):
     _fields_ = [("ncell", C.c_size_t), ("nt", C.c_int), ("doy", _ip), ("year", _ip), ("month", _ip),
                 ("sw_in", _dp), ("tc", _dp), ("pn", _dp), ("lat", _dp), ("elev", _dp),
-                ("slop", _dp), ("asp", _dp), ("resolution", _dp), ("soil", _dp), ("au", _dp)]
+                ("slop", _dp), ("asp", _dp), ("resolution", _dp), ("soil", _dp), ("au", _dp),
+                ("basin", _ip), ("n_basin", C.c_int),
+                ("sw_in_f32", _fp), ("tc_f32", _fp), ("pn_f32", _fp)]
 
 
 class Opts(C.Structure):
-    _fields_ = [("monthly_out", C.c_int), ("device", C.c_int), ("max_cells_per_launch", C.c_size_t)]
+    _fields_ = [("monthly_out", C.c_int), ("device", C.c_int), ("max_cells_per_launch", C.c_size_t),
+                ("n_devices", C.c_int), ("devices", _ip)]
 
 
 class GridOut(C.Structure):
-    _fields_ = [("out", _dp * NOUT), ("state_end", _dp), ("diag", _dp), ("aux", _dp)]
+    _fields_ = [("out", _dp * NOUT), ("state_end", _dp), ("diag", _dp), ("aux", _dp),
+                ("diag_acc", _lp)]
 
 
 class DevOut(C.Structure):
-    _fields_ = [("out", _vp * NOUT), ("ldo", C.c_size_t), ("monthly", C.c_int), ("diag", _vp),
-                ("diag_work", _vp)]
+    _fields_ = [("out", _vp * NOUT), ("ldo", C.c_size_t), ("monthly", C.c_int),
+                ("extra", _vp * NEXTRA), ("diag_acc", _vp), ("basin", _vp), ("n_basin", C.c_int)]
 
 
 def _load():
@@ -56,8 +64,12 @@ def _load():
     L.splash_dev_spin_up_work_size.argtypes = [C.c_size_t]
     L.splash_dev_spin_up.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t, _vp, _vp,
                                      C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp]
-    L.splash_dev_diag_work_size.restype = C.c_size_t
-    L.splash_dev_diag_work_size.argtypes = [C.c_size_t, C.c_int]
+    L.splash_dev_diag_acc_size.restype = C.c_size_t
+    L.splash_dev_diag_acc_size.argtypes = [C.c_int, C.c_int]
+    L.splash_dev_diag_finalize.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp]
+    L.splash_diag_finalize_host.argtypes = [_lp, C.c_int, C.c_int, _dp, _dp]
+    L.splash_diag_finalize_host.restype = None
+    L.splash_dev_infiltration_probe.argtypes = [C.c_size_t] + [_dp] * 6
     L.splash_dev_run_all.argtypes = [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, C.c_size_t,
                                      _vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(DevOut), _vp]
     L.splash_dev_synth_statics.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_size_t,
@@ -95,7 +107,8 @@ SYMBOLS = (
     "splash_calendar_create", "splash_calendar_destroy", "splash_calendar_nt",
     "splash_calendar_nmonth", "splash_calendar_orbit", "splash_orbit_day", "splash_dev_soil_hydro",
     "splash_dev_snow_threshold", "splash_dev_spin_up_work_size", "splash_dev_spin_up",
-    "splash_dev_diag_work_size",
+    "splash_dev_diag_acc_size", "splash_dev_diag_finalize", "splash_diag_finalize_host",
+    "splash_dev_infiltration_probe",
     "splash_dev_run_all", "splash_dev_synth_statics", "splash_dev_synth_forcing",
     "splash_dev_evap_batch", "splash_dev_math_probe", "splash_dev_unswc", "splash_unswc_run",
     "splash_grid_run", "splash_point_run", "splash_mod_spin_up",

@@ -14,7 +14,8 @@ import datetime as _dt
 import numpy as np
 
 from . import _lib
-from ._lib import DIAG_NAMES, NDIAG, NOUT, NPAR, NSTATE, OUT_NAMES, SplashError, check, lib
+from ._lib import (DIAG_NAMES, DIAG_REC, EXTRA_NAMES, NDIAG, NEXTRA, NOUT, NPAR, NSTATE, OUT_NAMES,
+                   SplashError, check, lib)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -103,7 +104,8 @@ def splash_point(sw_in, tc, pn, lat, elev, slop=0.0, asp=0.0, soil_data=None, Au
 # ---------------------------------------------------------------------------- splash.grid
 def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=250.0,
                 time_index=None, sim_control=None, outputs=OUT_NAMES, device=0,
-                max_cells_per_launch=0, want_aux=False, want_diag=False, outdir=None, lon=None):
+                max_cells_per_launch=0, want_aux=False, want_diag=False, outdir=None, lon=None,
+                basin=None, n_basin=0, devices=None):
     """R/splash.grid.R:28 on arrays.  sw_in/tc/pn: [nt, ncell] (or [nt, H, W]) daily rasters;
     elev/lat/slop/asp: [ncell]; soil: [6, ncell]; Au: [3, ncell] (area, ncellin, ncellout) or
     None.  The static rasters the reference derives with raster/GDAL/TauDEM (lat, slope, aspect,
@@ -113,11 +115,18 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     With `outdir` (and [nt, H, W] rasters) the bricks are also written as NetCDF files named, and
     with variables named, as the reference names them (sim.control$inmem = FALSE,
     R/splash.grid.R:186-216; rsplash_amd/io.py); `lon` [W] gives the x axis (default: column index),
-    the y axis is the latitude raster's first column.  Paths come back under "files"."""
+    the y axis is the latitude raster's first column.  Paths come back under "files".
+    Forcing arrays of dtype float32 are handed over as they are (single-precision transport, widened
+    on the device; the reference's rasters are FLT4S) -- the arithmetic is FP64 either way.
+    basin/n_basin: optional integer basin id per cell -> want_diag totals per basin
+    ([n_basin, nmonth] per quantity).  devices: list of HIP ordinals to split the cells over inside
+    the one call (one host thread per entry; the same ordinal may repeat)."""
     if time_index is None:
         raise ValueError("time_index is required")
     monthly = True if sim_control is None else bool(sim_control.get("monthly_out", True))
-    sw = np.asarray(sw_in, dtype=np.float64)
+    f32 = all(getattr(x, "dtype", None) == np.float32 for x in (sw_in, tc, pn))
+    fdt = np.float32 if f32 else np.float64
+    sw = np.asarray(sw_in, dtype=fdt)
     shp = sw.shape[1:]
     nt = sw.shape[0]
     ncell = int(np.prod(shp))
@@ -129,15 +138,27 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
         a = np.ascontiguousarray(np.asarray(a, dtype=np.float64)).reshape(lead + (ncell,))
         return a, a.ctypes.data_as(_dp)
 
-    f = [flat(x, (nt,)) for x in (sw, tc, pn)]
+    def flatf(a):
+        a = np.ascontiguousarray(np.asarray(a, dtype=fdt)).reshape((nt, ncell))
+        return a, a.ctypes.data_as(C.POINTER(C.c_float) if f32 else _dp)
+
+    f = [flatf(x) for x in (sw, tc, pn)]
     st = [flat(np.broadcast_to(np.asarray(x, dtype=np.float64), shp) if np.ndim(x) == 0 else x, ())
           for x in (lat, elev, slop, asp, resolution)]
     so = flat(soil, (6,))
     au = flat(Au, (3,)) if Au is not None else None
     ia = [_i(x) for x in (doy, year, month)]
-    gin = _lib.GridIn(ncell, nt, ia[0][1], ia[1][1], ia[2][1], f[0][1], f[1][1], f[2][1],
+    gin = _lib.GridIn(ncell, nt, ia[0][1], ia[1][1], ia[2][1],
+                      None if f32 else f[0][1], None if f32 else f[1][1], None if f32 else f[2][1],
                       st[0][1], st[1][1], st[2][1], st[3][1], st[4][1], so[1],
                       au[1] if au else None)
+    if f32:
+        gin.sw_in_f32, gin.tc_f32, gin.pn_f32 = f[0][1], f[1][1], f[2][1]
+    nbas = 1
+    if basin is not None:
+        bas = np.ascontiguousarray(np.asarray(basin, dtype=np.int32)).reshape(ncell)
+        nbas = int(n_basin) if n_basin else int(bas.max()) + 1
+        gin.basin, gin.n_basin = bas.ctypes.data_as(_ip), nbas
     nm = int(month_ids(year, month)[-1]) + 1
     nt_out = nm if monthly else nt
     res = {k: np.empty((nt_out,) + shp) for k in outputs}
@@ -151,9 +172,14 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
         aux = np.empty((4,) + shp)
         gout.aux = aux.ctypes.data_as(_dp)
     if want_diag:
-        diag = np.empty((nm, NDIAG))
+        diag = np.empty((nbas, nm, NDIAG))
         gout.diag = diag.ctypes.data_as(_dp)
-    opt = _lib.Opts(int(monthly), int(device), int(max_cells_per_launch))
+        acc = np.zeros((nbas, nm, DIAG_REC), np.int64)
+        gout.diag_acc = acc.ctypes.data_as(C.POINTER(C.c_int64))
+    opt = _lib.Opts(int(monthly), int(device), int(max_cells_per_launch), 0, None)
+    if devices is not None:
+        dv = np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
+        opt.n_devices, opt.devices = len(dv), dv.ctypes.data_as(_ip)
     err = C.create_string_buffer(512)
     rc = lib.splash_grid_run(C.byref(gin), C.byref(opt), C.byref(gout), err, 512)
     if rc:
@@ -169,7 +195,11 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     if want_aux:
         res["aux"] = dict(Tt=aux[0], AI=aux[1], passes1=aux[2], passes2=aux[3])
     if want_diag:
-        res["diag"] = {k: diag[:, i] for i, k in enumerate(DIAG_NAMES)}
+        # [nmonth] per quantity for the whole grid, [n_basin, nmonth] with basin ids
+        res["diag"] = {k: (diag[:, :, i] if basin is not None else diag[0, :, i])
+                       for i, k in enumerate(DIAG_NAMES)}
+        res["diag_acc"] = acc
+        res["diag_cells"] = acc[:, :, 2 * NDIAG] if basin is not None else acc[0, :, 2 * NDIAG]
     return res
 
 
@@ -367,20 +397,55 @@ def dev_spin_up(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, wo
                                  stream), "splash_dev_spin_up")
 
 
-def diag_work_size(ncell, nmonth):
-    return lib.splash_dev_diag_work_size(ncell, nmonth)
+def diag_acc_size(n_basin, nmonth):
+    """bytes of the exact water-balance accumulators: int64 [n_basin][nmonth][NDIAG+1][2]"""
+    return lib.splash_dev_diag_acc_size(int(n_basin), int(nmonth))
+
+
+def dev_diag_finalize(diag_acc, n_basin, nmonth, diag, counts=None, stream=None):
+    """limbs -> doubles on the device: diag [n_basin, nmonth, NDIAG]"""
+    check(lib.splash_dev_diag_finalize(_ptr(diag_acc), int(n_basin), int(nmonth), _ptr(diag),
+                                       _ptr(counts), stream), "splash_dev_diag_finalize")
+
+
+def diag_finalize_host(acc):
+    """limbs [n_basin, nmonth, NDIAG+1, 2] (numpy int64) -> (totals [n_basin, nmonth, NDIAG],
+    counts [n_basin, nmonth, 2])"""
+    a = np.ascontiguousarray(acc, dtype=np.int64)
+    nb, nm = a.shape[0], a.shape[1]
+    out, cnt = np.empty((nb, nm, NDIAG)), np.empty((nb, nm, 2))
+    lib.splash_diag_finalize_host(a.ctypes.data_as(C.POINTER(C.c_int64)), nb, nm,
+                                  out.ctypes.data_as(_dp), cnt.ctypes.data_as(_dp))
+    return out, cnt
+
+
+def infiltration_probe(cellpar, wn, ksat_visc, P):
+    """test hook: the day loop's own moist_surf()/inf_GA() -> (theta_surf, infiltration)"""
+    cp, cpp = _d(cellpar)
+    n = cp.shape[1]
+    a = [_d(x) for x in (wn, ksat_visc, P)]
+    th, inf = np.empty(n), np.empty(n)
+    check(lib.splash_dev_infiltration_probe(n, cpp, a[0][1], a[1][1], a[2][1],
+                                            th.ctypes.data_as(_dp), inf.ctypes.data_as(_dp)),
+          "splash_dev_infiltration_probe")
+    return th, inf
 
 
 def dev_run_all(cal, t0, nt, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, out_ptrs,
-                ldo, monthly=False, diag=None, diag_work=None, stream=None):
-    """out_ptrs: dict name -> tensor/pointer for the series to store (others are skipped)."""
+                ldo, monthly=False, diag_acc=None, basin=None, n_basin=0, stream=None):
+    """out_ptrs: dict name -> tensor/pointer for the series to store (others are skipped); the
+    names of OUT_NAMES plus, daily mode only, qin_prev / tdrain / snwage.
+    diag_acc: int64 tensor [n_basin, cal.nmonth, NDIAG+1, 2] the water-balance totals are ADDED to."""
     o = _lib.DevOut()
     for i, k in enumerate(OUT_NAMES):
         o.out[i] = _ptr(out_ptrs.get(k)) if out_ptrs else None
+    for i, k in enumerate(EXTRA_NAMES):
+        o.extra[i] = _ptr(out_ptrs.get(k)) if out_ptrs else None
     o.ldo = ldo
     o.monthly = int(bool(monthly))
-    o.diag = _ptr(diag)
-    o.diag_work = _ptr(diag_work)
+    o.diag_acc = _ptr(diag_acc)
+    o.basin = _ptr(basin)
+    o.n_basin = int(n_basin)
     check(lib.splash_dev_run_all(cal.h, t0, nt, ncell, _ptr(sw_in), _ptr(tc), _ptr(pn), ldf,
                                  _ptr(Tt), _ptr(cellpar), ldp, _ptr(state), lds, C.byref(o),
                                  stream), "splash_dev_run_all")

@@ -144,6 +144,12 @@ struct splash_calendar {
     int nt = 0, nmonth = 0, device = 0;
     std::vector<DayRec> host;
     DayRec* dev = nullptr;
+    // spin-up table (nt >= 365 only): the reference spins up on quick_run(i+1, y[1], ...) --
+    // day-of-year 1..365 of the FIRST year whatever date the series starts on (src/SPLASH.cpp:1658,
+    // 1674; R/splash.point.R:141-152) -- while the rain/snow split of those 365 records keeps the
+    // months of their real dates (R/splash.point.R:124-128 runs before the spin-up)
+    std::vector<DayRec> spin_host;
+    DayRec* spin_dev = nullptr;
 };
 
 extern "C" int splash_calendar_create(int nt, const int* doy, const int* year, const int* month,
@@ -180,10 +186,24 @@ extern "C" int splash_calendar_create(int nt, const int* doy, const int* year, c
         d.mdays = cnt[d.month_id];
         if (t == nt - 1 || cal->host[t + 1].month_id != d.month_id) d.flags |= 1;
     }
+    if (nt >= 365) {
+        cal->spin_host.assign(cal->host.begin(), cal->host.begin() + 365);
+        for (int i = 0; i < 365; i++) {
+            DayRec& d = cal->spin_host[i];
+            orbit_day(i + 1, year[0], d.dr, d.sd, d.cd);
+            d.doy = i + 1;
+        }
+    }
     (void)hipGetDevice(&cal->device);
-    hipError_t e = hipMalloc((void**)&cal->dev, sizeof(DayRec) * (size_t)nt);
+    const size_t nspin = cal->spin_host.size();
+    hipError_t e = hipMalloc((void**)&cal->dev, sizeof(DayRec) * ((size_t)nt + nspin));
     if (e == hipSuccess)
         e = hipMemcpy(cal->dev, cal->host.data(), sizeof(DayRec) * (size_t)nt, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nspin) {
+        cal->spin_dev = cal->dev + nt;
+        e = hipMemcpy(cal->spin_dev, cal->spin_host.data(), sizeof(DayRec) * nspin,
+                      hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         if (cal->dev) (void)hipFree(cal->dev);
         delete cal;
@@ -289,7 +309,7 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
     uint32_t* cnt = (uint32_t*)(w + o_cnt);
     HIP_TRY(hipMemsetAsync(cnt, 0, 64, s), nullptr, 0);
     SpinPhaseArgs a{};
-    a.days = cal->dev;
+    a.days = cal->spin_dev; // doy 1..365 of the first year, real months (see splash_calendar)
     a.n = 365;
     a.ncell = ncell;
     a.sw = sw_in;
@@ -321,9 +341,39 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
     return SPLASH_OK;
 }
 
-extern "C" size_t splash_dev_diag_work_size(size_t ncell, int nmonth)
+extern "C" size_t splash_dev_diag_acc_size(int n_basin, int nmonth)
 {
-    return run_all_blocks(ncell) * (size_t)std::max(nmonth, 0) * SPLASH_NDIAG_K * sizeof(double);
+    return (size_t)std::max(n_basin, 1) * (size_t)std::max(nmonth, 0) * SPLASH_DIAG_REC * sizeof(int64_t);
+}
+
+extern "C" int splash_dev_diag_finalize(const int64_t* diag_acc, int n_basin, int nmonth,
+                                        double* diag, double* counts, void* stream)
+{
+    REQ(diag_acc && diag && nmonth >= 0, "diag_finalize: NULL argument");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    HIP_TRY(launch_diag_finalize((const long long*)diag_acc, std::max(n_basin, 1) * nmonth, diag,
+                                 counts, (hipStream_t)stream), nullptr, 0);
+    return SPLASH_OK;
+}
+
+// the same conversion on the host: value = limb0/2^16 + limb1/2^48 (exact up to the final rounding)
+extern "C" void splash_diag_finalize_host(const int64_t* acc, int n_basin, int nmonth, double* diag,
+                                          double* counts)
+{
+    const size_t n_rec = (size_t)std::max(n_basin, 1) * (size_t)std::max(nmonth, 0);
+    for (size_t i = 0; i < n_rec; i++) {
+        const int64_t* r = acc + i * SPLASH_DIAG_REC;
+        for (int q = 0; q < SPLASH_NDIAG; q++) {
+            const double hi = (double)r[2 * q];
+            const double lo = (double)(r[2 * q] - (int64_t)hi);
+            diag[i * SPLASH_NDIAG + q] = hi * (1.0 / 65536.0) +
+                                         (lo * (1.0 / 65536.0) + (double)r[2 * q + 1] * (1.0 / 281474976710656.0));
+        }
+        if (counts) {
+            counts[2 * i] = (double)r[2 * SPLASH_NDIAG];
+            counts[2 * i + 1] = (double)r[2 * SPLASH_NDIAG + 1];
+        }
+    }
 }
 
 extern "C" int splash_dev_run_all(const splash_calendar* cal, int t0, int nt, size_t ncell,
@@ -335,7 +385,10 @@ extern "C" int splash_dev_run_all(const splash_calendar* cal, int t0, int nt, si
     REQ(t0 >= 0 && nt >= 0 && t0 + nt <= cal->nt, "run_all: day range outside the calendar");
     REQ(ldf >= ncell && ldp >= ncell && lds >= ncell && out->ldo >= ncell,
         "run_all: leading dimension < ncell");
-    REQ(!out->diag || out->diag_work, "run_all: diag requested without diag_work");
+    REQ(!out->basin || out->diag_acc, "run_all: basin ids given without diag_acc");
+    REQ(!out->basin || out->n_basin > 0, "run_all: basin ids given with n_basin <= 0");
+    REQ(!(out->monthly && (out->extra[0] || out->extra[1] || out->extra[2])),
+        "run_all: the qin_prev/tdrain/snwage series are daily (monthly = 0)");
     REQ(ncell <= kMaxCellsPerLaunch, "run_all: more than 2^29-1 cells in one call (32-bit lane byte offsets)");
     if (int rc = need_device(nullptr, 0)) return rc;
     if (nt == 0 || ncell == 0) return SPLASH_OK;
@@ -354,22 +407,17 @@ extern "C" int splash_dev_run_all(const splash_calendar* cal, int t0, int nt, si
     a.state = state;
     a.lds = lds;
     for (int k = 0; k < SPLASH_NOUT; k++) a.out[k] = out->out[k];
+    for (int k = 0; k < SPLASH_NEXTRA; k++) a.extra[k] = out->extra[k];
     a.ldo = out->ldo;
     a.monthly = out->monthly;
     a.month0 = cal->host[t0].month_id;
     a.head_partial = (t0 > 0 && cal->host[t0 - 1].month_id == a.month0) ? 1 : 0;
     a.nmonth = cal->host[t0 + nt - 1].month_id - a.month0 + 1;
-    a.diag_part = nullptr;
-    hipStream_t s = (hipStream_t)stream;
-    if (out->diag) {
-        a.diag_part = out->diag_work;
-        HIP_TRY(hipMemsetAsync(out->diag_work, 0, splash_dev_diag_work_size(ncell, a.nmonth), s),
-                nullptr, 0);
-    }
-    HIP_TRY(launch_run_all(a, s), nullptr, 0);
-    if (out->diag)
-        HIP_TRY(launch_diag_reduce(a.diag_part, run_all_blocks(ncell), a.nmonth, out->diag, s),
-                nullptr, 0);
+    a.diag_acc = (long long*)out->diag_acc;
+    a.basin = out->basin;
+    a.n_basin = out->basin ? out->n_basin : 1;
+    a.nmonth_cal = cal->nmonth;
+    HIP_TRY(launch_run_all(a, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
 }
 
@@ -485,11 +533,41 @@ extern "C" int splash_dev_math_probe(size_t n, const double* x, const double* y,
     return SPLASH_OK;
 }
 
-// first touch of the output arrays by a few host threads (one write per 4 KiB page)
-static void prefault_outputs(double* const* bufs, int nbuf, size_t elems)
+// test hook: the day loop's own moist_surf()/inf_GA() device functions (host pointers)
+extern "C" int splash_dev_infiltration_probe(size_t n, const double* cellpar, const double* wn,
+                                             const double* ksat_visc, const double* P,
+                                             double* theta_surf, double* infiltration)
+{
+    REQ(cellpar && wn && ksat_visc && P && theta_surf && infiltration,
+        "infiltration_probe: NULL argument");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    if (n == 0) return SPLASH_OK;
+    DevBuf dp, dw, dk, dP, dt, di;
+    const double* hin[3] = {wn, ksat_visc, P};
+    DevBuf* din[3] = {&dw, &dk, &dP};
+    HIP_TRY(dp.alloc(SPLASH_NPAR * n * 8), nullptr, 0);
+    HIP_TRY(hipMemcpy(dp.p, cellpar, SPLASH_NPAR * n * 8, hipMemcpyHostToDevice), nullptr, 0);
+    for (int k = 0; k < 3; k++) {
+        HIP_TRY(din[k]->alloc(n * 8), nullptr, 0);
+        HIP_TRY(hipMemcpy(din[k]->p, hin[k], n * 8, hipMemcpyHostToDevice), nullptr, 0);
+    }
+    HIP_TRY(dt.alloc(n * 8), nullptr, 0);
+    HIP_TRY(di.alloc(n * 8), nullptr, 0);
+    HIP_TRY(launch_infiltration_probe(n, dp.as<double>(), dw.as<double>(), dk.as<double>(),
+                                      dP.as<double>(), dt.as<double>(), di.as<double>(), nullptr),
+            nullptr, 0);
+    HIP_TRY(hipMemcpy(theta_surf, dt.p, n * 8, hipMemcpyDeviceToHost), nullptr, 0);
+    HIP_TRY(hipMemcpy(infiltration, di.p, n * 8, hipMemcpyDeviceToHost), nullptr, 0);
+    return SPLASH_OK;
+}
+
+// first touch of the output arrays by a few host threads (one write per 4 KiB page): columns
+// [c0, c0+ncols) of every row of the [nrows][N] arrays
+static void prefault_outputs(double* const* bufs, int nbuf, size_t N, size_t c0, size_t ncols,
+                             size_t nrows)
 {
     const size_t step = 4096 / sizeof(double);
-    if (elems < (size_t)(64u << 20) / sizeof(double)) return; // small arrays: not worth threads
+    if (ncols * nrows < (size_t)(64u << 20) / sizeof(double)) return; // small arrays: not worth threads
     unsigned nthr = std::thread::hardware_concurrency();
     nthr = nthr == 0 ? 4 : (nthr > 8 ? 8 : nthr);
     std::vector<std::thread> pool;
@@ -497,85 +575,67 @@ static void prefault_outputs(double* const* bufs, int nbuf, size_t elems)
         pool.emplace_back([=]() {
             for (int k = 0; k < nbuf; k++) {
                 if (!bufs[k]) continue;
-                const size_t lo = elems / nthr * w, hi = (w + 1 == nthr) ? elems : elems / nthr * (w + 1);
-                volatile double* p = bufs[k];
-                for (size_t i = lo; i < hi; i += step) p[i] = 0.0;
+                for (size_t r = w; r < nrows; r += nthr) {
+                    volatile double* p = bufs[k] + r * N + c0;
+                    for (size_t i = 0; i < ncols; i += step) p[i] = 0.0;
+                    if (ncols) p[ncols - 1] = 0.0;
+                }
             }
         });
     for (auto& t : pool) t.join();
 }
 
 // ------------------------------------------------------------------ splash.grid / splash.point
-extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
-                               const splash_grid_out* out, char* err, size_t errlen)
-{
-    if (!in || !out) return fail(SPLASH_EINVAL, err, errlen, "grid_run: NULL in/out");
-    if (!in->doy || !in->year || !in->month || !in->sw_in || !in->tc || !in->pn || !in->lat ||
-        !in->elev || !in->slop || !in->asp || !in->resolution || !in->soil)
-        return fail(SPLASH_EINVAL, err, errlen, "grid_run: NULL input array");
-    if (in->nt < 365)
-        return fail(SPLASH_EINVAL, err, errlen,
-                    "grid_run: %d days given, the spin-up needs the first 365 "
-                    "(R/splash.point.R:141-144)", in->nt);
-    if (int rc = need_device(err, errlen)) return rc;
-    const int device = opt ? opt->device : 0;
-    const int monthly = opt ? opt->monthly_out : 0;
-    HIP_TRY(hipSetDevice(device), err, errlen);
+namespace {
 
-    const size_t N = in->ncell;
-    const int nt = in->nt;
+// What one call of splash_grid_run works on, shared by its per-device workers.
+struct GridPlan {
+    const splash_grid_in* in;
+    const splash_grid_out* out;
+    const size_t* idx; // valid (non-NA) cells, ascending
+    size_t nv, N;
+    bool dense;        // nv == N: no gather/scatter
+    int nt, nmonth, nt_out, n_out, monthly, n_basin;
+    size_t max_cells;
+    bool want_diag;
+};
+
+// Valid cells [v0, v1) on `device`: what clFun does for a row block (R/splash.grid.R:277-308),
+// in HBM-sized blocks.  `share` = workers using this device (they split its free memory).
+// acc: this worker's host copy of the exact diagnostic limbs (summed by the caller).
+int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, int64_t* acc,
+                char* err, size_t errlen)
+{
+    const splash_grid_in* in = P.in;
+    const splash_grid_out* out = P.out;
+    const size_t N = P.N;
+    const int nt = P.nt, nt_out = P.nt_out, n_out = P.n_out;
+    HIP_TRY(hipSetDevice(device), err, errlen);
+    if (v1 <= v0) return SPLASH_OK;
     splash_calendar* cal = nullptr;
     if (int rc = splash_calendar_create(nt, in->doy, in->year, in->month, &cal, err, errlen)) return rc;
     struct CalGuard {
         splash_calendar* c;
         ~CalGuard() { splash_calendar_destroy(c); }
     } cg{cal};
-    const int nmonth = cal->nmonth;
-    const int nt_out = monthly ? nmonth : nt;
-    const double NaN = std::numeric_limits<double>::quiet_NaN();
-
-    // NA cells (R: every comparison false, all outputs NA): mask them out, emit NaN
-    std::vector<size_t> idx;
-    idx.reserve(N);
-    for (size_t c = 0; c < N; c++) {
-        bool bad = isnan_d(in->lat[c]) || isnan_d(in->elev[c]) || isnan_d(in->slop[c]) ||
-                   isnan_d(in->asp[c]) || isnan_d(in->resolution[c]) || isnan_d(in->sw_in[c]) ||
-                   isnan_d(in->tc[c]) || isnan_d(in->pn[c]);
-        for (int k = 0; k < 6 && !bad; k++)
-            if (k != 4 && isnan_d(in->soil[(size_t)k * N + c])) bad = true; // bd NA is legal
-        if (in->au)
-            for (int k = 0; k < 3 && !bad; k++)
-                if (isnan_d(in->au[(size_t)k * N + c])) bad = true;
-        if (!bad) idx.push_back(c);
-    }
-    const size_t nv = idx.size();
-    const bool dense = (nv == N);
-    if (!dense) {
-        for (int k = 0; k < SPLASH_NOUT; k++)
-            if (out->out[k]) std::fill(out->out[k], out->out[k] + (size_t)nt_out * N, NaN);
-        if (out->state_end) std::fill(out->state_end, out->state_end + 5 * N, NaN);
-        if (out->aux) std::fill(out->aux, out->aux + 4 * N, NaN);
-    }
-    if (out->diag) std::fill(out->diag, out->diag + (size_t)nmonth * SPLASH_NDIAG, 0.0);
-    if (nv == 0) return SPLASH_OK;
-
-    int n_out = 0;
-    for (int k = 0; k < SPLASH_NOUT; k++) n_out += out->out[k] ? 1 : 0;
+    const bool f32 = (in->sw_in == nullptr);
 
     // cells per launch from free HBM
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b), err, errlen);
-    const size_t per_cell = (size_t)nt * 3 * 8 + (size_t)nt_out * n_out * 8 +
-                            (SPLASH_NPAR + SPLASH_NSTATE + 6 + 5 + 3 + 1 + 4 + 4) * 8 + 64;
-    size_t nb_max = (size_t)((double)free_b * 0.85) / per_cell;
-    if (opt && opt->max_cells_per_launch) nb_max = std::min(nb_max, opt->max_cells_per_launch);
+    const size_t per_cell = (size_t)nt * 3 * 8 + (f32 ? (size_t)nt * 4 : 0) +
+                            (size_t)nt_out * n_out * 8 +
+                            (SPLASH_NPAR + SPLASH_NSTATE + 6 + 5 + 3 + 1 + 4 + 4 + 1) * 8 + 64;
+    size_t nb_max = (size_t)((double)free_b * 0.85 / (double)std::max(share, 1)) / per_cell;
+    if (P.max_cells) nb_max = std::min(nb_max, P.max_cells);
     if (nb_max == 0) return fail(SPLASH_ENOMEM, err, errlen, "grid_run: not enough device memory");
-    nb_max = std::min(nb_max, nv);
+    nb_max = std::min(nb_max, v1 - v0);
     nb_max = std::min(nb_max, kMaxCellsPerLaunch);
     if (nb_max > 256) nb_max -= nb_max % 256;
 
-    DevBuf d_force, d_out, d_par, d_state, d_stat, d_tt, d_pass, d_diag, d_dwork, d_swork;
+    DevBuf d_force, d_f32, d_out, d_par, d_state, d_stat, d_tt, d_pass, d_acc, d_swork, d_basin;
     HIP_TRY(d_force.alloc((size_t)nt * 3 * nb_max * 8), err, errlen);
+    if (f32) HIP_TRY(d_f32.alloc((size_t)nt * nb_max * 4), err, errlen);
     HIP_TRY(d_out.alloc((size_t)nt_out * std::max(n_out, 1) * nb_max * 8), err, errlen);
     HIP_TRY(d_par.alloc((size_t)SPLASH_NPAR * nb_max * 8), err, errlen);
     HIP_TRY(d_state.alloc((size_t)SPLASH_NSTATE * nb_max * 8), err, errlen);
@@ -583,50 +643,80 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
     HIP_TRY(d_tt.alloc(nb_max * 8), err, errlen);
     HIP_TRY(d_pass.alloc(2 * nb_max * sizeof(int)), err, errlen);
     HIP_TRY(d_swork.alloc(splash_dev_spin_up_work_size(nb_max)), err, errlen);
-    if (out->diag) {
-        HIP_TRY(d_diag.alloc((size_t)nmonth * SPLASH_NDIAG * 8), err, errlen);
-        HIP_TRY(hipMemset(d_diag.p, 0, (size_t)nmonth * SPLASH_NDIAG * 8), err, errlen);
-        HIP_TRY(d_dwork.alloc(splash_dev_diag_work_size(nb_max, nmonth)), err, errlen);
+    const size_t acc_bytes = splash_dev_diag_acc_size(P.n_basin, P.nmonth);
+    if (P.want_diag) {
+        HIP_TRY(d_acc.alloc(acc_bytes), err, errlen);
+        HIP_TRY(hipMemset(d_acc.p, 0, acc_bytes), err, errlen);
+        if (in->basin) HIP_TRY(d_basin.alloc(nb_max * sizeof(int32_t)), err, errlen);
     }
     std::vector<double> stage; // host gather/scatter buffer for masked grids
+    std::vector<float> stage32;
     std::vector<double> hstat((size_t)(5 + 6 + 3) * nb_max), hsmall(5 * nb_max);
     std::vector<int> hpass(2 * nb_max);
-    if (!dense) stage.resize((size_t)std::max(nt, nt_out) * nb_max);
+    std::vector<int32_t> hbasin(in->basin && P.want_diag ? nb_max : 0);
+    if (!P.dense) {
+        stage.resize((size_t)std::max(f32 ? 0 : nt, nt_out) * nb_max);
+        if (f32) stage32.resize((size_t)nt * nb_max);
+    }
 
     hipStream_t s = nullptr;
-    for (size_t b0 = 0; b0 < nv; b0 += nb_max) {
-        const size_t nb = std::min(nb_max, nv - b0);
+    bool prefaulted = false;
+    for (size_t b0 = v0; b0 < v1; b0 += nb_max) {
+        const size_t nb = std::min(nb_max, v1 - b0);
+        const size_t* idx = P.idx + b0; // idx[j] = grid cell of the block's j-th cell
+        const size_t c0 = idx[0];       // dense: the block is cells [c0, c0+nb)
         double* F = d_force.as<double>();
-        double* dsw = F;
-        double* dtc = F + (size_t)nt * nb;
-        double* dpn = F + (size_t)2 * nt * nb;
-        const double* hsrc[3] = {in->sw_in, in->tc, in->pn};
-        double* ddst[3] = {dsw, dtc, dpn};
-        for (int v = 0; v < 3; v++) {
-            if (dense) {
-                HIP_TRY(hipMemcpy2D(ddst[v], nb * 8, hsrc[v] + b0, N * 8, nb * 8, (size_t)nt,
-                                    hipMemcpyHostToDevice), err, errlen);
-            } else {
-                for (int t = 0; t < nt; t++)
-                    for (size_t j = 0; j < nb; j++)
-                        stage[(size_t)t * nb + j] = hsrc[v][(size_t)t * N + idx[b0 + j]];
-                HIP_TRY(hipMemcpy(ddst[v], stage.data(), (size_t)nt * nb * 8, hipMemcpyHostToDevice),
-                        err, errlen);
+        double* ddst[3] = {F, F + (size_t)nt * nb, F + (size_t)2 * nt * nb};
+        double *dsw = ddst[0], *dtc = ddst[1], *dpn = ddst[2];
+        if (!f32) {
+            const double* hsrc[3] = {in->sw_in, in->tc, in->pn};
+            for (int v = 0; v < 3; v++) {
+                if (P.dense) {
+                    HIP_TRY(hipMemcpy2D(ddst[v], nb * 8, hsrc[v] + c0, N * 8, nb * 8, (size_t)nt,
+                                        hipMemcpyHostToDevice), err, errlen);
+                } else {
+                    for (int t = 0; t < nt; t++)
+                        for (size_t j = 0; j < nb; j++)
+                            stage[(size_t)t * nb + j] = hsrc[v][(size_t)t * N + idx[j]];
+                    HIP_TRY(hipMemcpy(ddst[v], stage.data(), (size_t)nt * nb * 8,
+                                      hipMemcpyHostToDevice), err, errlen);
+                }
+            }
+        } else { // single-precision transport, widened on the device (lossless for FLT4S rasters)
+            const float* hsrc[3] = {in->sw_in_f32, in->tc_f32, in->pn_f32};
+            for (int v = 0; v < 3; v++) {
+                if (P.dense) {
+                    HIP_TRY(hipMemcpy2D(d_f32.p, nb * 4, hsrc[v] + c0, N * 4, nb * 4, (size_t)nt,
+                                        hipMemcpyHostToDevice), err, errlen);
+                } else {
+                    for (int t = 0; t < nt; t++)
+                        for (size_t j = 0; j < nb; j++)
+                            stage32[(size_t)t * nb + j] = hsrc[v][(size_t)t * N + idx[j]];
+                    HIP_TRY(hipMemcpy(d_f32.p, stage32.data(), (size_t)nt * nb * 4,
+                                      hipMemcpyHostToDevice), err, errlen);
+                }
+                HIP_TRY(launch_widen_f32(d_f32.as<float>(), (size_t)nt * nb, ddst[v], s), err, errlen);
+                HIP_TRY(hipStreamSynchronize(s), err, errlen); // d_f32 is reused by the next series
             }
         }
         // statics: lat, elev, slop, asp, resolution, soil[6], au[3]
         const double* st1[5] = {in->lat, in->elev, in->slop, in->asp, in->resolution};
         for (int k = 0; k < 5; k++)
-            for (size_t j = 0; j < nb; j++) hstat[(size_t)k * nb + j] = st1[k][idx[b0 + j]];
+            for (size_t j = 0; j < nb; j++) hstat[(size_t)k * nb + j] = st1[k][idx[j]];
         for (int k = 0; k < 6; k++)
             for (size_t j = 0; j < nb; j++)
-                hstat[(size_t)(5 + k) * nb + j] = in->soil[(size_t)k * N + idx[b0 + j]];
+                hstat[(size_t)(5 + k) * nb + j] = in->soil[(size_t)k * N + idx[j]];
         if (in->au)
             for (int k = 0; k < 3; k++)
                 for (size_t j = 0; j < nb; j++)
-                    hstat[(size_t)(11 + k) * nb + j] = in->au[(size_t)k * N + idx[b0 + j]];
+                    hstat[(size_t)(11 + k) * nb + j] = in->au[(size_t)k * N + idx[j]];
         double* S = d_stat.as<double>();
         HIP_TRY(hipMemcpy(S, hstat.data(), (size_t)14 * nb * 8, hipMemcpyHostToDevice), err, errlen);
+        if (!hbasin.empty()) {
+            for (size_t j = 0; j < nb; j++) hbasin[j] = in->basin[idx[j]];
+            HIP_TRY(hipMemcpy(d_basin.p, hbasin.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice),
+                    err, errlen);
+        }
 
         double* par = d_par.as<double>();
         double* state = d_state.as<double>();
@@ -645,35 +735,41 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
         for (int k = 0; k < SPLASH_NOUT; k++)
             dout.out[k] = out->out[k] ? d_out.as<double>() + (size_t)(q++) * nt_out * nb : nullptr;
         dout.ldo = nb;
-        dout.monthly = monthly;
-        dout.diag = out->diag ? d_diag.as<double>() : nullptr;
-        dout.diag_work = out->diag ? d_dwork.as<double>() : nullptr;
+        dout.monthly = P.monthly;
+        if (P.want_diag) {
+            dout.diag_acc = d_acc.as<int64_t>();
+            dout.basin = in->basin ? d_basin.as<int32_t>() : nullptr;
+            dout.n_basin = P.n_basin;
+        }
         rc = splash_dev_run_all(cal, 0, nt, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, &dout, s);
         if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
         // The kernels of this block are queued; while they run, map the caller's (typically
         // freshly allocated) output arrays: the first touch of tens of GB is otherwise paid page
         // by page inside the device-to-host copies.
-        if (dense && b0 == 0) prefault_outputs(out->out, SPLASH_NOUT, (size_t)nt_out * N);
+        if (P.dense && !prefaulted) {
+            prefault_outputs(out->out, SPLASH_NOUT, N, c0, v1 - b0, (size_t)nt_out);
+            prefaulted = true;
+        }
         HIP_TRY(hipStreamSynchronize(s), err, errlen);
 
         for (int k = 0; k < SPLASH_NOUT; k++) {
             if (!out->out[k]) continue;
-            if (dense) {
-                HIP_TRY(hipMemcpy2D(out->out[k] + b0, N * 8, dout.out[k], nb * 8, nb * 8,
+            if (P.dense) {
+                HIP_TRY(hipMemcpy2D(out->out[k] + c0, N * 8, dout.out[k], nb * 8, nb * 8,
                                     (size_t)nt_out, hipMemcpyDeviceToHost), err, errlen);
             } else {
                 HIP_TRY(hipMemcpy(stage.data(), dout.out[k], (size_t)nt_out * nb * 8,
                                   hipMemcpyDeviceToHost), err, errlen);
                 for (int t = 0; t < nt_out; t++)
                     for (size_t j = 0; j < nb; j++)
-                        out->out[k][(size_t)t * N + idx[b0 + j]] = stage[(size_t)t * nb + j];
+                        out->out[k][(size_t)t * N + idx[j]] = stage[(size_t)t * nb + j];
             }
         }
         if (out->state_end) {
             HIP_TRY(hipMemcpy(hsmall.data(), state, 5 * nb * 8, hipMemcpyDeviceToHost), err, errlen);
             for (int k = 0; k < 5; k++)
                 for (size_t j = 0; j < nb; j++)
-                    out->state_end[(size_t)k * N + idx[b0 + j]] = hsmall[(size_t)k * nb + j];
+                    out->state_end[(size_t)k * N + idx[j]] = hsmall[(size_t)k * nb + j];
         }
         if (out->aux) {
             HIP_TRY(hipMemcpy(hsmall.data(), Tt, nb * 8, hipMemcpyDeviceToHost), err, errlen);
@@ -682,16 +778,141 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
             HIP_TRY(hipMemcpy(hpass.data(), d_pass.p, 2 * nb * sizeof(int), hipMemcpyDeviceToHost),
                     err, errlen);
             for (size_t j = 0; j < nb; j++) {
-                out->aux[idx[b0 + j]] = hsmall[j];
-                out->aux[N + idx[b0 + j]] = hsmall[nb + j];
-                out->aux[2 * N + idx[b0 + j]] = hpass[j];
-                out->aux[3 * N + idx[b0 + j]] = hpass[nb + j];
+                out->aux[idx[j]] = hsmall[j];
+                out->aux[N + idx[j]] = hsmall[nb + j];
+                out->aux[2 * N + idx[j]] = hpass[j];
+                out->aux[3 * N + idx[j]] = hpass[nb + j];
             }
         }
     }
-    if (out->diag)
-        HIP_TRY(hipMemcpy(out->diag, d_diag.p, (size_t)nmonth * SPLASH_NDIAG * 8,
-                          hipMemcpyDeviceToHost), err, errlen);
+    if (P.want_diag)
+        HIP_TRY(hipMemcpy(acc, d_acc.p, acc_bytes, hipMemcpyDeviceToHost), err, errlen);
+    return SPLASH_OK;
+}
+
+} // namespace
+
+extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
+                               const splash_grid_out* out, char* err, size_t errlen)
+{
+    if (!in || !out) return fail(SPLASH_EINVAL, err, errlen, "grid_run: NULL in/out");
+    const bool f64 = in->sw_in && in->tc && in->pn;
+    const bool f32 = !in->sw_in && !in->tc && !in->pn && in->sw_in_f32 && in->tc_f32 && in->pn_f32;
+    if (!in->doy || !in->year || !in->month || !(f64 || f32) || !in->lat || !in->elev ||
+        !in->slop || !in->asp || !in->resolution || !in->soil)
+        return fail(SPLASH_EINVAL, err, errlen,
+                    "grid_run: NULL input array (forcing: all three series as double, or all "
+                    "three as float with the double pointers NULL)");
+    if (in->nt < 365)
+        return fail(SPLASH_EINVAL, err, errlen,
+                    "grid_run: %d days given, the spin-up needs the first 365 "
+                    "(R/splash.point.R:141-144)", in->nt);
+    if (in->basin && in->n_basin <= 0)
+        return fail(SPLASH_EINVAL, err, errlen, "grid_run: basin ids given with n_basin <= 0");
+    if (int rc = need_device(err, errlen)) return rc;
+
+    // devices: one worker per entry of the list (the same ordinal may repeat)
+    std::vector<int> devs;
+    if (opt && opt->n_devices > 1) {
+        for (int k = 0; k < opt->n_devices; k++) devs.push_back(opt->devices ? opt->devices[k] : k);
+    } else {
+        devs.push_back(opt ? ((opt->n_devices == 1 && opt->devices) ? opt->devices[0] : opt->device) : 0);
+    }
+    const int ndev_present = splash_hip_device_count();
+    for (int d : devs)
+        if (d < 0 || d >= ndev_present)
+            return fail(SPLASH_EINVAL, err, errlen, "grid_run: device %d not present (%d visible)", d,
+                        ndev_present);
+
+    GridPlan P{};
+    P.in = in;
+    P.out = out;
+    P.N = in->ncell;
+    P.nt = in->nt;
+    P.monthly = opt ? opt->monthly_out : 0;
+    P.max_cells = opt ? opt->max_cells_per_launch : 0;
+    P.n_basin = in->basin ? in->n_basin : 1;
+    P.want_diag = out->diag || out->diag_acc;
+    // month count without touching a device: same rule as splash_calendar_create
+    {
+        int mid = 0;
+        for (int t = 0; t < in->nt; t++) {
+            if (in->month[t] < 1 || in->month[t] > 12 || in->doy[t] < 1 || in->doy[t] > 366)
+                return fail(SPLASH_EINVAL, err, errlen, "calendar: bad doy/month at day %d", t);
+            if (t > 0 && (in->month[t] != in->month[t - 1] || in->year[t] != in->year[t - 1])) mid++;
+        }
+        P.nmonth = mid + 1;
+    }
+    P.nt_out = P.monthly ? P.nmonth : P.nt;
+    const size_t N = P.N;
+    const double NaN = std::numeric_limits<double>::quiet_NaN();
+
+    // NA cells (R: every comparison false, all outputs NA): mask them out, emit NaN.  A cell is NA
+    // when a static or its first forcing record is NaN (ocean cells of a masked raster); NaNs
+    // later in a series propagate through the arithmetic like R's NA (see the header).
+    std::vector<size_t> idx;
+    idx.reserve(N);
+    for (size_t c = 0; c < N; c++) {
+        bool bad = isnan_d(in->lat[c]) || isnan_d(in->elev[c]) || isnan_d(in->slop[c]) ||
+                   isnan_d(in->asp[c]) || isnan_d(in->resolution[c]);
+        if (f64)
+            bad = bad || isnan_d(in->sw_in[c]) || isnan_d(in->tc[c]) || isnan_d(in->pn[c]);
+        else
+            bad = bad || in->sw_in_f32[c] != in->sw_in_f32[c] || in->tc_f32[c] != in->tc_f32[c] ||
+                  in->pn_f32[c] != in->pn_f32[c];
+        for (int k = 0; k < 6 && !bad; k++)
+            if (k != 4 && isnan_d(in->soil[(size_t)k * N + c])) bad = true; // bd NA is legal
+        if (in->au)
+            for (int k = 0; k < 3 && !bad; k++)
+                if (isnan_d(in->au[(size_t)k * N + c])) bad = true;
+        if (!bad) idx.push_back(c);
+    }
+    P.idx = idx.data();
+    P.nv = idx.size();
+    P.dense = (P.nv == N);
+    if (!P.dense) {
+        for (int k = 0; k < SPLASH_NOUT; k++)
+            if (out->out[k]) std::fill(out->out[k], out->out[k] + (size_t)P.nt_out * N, NaN);
+        if (out->state_end) std::fill(out->state_end, out->state_end + 5 * N, NaN);
+        if (out->aux) std::fill(out->aux, out->aux + 4 * N, NaN);
+    }
+    const size_t n_rec = (size_t)P.n_basin * P.nmonth;
+    if (out->diag) std::fill(out->diag, out->diag + n_rec * SPLASH_NDIAG, 0.0);
+    if (out->diag_acc) std::fill(out->diag_acc, out->diag_acc + n_rec * SPLASH_DIAG_REC, (int64_t)0);
+    if (P.nv == 0) return SPLASH_OK;
+    for (int k = 0; k < SPLASH_NOUT; k++) P.n_out += out->out[k] ? 1 : 0;
+
+    // contiguous ranges of equal valid-cell count, one per worker (cells are independent: the
+    // split changes nothing in the results, totals included -- they are exact integer sums)
+    const int nw = (int)devs.size();
+    std::vector<std::vector<int64_t>> acc(nw);
+    std::vector<int> rcs(nw, 0);
+    std::vector<std::string> msgs(nw);
+    auto run = [&](int w) {
+        const size_t v0 = P.nv * (size_t)w / nw, v1 = P.nv * (size_t)(w + 1) / nw;
+        int share = 0;
+        for (int d : devs) share += (d == devs[w]);
+        if (P.want_diag) acc[w].assign(n_rec * SPLASH_DIAG_REC, 0);
+        char buf[512] = "";
+        rcs[w] = grid_worker(P, devs[w], share, v0, v1, acc[w].data(), buf, sizeof buf);
+        msgs[w] = buf;
+    };
+    if (nw == 1) {
+        run(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int w = 0; w < nw; w++) pool.emplace_back(run, w);
+        for (auto& t : pool) t.join();
+    }
+    for (int w = 0; w < nw; w++)
+        if (rcs[w]) return fail(rcs[w], err, errlen, "device %d: %s", devs[w], msgs[w].c_str());
+    if (P.want_diag) {
+        std::vector<int64_t> total(n_rec * SPLASH_DIAG_REC, 0);
+        for (int w = 0; w < nw; w++)
+            for (size_t i = 0; i < total.size(); i++) total[i] += acc[w][i];
+        if (out->diag_acc) std::copy(total.begin(), total.end(), out->diag_acc);
+        if (out->diag) splash_diag_finalize_host(total.data(), P.n_basin, P.nmonth, out->diag, nullptr);
+    }
     return SPLASH_OK;
 }
 

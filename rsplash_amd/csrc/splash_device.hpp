@@ -934,20 +934,34 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
 }
 
 // ---- rain / snow split: R/splash.point.R:120-128, 521-578 -------------------------------------
-// snow_term = elev*0.0004596581 + |lat|*0.0110592101 (cell-static part of snowfall_prob, :576)
-__device__ __forceinline__ double snowfall_prob(double tc, double snow_term)
+// Exponent of the snowfall logistic (:576) in R's own evaluation order,
+//   ((-0.4710405934 + 1.0473543991*tc) - elev*0.0004596581) - |lat|*0.0110592101,
+// with every product and sum rounded separately (no FMA: R's build has none on x86-64).
+// e1 = elev*0.0004596581 and e2 = |lat|*0.0110592101 are the cell-static products.
+__device__ __forceinline__ double snow_logit(double tc, double e1, double e2)
 {
-    return 1 / (1 + fexp(-0.4710405934 + 1.0473543991 * tc - snow_term));
+#pragma clang fp contract(off)
+    return ((-0.4710405934 + 1.0473543991 * tc) - e1) - e2;
+}
+// p_snow = 1/(1+exp(x)) >= 0.5 as the reference evaluates it in doubles: exp(x) rounds to 1 for
+// x <= 2^-53 and to 1+2^-52 up to 1.5*2^-52; 1+(1+2^-52) ties to 2 and 1/2 = 0.5 passes, the next
+// double up gives 0.5-2^-54.  So the test is x <= 1.5*2^-52 (not x <= 0): identical to the
+// logistic for a correctly rounded exp (glibc's is, at these arguments), without evaluating it.
+// A NaN exponent (missing tc) is neither: R's ifelse() then yields NA (see rain_snow_split).
+constexpr double kSnowLogitMax = 0x1.8p-52;
+
+__device__ __forceinline__ double snowfall_prob(double tc, double e1, double e2)
+{
+    return 1 / (1 + fexp(snow_logit(tc, e1, e2)));
 }
 
 __device__ __forceinline__ void rain_snow_split(const DayConst& d, double tc, double pn, double Tt,
-                                                double snow_term, double& rain, double& snowfall)
+                                                double e1, double e2, double& rain,
+                                                double& snowfall)
 {
-    // p_snow = 1/(1+exp(x)) >= 0.5  <=>  1+exp(x) <= 2  <=>  x <= 0 (exp is monotone and
-    // exp(0) = 1 exactly), so the logistic itself is not needed for the branch
-    const double x = -0.4710405934 + 1.0473543991 * tc - snow_term;
+    const double x = snow_logit(tc, e1, e2);
     double f_rain = 1.0;
-    if (x <= 0.0) {
+    if (x <= kSnowLogitMax) {
         double Ttm = Tt + (Tt * d.ttm_s);
         double q = ((tc - Ttm) * d.inv_trm14); // the divisor is a per-day constant: reciprocal from the host table
         double q2 = q * q, q3 = q2 * q;
@@ -957,9 +971,11 @@ __device__ __forceinline__ void rain_snow_split(const DayConst& d, double tc, do
         } else {
             fr = 5 * q3 - 6.76 * q2 + 3.19 * q + 0.5;
         }
-        if (fr < 0) fr = 0;
+        if (fr < 0) fr = 0; // frain[frain<0] <- 0 leaves NA (Tt = NA: a gap in tc) alone
         if (fr > 1) fr = 1;
         f_rain = fr;
+    } else if (x != x) {
+        f_rain = x; // ifelse(NA >= 0.5, ., .) is NA
     }
     snowfall = pn * (1 - f_rain);
     rain = pn * f_rain;

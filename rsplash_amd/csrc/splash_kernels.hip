@@ -103,16 +103,18 @@ __global__ __launch_bounds__(kBlock) void k_snow_threshold(size_t ncell, int nt,
 {
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= ncell) return;
-    double snow_term = par[P_ELV * ldp + i] * 0.0004596581 + fabs(par[P_LAT * ldp + i]) * 0.0110592101;
+    const double e1 = par[P_ELV * ldp + i] * 0.0004596581, e2 = fabs(par[P_LAT * ldp + i]) * 0.0110592101;
     double best = -__builtin_inf();
+    bool gap = false;
 #pragma unroll 4
     for (int t = 0; t < nt; t++) {
         double v = __builtin_nontemporal_load(&tc[(size_t)t * ldf + i]);
         // p_snow >= 0.5  <=>  the logistic's exponent <= 0 (see rain_snow_split)
-        const double x = -0.4710405934 + 1.0473543991 * v - snow_term;
-        if (x <= 0.0 && v > best) best = v;
+        const double x = snow_logit(v, e1, e2);
+        if (x <= kSnowLogitMax && v > best) best = v;
+        gap |= (x != x); // a missing tc makes R's max() NA for the whole series
     }
-    Tt[i] = best;
+    Tt[i] = gap ? __builtin_nan("") : best;
 }
 
 // ================================================================ forcing access ==============
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void k_snow_threshold(size_t ncell, int nt,
 struct Forcing {
     const double *sw, *tc, *pn, *snowfall; // snowfall != NULL => explicit rain/snow series
     size_t ld;
-    double Tt, snow_term;
+    double Tt, e1, e2; // snowfall threshold; elev*0.0004596581, |lat|*0.0110592101 (snow_logit)
     unsigned off; // cell * sizeof(double)
     static __device__ __forceinline__ double at(const double* row, unsigned off_bytes)
     {
@@ -143,7 +145,7 @@ struct Forcing {
             snowf = at(snowfall + (size_t)t * ld, off);
         } else {
             DayConst dc{d.dr, d.sd, d.cd, d.ttm_s, d.inv_trm14};
-            rain_snow_split(dc, tcv, pnv, Tt, snow_term, rain, snowf);
+            rain_snow_split(dc, tcv, pnv, Tt, e1, e2, rain, snowf);
         }
     }
 };
@@ -176,6 +178,11 @@ __device__ __forceinline__ DayConst day_const(const DayRec& d)
     return DayConst{d.dr, d.sd, d.cd, d.ttm_s, d.inv_trm14};
 }
 
+__device__ __forceinline__ bool same_bits(double a, double b)
+{
+    return __double_as_longlong(a) == __double_as_longlong(b); // NaN-safe (sticky NaN drainage time)
+}
+
 // ================================================================ K4 spin-up ===================
 // Grid spin-up: both spin-ups of splash.point (R/splash.point.R:141-152) as a resumable per-cell
 // job.  The number of passes is data dependent (2..1000, src/SPLASH.cpp:1697): most cells need
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     const size_t ci = a.wl_in ? (size_t)a.wl_in[sl] : sl;
 
     Forcing f{a.sw, a.tc, a.pn, nullptr, a.ldf, a.Tt[ci],
-              a.par[P_ELV * a.ldp + ci] * 0.0004596581 + fabs(a.par[P_LAT * a.ldp + ci]) * 0.0110592101,
+              a.par[P_ELV * a.ldp + ci] * 0.0004596581, fabs(a.par[P_LAT * a.ldp + ci]) * 0.0110592101,
               (unsigned)(ci * sizeof(double))};
     const DayTable days = day_table(a.days);
     const DayRec d0 = day_rec(days, 0);
@@ -226,6 +233,17 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         e = State{a.state[ci], a.state[a.lds + ci], a.state[2 * a.lds + ci],
                   a.state[3 * a.lds + ci], a.state[4 * a.lds + ci]};
     }
+    // Exact-cycle detection (Brent): the day-1 state of a pass determines everything after it, so
+    // if it ever repeats bit for bit (period lam), the passes up to the 1000-pass cap
+    // (src/SPLASH.cpp:1697) only go round that cycle -- the stopping rule cannot fire inside it, or
+    // it would have fired on the first traversal -- and the state the reference ends with is the
+    // one (1000 - count) mod lam passes ahead.  Most cells that never meet the 1 mm criterion sit in
+    // an exact 2- or 3-cycle after a few dozen passes.  The checkpoint lives in LDS (one compare
+    // per pass); it restarts with every phase, moving to the current state whenever the number of
+    // passes since the phase began is a power of two.
+    __shared__ double s_chk[5][kBlock];
+    __shared__ int s_chk_count[kBlock];
+    s_chk_count[threadIdx.x] = -1;
     bool done = !valid;
     for (int it = 0; it < a.budget; it++) {
         const bool acc = a.fresh && it == 0; // first pass of spin-up #1 (uniform)
@@ -261,6 +279,23 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             if (cont) {
                 e = nxt;
                 count++;
+                const int cc = s_chk_count[threadIdx.x];
+                const bool same = cc >= 0 && same_bits(e.wn, s_chk[0][threadIdx.x]) &&
+                                  same_bits(e.snow, s_chk[1][threadIdx.x]) &&
+                                  same_bits(e.qin, s_chk[2][threadIdx.x]) &&
+                                  same_bits(e.td, s_chk[3][threadIdx.x]) &&
+                                  same_bits(e.nd, s_chk[4][threadIdx.x]);
+                if (same) {
+                    count = 1000 - ((1000 - count) % (count - cc));
+                    s_chk_count[threadIdx.x] = -1; // the remaining < lam passes run plainly
+                } else if (((it + 1) & it) == 0) { // it + 1 = passes in this phase: 1, 2, 4, 8, ...
+                    s_chk[0][threadIdx.x] = e.wn;
+                    s_chk[1][threadIdx.x] = e.snow;
+                    s_chk[2][threadIdx.x] = e.qin;
+                    s_chk[3][threadIdx.x] = e.td;
+                    s_chk[4][threadIdx.x] = e.nd;
+                    s_chk_count[threadIdx.x] = count;
+                }
             } else if (stage == 1) {
                 if (a.passes) a.passes[ci] = count;
                 const double AI = a.ai[ci];
@@ -268,6 +303,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 cell_setup(c, a.par, a.ldp, ci, AI);
                 stage = 2;
                 count = 1;
+                s_chk_count[threadIdx.x] = -1;
                 e = State{c.RES, 0.0, 0.0, 0.0, 0.0};
                 day_step(c, day_const(d0), sw0, tc0, rain0, snf0, e, o);
             } else {
@@ -304,7 +340,7 @@ __global__ __launch_bounds__(64) void k_spin_up_mod(SpinArgs a, double* const* s
     lds_tables_init();
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const size_t ci = 0;
-    Forcing f{a.sw, a.tc, a.pn, snowfall, a.ldf, 0.0, 0.0, (unsigned)(ci * sizeof(double))};
+    Forcing f{a.sw, a.tc, a.pn, snowfall, a.ldf, 0.0, 0.0, 0.0, (unsigned)(ci * sizeof(double))};
     CellConst c;
     cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci]);
     State w{c.RES, 0.0, 0.0, 0.0, 0.0}; // wn_vec(n,RES), others 0: read at [n-1] on day 1
@@ -350,6 +386,84 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// K7: add one cell's monthly figures to the (basin, month) record of exact fixed-point limbs
+// (include/splash_hip.h).  v = a/2^16 + r with a = rint(v*2^16) and r = v - a/2^16 EXACT (scaling
+// by a power of two and the subtraction of two nearby doubles are exact), then b = rint(r*2^48):
+// the only rounding is below 2^-49 mm per addend.  Integer addition is associative, so the totals
+// do not depend on which lane, wave, block, launch or GPU adds first.  Wavefronts whose cells
+// share one basin (the usual case: basins are spatially coherent) reduce in registers and issue
+// one atomic per limb; mixed wavefronts add lane by lane.
+__device__ __forceinline__ void diag_add(long long* __restrict__ acc, const int* __restrict__ basin,
+                                         int n_basin, int nmonth_cal, int month_id, size_t cell,
+                                         bool valid, const double (&w)[SPLASH_NDIAG_K],
+                                         bool month_end)
+{
+    constexpr int REC = (SPLASH_NDIAG_K + 1) * 2;
+    const int b = basin ? basin[cell] : 0;
+    const bool in = valid && (unsigned)b < (unsigned)n_basin;
+    long long limb[REC];
+    long long skipped = 0;
+#pragma unroll
+    for (int q = 0; q < SPLASH_NDIAG_K; q++) {
+        const double v = w[q];
+        const bool ok = in && (fabs(v) < 1048576.0); // false for NaN/inf too
+        const double a = rint(v * 65536.0);
+        const double r = v - a * (1.0 / 65536.0);
+        limb[2 * q] = ok ? (long long)a : 0;
+        limb[2 * q + 1] = ok ? (long long)rint(r * 281474976710656.0) : 0;
+        skipped += (in && !ok) ? 1 : 0;
+    }
+    limb[2 * SPLASH_NDIAG_K] = (in && month_end) ? 1 : 0;
+    limb[2 * SPLASH_NDIAG_K + 1] = skipped;
+    const int b0 = __builtin_amdgcn_readfirstlane(in ? b : -1);
+    // uniform: every participating lane has the first lane's basin (lanes that do not take part
+    // carry zeros and may be summed along)
+    const bool uniform = __all(!in || b == b0) && b0 >= 0;
+    if (uniform) {
+        unsigned long long* rec =
+            (unsigned long long*)acc + ((size_t)b0 * nmonth_cal + month_id) * REC;
+#pragma unroll
+        for (int q = 0; q < REC; q++) {
+            const long long s = wave_sum_i64(limb[q]);
+            if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(rec + q, (unsigned long long)s);
+        }
+    } else if (in) {
+        unsigned long long* rec =
+            (unsigned long long*)acc + ((size_t)b * nmonth_cal + month_id) * REC;
+#pragma unroll
+        for (int q = 0; q < REC; q++)
+            if (limb[q] != 0) atomicAdd(rec + q, (unsigned long long)limb[q]);
+    }
+}
+
+// limbs -> doubles, one thread per (basin, month) record
+__global__ __launch_bounds__(kBlock) void k_diag_finalize(const long long* __restrict__ acc,
+                                                         int n_rec, double* __restrict__ diag,
+                                                         double* __restrict__ counts)
+{
+    constexpr int REC = (SPLASH_NDIAG_K + 1) * 2;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_rec) return;
+    const long long* r = acc + (size_t)i * REC;
+    for (int q = 0; q < SPLASH_NDIAG_K; q++) {
+        const double hi = (double)r[2 * q];               // rounds beyond 2^53
+        const double lo = (double)(r[2 * q] - (long long)hi); // exact remainder
+        diag[(size_t)i * SPLASH_NDIAG_K + q] =
+            hi * (1.0 / 65536.0) + (lo * (1.0 / 65536.0) + (double)r[2 * q + 1] * (1.0 / 281474976710656.0));
+    }
+    if (counts) {
+        counts[2 * (size_t)i] = (double)r[2 * SPLASH_NDIAG_K];
+        counts[2 * (size_t)i + 1] = (double)r[2 * SPLASH_NDIAG_K + 1];
+    }
+}
+
 // SPLASH::run_all, src/SPLASH.cpp:1833-1916 (+ sm_lim and monthly aggregation of
 // R/splash.point.R:197-214, + monthly grid totals for the water-balance diagnostics).
 // outputs in order: wn, ro, pet, aet, snow, cond, bflow, netr, sm_lim
@@ -363,12 +477,11 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
     if (threadIdx.x == 0) s_site_on = 1;
     __syncthreads();
 #endif
-    __shared__ double red[DIAG ? 4 * SPLASH_NDIAG_K : 1];
     size_t cell = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool valid = cell < a.ncell;
     const size_t ci = valid ? cell : a.ncell - 1;
     Forcing f{a.sw, a.tc, a.pn, a.snowfall, a.ldf, a.Tt ? a.Tt[ci] : 0.0,
-              a.par[P_ELV * a.ldp + ci] * 0.0004596581 + fabs(a.par[P_LAT * a.ldp + ci]) * 0.0110592101,
+              a.par[P_ELV * a.ldp + ci] * 0.0004596581, fabs(a.par[P_LAT * a.ldp + ci]) * 0.0110592101,
               (unsigned)(ci * sizeof(double))};
     const DayTable days = day_table(a.days);
     CellConst c;
@@ -423,6 +536,14 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
                 if (omask & (1u << q))
                     __builtin_nontemporal_store(
                         v[q], reinterpret_cast<double*>(reinterpret_cast<char*>(a.out[q] + row) + f.off));
+            if (OUTMASK == 0) { // general variant only: the state series run_all also returns
+                const double x[3] = {st.qin, st.td, st.nd}; // qin_prev, tdrain, snwage (:1913-1915)
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+                    if (a.extra[q])
+                        __builtin_nontemporal_store(
+                            x[q], reinterpret_cast<double*>(reinterpret_cast<char*>(a.extra[q] + row) + f.off));
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < 9; q++) acc[q] += v[q];
@@ -453,22 +574,12 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
                 }
             }
             if (DIAG) {
-                double w[SPLASH_NDIAG_K] = {dg[0], dg[1], dg[2], dg[3],
-                                            month_end ? st.wn : 0.0, month_end ? st.snow : 0.0};
-                const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-                for (int q = 0; q < SPLASH_NDIAG_K; q++) {
-                    double s = wave_sum(valid ? w[q] : 0.0);
-                    if (lane == 0) red[wave * SPLASH_NDIAG_K + q] = s;
-                }
-                __syncthreads();
-                if (threadIdx.x < SPLASH_NDIAG_K) {
-                    double s = red[threadIdx.x] + red[SPLASH_NDIAG_K + threadIdx.x] +
-                               red[2 * SPLASH_NDIAG_K + threadIdx.x] +
-                               red[3 * SPLASH_NDIAG_K + threadIdx.x];
-                    a.diag_part[((size_t)blockIdx.x * a.nmonth + m) * SPLASH_NDIAG_K + threadIdx.x] += s;
-                }
-                __syncthreads();
+                // flux totals of the (part of the) month inside this call; the storages wn and
+                // snow and the cell-month count only at the month's real last day
+                const double w[SPLASH_NDIAG_K] = {dg[0], dg[1], dg[2], dg[3],
+                                                  month_end ? st.wn : 0.0, month_end ? st.snow : 0.0};
+                diag_add(a.diag_acc, a.basin, a.n_basin, a.nmonth_cal, d.month_id, ci, valid, w,
+                         month_end);
 #pragma unroll
                 for (int q = 0; q < 4; q++) dg[q] = 0.0;
             }
@@ -492,7 +603,7 @@ __global__ __launch_bounds__(64) void k_run_all_mod(RunArgs a)
     lds_tables_init();
     size_t cell = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (cell >= a.ncell) return;
-    Forcing f{a.sw, a.tc, a.pn, a.snowfall, a.ldf, 0.0, 0.0, (unsigned)(cell * sizeof(double))};
+    Forcing f{a.sw, a.tc, a.pn, a.snowfall, a.ldf, 0.0, 0.0, 0.0, (unsigned)(cell * sizeof(double))};
     CellConst c;
     cell_setup(c, a.par, a.ldp, cell, a.par[P_CELLOUT * a.ldp + cell]);
     State st{a.state[cell], a.state[a.lds + cell], a.state[2 * a.lds + cell],
@@ -513,20 +624,6 @@ __global__ __launch_bounds__(64) void k_run_all_mod(RunArgs a)
         if (a.extra[1]) a.extra[1][k] = st.td;
         if (a.extra[2]) a.extra[2][k] = st.nd;
     }
-}
-
-// fixed-order reduction of the per-workgroup diagnostic partials: diag[m][k] += sum_b part[b][m][k]
-// one wavefront per element: lane l sums blocks l, l+64, ... then a butterfly (deterministic)
-__global__ __launch_bounds__(64) void k_diag_reduce(const double* __restrict__ part,
-                                                   size_t nblocks, int nmonth,
-                                                   double* __restrict__ diag)
-{
-    const int e = blockIdx.x;
-    const size_t stride = (size_t)nmonth * SPLASH_NDIAG_K;
-    double s = 0.0;
-    for (size_t b = threadIdx.x; b < nblocks; b += 64) s += part[b * stride + e];
-    s = wave_sum(s);
-    if (threadIdx.x == 0) diag[e] += s;
 }
 
 // ================================================================ unSWC ==========
@@ -666,6 +763,24 @@ __global__ __launch_bounds__(kBlock) void k_math_probe(size_t n, const double* x
     out[4 * n + i] = fsqrt(x[i]);
 }
 
+// The day loop's own forms of moist_surf() and inf_GA() (splash_device.hpp: shared log/exp algebra,
+// reciprocal-based divisions, surface moisture only inside the ponding branch) for n independent
+// (cell, wn, Ksat_visc, P) rows -- the code run_one_day's restatement actually executes, as opposed
+// to the literal module mirrors below.
+__global__ __launch_bounds__(kBlock) void k_infiltration_probe(size_t n, const double* par,
+                                                              const double* wn, const double* ksat,
+                                                              const double* P, double* theta_surf,
+                                                              double* infi)
+{
+    lds_tables_init();
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    CellConst c;
+    cell_setup(c, par, n, i, par[P_CELLOUT * n + i]);
+    theta_surf[i] = moist_surf(c, wn[i]);
+    infi[i] = inf_GA(c, wn[i], ksat[i], P[i]);
+}
+
 // general-argument forms of the two exported helper methods (src/SPLASH.cpp:1921-1961, 1963-2023)
 __global__ void k_moist_surf(double depth, double z, double bub_p, double wn, double SAT,
                              double RES, double lambda, double* out)
@@ -714,6 +829,14 @@ __global__ void k_inf_GA(double bub_press, double theta_i, double Ksat, double t
     }
     if (I > P) I = P;
     *out = I;
+}
+
+// single-precision transport of forcing rasters (FLT4S in the reference): widen on the device
+__global__ __launch_bounds__(kBlock) void k_widen_f32(const float* __restrict__ src, size_t n,
+                                                     double* __restrict__ dst)
+{
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+        dst[i] = (double)__builtin_nontemporal_load(&src[i]);
 }
 
 // ================================================================ synthetic inputs =============
@@ -870,9 +993,10 @@ hipError_t launch_run_all(const RunArgs& a, hipStream_t s)
 #endif
     if (a.ncell == 0 || a.nt == 0) return hipSuccess;
     dim3 g(nblk(a.ncell, kBlock)), b(kBlock);
-    const bool diag = a.diag_part != nullptr;
+    const bool diag = a.diag_acc != nullptr;
     unsigned mask = 0;
     for (int q = 0; q < 9; q++) mask |= (a.out[q] != nullptr ? 1u : 0u) << q;
+    if (a.extra[0] || a.extra[1] || a.extra[2]) mask = 0x200u; // only the general variant stores them
     if (a.monthly) {
         if (diag)
             hipLaunchKernelGGL((k_run_all<true, true, 0>), g, b, 0, s, a);
@@ -904,16 +1028,23 @@ hipError_t launch_run_all_mod(const RunArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_diag_reduce(const double* part, size_t nblocks, int nmonth, double* diag,
-                              hipStream_t s)
+hipError_t launch_diag_finalize(const long long* acc, int n_rec, double* diag, double* counts,
+                                hipStream_t s)
 {
-    int e = nmonth * SPLASH_NDIAG_K;
-    if (e == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_diag_reduce, dim3(e), dim3(64), 0, s, part, nblocks, nmonth, diag);
+    if (n_rec <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_diag_finalize, dim3(nblk((size_t)n_rec, kBlock)), dim3(kBlock), 0, s, acc,
+                       n_rec, diag, counts);
     return hipGetLastError();
 }
 
-size_t run_all_blocks(size_t ncell) { return nblk(ncell, kBlock); }
+hipError_t launch_widen_f32(const float* src, size_t n, double* dst, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const size_t nb = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)(nb < 65536 ? nb : 65536)), dim3(kBlock), 0, s, src,
+                       n, dst);
+    return hipGetLastError();
+}
 
 hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, const double* sw,
                              const double* dr, const double* sd, const double* cd,
@@ -941,6 +1072,16 @@ hipError_t launch_math_probe(size_t n, const double* x, const double* y, double*
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_math_probe, dim3(nblk(n, kBlock)), dim3(kBlock), 0, s, n, x, y, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_infiltration_probe(size_t n, const double* par, const double* wn,
+                                     const double* ksat, const double* P, double* theta_surf,
+                                     double* infi, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_infiltration_probe, dim3(nblk(n, kBlock)), dim3(kBlock), 0, s, n, par, wn,
+                       ksat, P, theta_surf, infi);
     return hipGetLastError();
 }
 

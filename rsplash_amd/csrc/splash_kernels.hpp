@@ -80,8 +80,13 @@ struct RunArgs {
     int monthly;
     int month0;       // month_id of day t0
     int head_partial; // month0 began before t0 (add to the stored partial)
-    double* diag_part;
-    int nmonth;
+    int nmonth;       // months touched by [t0, t0+nt)
+    // K7 water-balance totals (see include/splash_hip.h): exact fixed-point limbs, added with
+    // integer atomics into acc[basin][month_id][SPLASH_NDIAG+1][2]
+    long long* diag_acc;
+    const int* basin; // [ncell] or NULL
+    int n_basin;
+    int nmonth_cal;   // months in the whole calendar (row stride of diag_acc)
 };
 
 hipError_t launch_soil_hydro(size_t ncell, const double* lat, const double* elev,
@@ -94,9 +99,9 @@ hipError_t launch_spin_up_mod(const SpinArgs& a, double* const* series_dev, size
                               const double* snowfall, hipStream_t s);
 hipError_t launch_run_all(const RunArgs& a, hipStream_t s);
 hipError_t launch_run_all_mod(const RunArgs& a, hipStream_t s);
-hipError_t launch_diag_reduce(const double* part, size_t nblocks, int nmonth, double* diag,
-                              hipStream_t s);
-size_t run_all_blocks(size_t ncell);
+hipError_t launch_diag_finalize(const long long* acc, int n_rec, double* diag, double* counts,
+                                hipStream_t s);
+hipError_t launch_widen_f32(const float* src, size_t n, double* dst, hipStream_t s);
 hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, const double* sw,
                              const double* dr, const double* sd, const double* cd,
                              const double* sw_in, const double* tc, const double* slop,
@@ -106,6 +111,9 @@ hipError_t launch_unswc(size_t ncell, int nt, const double* wn, size_t ldw, cons
                         double uns_depth, double* wn_z, double* wtd, double* theta, size_t ldo,
                         hipStream_t s);
 hipError_t launch_math_probe(size_t n, const double* x, const double* y, double* out, hipStream_t s);
+hipError_t launch_infiltration_probe(size_t n, const double* par, const double* wn,
+                                     const double* ksat, const double* P, double* theta_surf,
+                                     double* infi, hipStream_t s);
 hipError_t launch_moist_surf(double depth, double z, double bub_p, double wn, double SAT,
                              double RES, double lambda, double* out, hipStream_t s);
 hipError_t launch_inf_GA(double bub_press, double theta_i, double Ksat, double theta_s,

@@ -96,3 +96,26 @@ def test_two_rank_partition_and_diag_allreduce(oracle):
             ref = np.array([res[k][mid == m].sum() for m in range(nm)])
             assert np.allclose(d[:, j], ref, rtol=1e-12)
     assert np.array_equal(got[0][2], got[1][2])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` (no torch.distributed.run around it) starts N fresh rank processes
+    before anything touches a GPU, rendezvous on 127.0.0.1, and relays rank 0's single JSON line;
+    a failing rank makes the launcher fail.  (Dry run: gloo, no GPU, no compute.)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SPLASH_BENCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"dryrun": True, "n_gpus": 3, "sum_of_ranks": 6.0}
+    # without a GPU the real ranks refuse loudly and the launcher reports the failure
+    env.pop("SPLASH_BENCH_DRYRUN")
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

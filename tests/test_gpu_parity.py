@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 
 from conftest import rel_err
+from gpu_pipeline import (assert_one_step, assert_trajectory, assert_whole_pipeline,
+                          device_pipeline)
 
 pytestmark = pytest.mark.gpu
 
@@ -153,11 +155,12 @@ def test_day_step_transitions_random_and_edges(api, oracle):
         s1, e1 = oracle.run_one_day(lat, elv, doy, yr, wn, sw_in, tc, pn, slop, asp, snow, snf, si, qin,
                                     td, nd)
         from oracle.binding import grazing_mask
-        if abs(si[4]) < 0.01 or oracle.fragile_events() > 0 or \
+        if oracle.fragile_events() > 0 or \
                 grazing_mask(oracle, np.array([lat]), np.array([slop]), np.array([asp]),
                              np.array([doy], np.int32), np.array([yr], np.int32)).any():
             continue  # conditioning classes (DESIGN "Conditioning")
-        dbg = (C.c_double * 16).in_dll(oracle.lib, "orc_debug")
+        oracle.lib.orc_debug_ptr.restype = C.POINTER(C.c_double * 16)
+        dbg = oracle.lib.orc_debug_ptr().contents
         if 0.0 < abs(dbg[6]) < 1e-10:
             # the bucket started at SAT and overflowed: what is left of the recharge after
             # `R -= ro_d` (src/SPLASH.cpp:1386-1390) is the rounding residual of (SAT + R) - SAT,
@@ -283,7 +286,7 @@ def test_splash_point_atneu(api, oracle, atneu, slop, asp):
     o, aux = oracle.point(b["doy"], b["year"], b["month"], b["month_id"], b["nmonth"], b["sw_in"],
                           b["Ta"], b["P"], s["latitude"], s["elev_m"], slop, asp, b["soil"],
                           [au, 3, 3], 250.0)
-    assert aux["fragile"] == 0
+    assert aux["critical"] == 0
     worst = {k: close(g[k], o[k], f"atneu[{slop}].{k}") for k in o}
     print("max rel err", {k: f"{v:.2e}" for k, v in worst.items()})
 
@@ -308,13 +311,13 @@ def test_splash_grid_sa_cru_statics(api, oracle, sa_cru):
                          res, monthly_out=True)
     land = ~np.isnan(o["wn"][0])
     assert 6000 < land.sum() < 6200
-    ok = land & (aux["fragile"] == 0) & (aux["soil_info"][:, 4] >= 0.01)
-    assert ok.sum() > 0.97 * land.sum()
     for k in o:
         assert np.isnan(g[k][:, ~land]).all() and np.isfinite(g[k][:, land]).all(), k
+    r = assert_whole_pipeline(oracle, g, o, aux, dict(lat=lat, slop=flat, asp=flat), doy, year, "sa_cru",
+                              monthly_mid=mid)
+    ok = r.pop("ok") & land
     assert np.array_equal(g["aux"]["passes2"][ok], aux["passes2"][ok])
-    worst = {k: close(g[k][:, ok], o[k][:, ok], "sa_cru." + k) for k in o}
-    print("max rel err", {k: f"{v:.2e}" for k, v in worst.items()}, "set aside:", int((land & ~ok).sum()))
+    print(r)
 
 
 # ---------------------------------------------------------------- splash.grid
@@ -339,15 +342,15 @@ def test_splash_grid_synthetic(api, oracle, terrain, monthly):
                          d["pn"], st["lat"], st["elev"], st["slop"], st["asp"], st["soil"],
                          st["au"], st["resolution"], monthly_out=monthly)
     assert np.array_equal(g["aux"]["Tt"], aux["Tt"])
-    # cells in which the reference computed a drainage time from a rounding-noise transmittance
-    # (DESIGN.md "Conditioning") are set aside; there must be few of them
-    ok = (aux["fragile"] == 0) & (aux["soil_info"][:, 4] >= 0.01)
-    assert ok.mean() > 0.9
+    # strict for every cell without a critical event of the reference (DESIGN.md "Conditioning");
+    # of the cells with one, at most a few per cent may differ
+    r = assert_whole_pipeline(oracle, g, o, aux, st, d["doy"], d["year"], f"grid[{terrain},{monthly}]",
+                              monthly_mid=d["mid"] if monthly else None)
+    ok = r.pop("ok")
+    print(r)
     assert np.array_equal(g["aux"]["passes1"][ok], aux["passes1"][ok])
     assert np.array_equal(g["aux"]["passes2"][ok], aux["passes2"][ok])
     close(g["aux"]["AI"][ok], aux["AI"][ok], "AI", rtol=1e-10)
-    worst = {k: close(g[k][:, ok], o[k][:, ok], f"grid[{terrain},{monthly}].{k}") for k in o}
-    print("max rel err", {k: f"{v:.2e}" for k, v in worst.items()}, "set aside:", int((~ok).sum()))
     close(g["state_end"][[0, 1, 2]][:, ok], aux["state1"].T[[0, 1, 2]][:, ok], "state_end")
     assert np.array_equal(g["state_end"][4][ok], aux["state1"][:, 4][ok])
     for k in o:
@@ -360,6 +363,14 @@ def test_splash_grid_synthetic(api, oracle, terrain, monthly):
         last = np.array([np.where(d["mid"] == m)[0][-1] for m in range(d["nm"])])
         assert np.allclose(g["diag"]["wn"], o["wn"][last].sum(1), rtol=1e-10)
         assert np.allclose(g["diag"]["snow"], o["snow"][last].sum(1), rtol=1e-9, atol=1e-9)
+        assert (g["diag_cells"] == H * W).all()
+    if not monthly:
+        # the totals are exact sums of the GPU's own cell values (fixed point, order free): equal
+        # to a long-double sum of the returned rasters to the last bits of a double
+        mids = d["mid"]
+        for k in ("aet", "ro", "bflow"):
+            ref = np.array([g[k][mids == m].astype(np.longdouble).sum() for m in range(d["nm"])])
+            assert np.allclose(g["diag"][k], ref.astype(np.float64), rtol=1e-13, atol=1e-10), k
 
 
 def test_splash_grid_writes_reference_named_bricks(api, oracle, tmp_path):
@@ -546,54 +557,237 @@ def test_config1_flat_256x256_properties(api):
     cal.close()
 
 
-def test_high_latitude_steep_slopes_and_conditioning(api, oracle):
-    """First rows of the 4096-row benchmark grid (lat ~ 60 N, slopes up to 30 deg, winter sun
-    grazing the slopes).  Where the sunset angle on the slope is ~0 but not 0 the reference divides
-    by a geometry integral that cancels to rounding noise (oracle.binding.grazing_mask, DESIGN.md
-    "Conditioning"): those cell-days cannot agree between two libm implementations.  Every other
-    cell must meet the tolerance; the flagged ones must stay finite and bounded."""
-    import torch
-    from oracle.binding import grazing_mask
-    dev = torch.device("cuda:0")
-    Htot, W, rows, nt, seed = 4096, 4096, 8, 365, 20221130
-    n = rows * W
-    dates = np.datetime64("2001-01-01") + np.arange(nt)
-    cal = api.Calendar.from_dates(dates)
+CASES = {
+    # name: (seed, Htot, W, cell0, cells, days, terrain, start)
+    "terrain": (777000, 64, 128, 0, 8192, 730, 1, "01-01"),
+    # first rows of the 4096-row benchmark grid: lat ~60 N, slopes up to 30 deg, winter sun grazing
+    # the slopes (0 < hs < 2e-3 deg: the reference's daily radiation is rounding noise there)
+    "benchmark-rows-60N": (20221130, 4096, 4096, 0, 4 * 4096, 365, 1, "01-01"),
+    "flat": (816595, 32, 128, 0, 4096, 400, 0, "01-01"),
+    # a series that starts in October: the spin-up still runs day-of-year 1..365 of the first year
+    "starts-in-october": (784919, 32, 128, 0, 4096, 500, 1, "10-01"),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_every_cell_day_one_step_and_trajectory(api, oracle, case):
+    """The device pipeline (soil_hydro, snow threshold, both spin-ups, run_all with all 11 daily
+    series) against the oracle on EVERY cell-day, two ways (tests/gpu_pipeline.py): one-step (the
+    oracle re-does each day from the GPU's previous-day state: nothing can hide behind an earlier
+    difference) and trajectory (the oracle carries its own state like SPLASH::run_all).  Set aside
+    are only cell-days on which the reference disagrees with itself (profiles/r02_conditioning.md)."""
+    seed, Htot, W, cell0, n, nt, terrain, start = CASES[case]
+    p = device_pipeline(api, seed, Htot, W, cell0, n, nt, terrain, start=start)
+    r1 = assert_one_step(oracle, p, case)
+    print("one-step", r1)
+    r2 = assert_trajectory(oracle, p, case)
+    print("trajectory", r2)
+    if case == "benchmark-rows-60N":
+        assert r1["grazing"] > 0  # the class exists on this grid
+    # snow age is index-like: identical wherever the snow pack is
+    assert np.isfinite(p["out"]["wn"]).all()
+
+
+def test_spin_up_runs_on_day_of_year_1_to_365_of_the_first_year(api, oracle):
+    """src/SPLASH.cpp:1658/1674 + R/splash.point.R:141-152: spin_up(365, y[1], ...) evaluates
+    quick_run(i+1, y, ...) -- orbit of day-of-year 1..365 of the first year -- on the first 365
+    RECORDS, whatever their dates (while the rain/snow split keeps the records' real months).
+    Whole pipeline against the oracle's splash.grid restatement for a series starting 2001-10-01."""
+    H, W, nt = 8, 64, 500
+    n = H * W
+    dates = np.datetime64("2001-10-01") + np.arange(nt)
     doy, year, month = api.time_fields(dates)
-    f64 = dict(dtype=torch.float64, device=dev)
-    lat, elev, slop, asp, res = (torch.empty(n, **f64) for _ in range(5))
-    soil, au = torch.empty(6, n, **f64), torch.empty(3, n, **f64)
-    api.dev_synth_statics(seed, Htot, W, 0, n, 1, lat, elev, slop, asp, res, soil, au)
-    sw, tc, pn = (torch.empty(nt, n, **f64) for _ in range(3))
-    api.dev_synth_forcing(seed, cal, 0, nt, 0, n, lat, elev, sw, tc, pn, n)
-    par = torch.empty(api.NPAR, n, **f64)
-    Tt = torch.empty(n, **f64)
-    state = torch.empty(api.NSTATE, n, **f64)
-    api.dev_soil_hydro(n, lat, elev, slop, asp, res, soil, au, par)
-    api.dev_snow_threshold(n, nt, tc, n, par, n, Tt)
-    work = torch.empty(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
-    api.dev_spin_up(cal, n, sw, tc, pn, n, Tt, par, n, state, n, work)
-    state0 = state.clone()
-    names = ("wn", "snow", "ro", "aet", "pet")
-    g = {k: torch.empty(nt, n, **f64) for k in names}
-    api.dev_run_all(cal, 0, nt, n, sw, tc, pn, n, Tt, par, n, state, n, g, n)
+    mid = api.month_ids(year, month)
+    nm = int(mid[-1]) + 1
+    st = oracle.synth_statics(4242, H, W, 0, n, 1)
+    sw, tc, pn = oracle.synth_forcing(4242, H, W, 0, n, 273, doy, st["lat"], st["elev"])
+    g = api.splash_grid(sw, tc, pn, st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"],
+                        st["resolution"], time_index=dates, sim_control=dict(monthly_out=False),
+                        want_aux=True)
+    o, aux = oracle.grid(doy, year, month, mid, nm, sw, tc, pn, st["lat"], st["elev"], st["slop"],
+                         st["asp"], st["soil"], st["au"], st["resolution"])
+    r = assert_whole_pipeline(oracle, g, o, aux, st, doy, year, "october")
+    ok = r.pop("ok")
+    print(r)
+    close(g["aux"]["AI"][ok], aux["AI"][ok], "AI", rtol=1e-10)
+    assert np.array_equal(g["aux"]["passes2"][ok], aux["passes2"][ok])
+    # and it matters: spinning up on the records' own day numbers gives another aridity index
+    st0 = np.stack([g["state_end"][k] for k in range(3)])
+    assert np.isfinite(st0).all()
+
+
+def test_gaps_in_the_forcing_propagate_like_NA_in_R(api, oracle):
+    """NaN later in a series is not a cell mask (R/splash.point.R:120-128): one missing tc makes
+    Tt = max(tc[p_snow >= 0.5]) NA, hence NA rain and snowfall on every day with p_snow >= 0.5 and on
+    the gap day itself; a missing sw_in or pn poisons the day it falls on.  Same NaN pattern and
+    same numbers as the oracle."""
+    H, W, nt = 2, 32, 450
+    n = H * W
+    d = _synth(oracle, H, W, nt, 1, seed=99)
+    st = d["st"]
+    sw, tc, pn = d["sw"].copy(), d["tc"].copy(), d["pn"].copy()
+    tc[400, 3] = np.nan   # after the spin-up year
+    tc[100, 7] = np.nan   # inside it
+    sw[420, 11] = np.nan
+    pn[380, 13] = np.nan
+    g = api.splash_grid(sw, tc, pn, st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"],
+                        st["resolution"], time_index=d["dates"], sim_control=dict(monthly_out=False),
+                        want_aux=True)
+    o, aux = oracle.grid(d["doy"], d["year"], d["month"], d["mid"], d["nm"], sw, tc, pn, st["lat"],
+                         st["elev"], st["slop"], st["asp"], st["soil"], st["au"], st["resolution"])
+    assert np.isnan(aux["Tt"][[3, 7]]).all() and np.isnan(g["aux"]["Tt"][[3, 7]]).all()
+    assert np.array_equal(np.isnan(g["aux"]["Tt"]), np.isnan(aux["Tt"]))
+    gaps = [3, 7, 11, 13]
+    for k in ("wn", "snow", "ro", "aet", "pet"):
+        assert np.array_equal(np.isnan(g[k][:, gaps]), np.isnan(o[k][:, gaps])), k
+        assert np.isnan(o[k][:, gaps]).any()
+        close(g[k][:, gaps], o[k][:, gaps], "gaps." + k)
+    r = assert_whole_pipeline(oracle, g, o, aux, st, d["doy"], d["year"], "gaps")
+    r.pop("ok")
+    print(r)
+
+
+def test_soil_hydro_cellpar_direct(api, oracle, sa_cru):
+    """K1 alone: dev_soil_hydro's cellpar rows against orc_soil_info for every land cell of the
+    reference's bundled South America soils (up to 45 % organic matter, 51 % gravel) and for
+    synthetic soils with a missing bulk density (R/splash.point.R:276)."""
+    import torch
+    land = ~np.isnan(sa_cru["elev"])
+    soil = sa_cru["soil"][:, land].copy()
+    n0 = soil.shape[1]
+    rng = np.random.default_rng(8)
+    extra = np.stack([rng.uniform(5, 90, 500), rng.uniform(2, 60, 500), rng.uniform(0.1, 40, 500),
+                      rng.uniform(0, 60, 500), np.full(500, np.nan), rng.uniform(0.3, 3.0, 500)])
+    soil = np.concatenate([soil, extra], axis=1)
+    n = soil.shape[1]
+    au = np.stack([rng.uniform(0, 1e7, n), rng.integers(1, 4, n).astype(float), np.full(n, 3.0)])
+    res = rng.uniform(100, 60000, n)
+    lat, elev, slop, asp = rng.uniform(-60, 60, n), rng.uniform(0, 4000, n), rng.uniform(0, 40, n), \
+        rng.uniform(0, 360, n)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    par = torch.empty(api.NPAR, n, dtype=torch.float64, device="cuda")
+    api.dev_soil_hydro(n, t(lat), t(elev), t(slop), t(asp), t(res), t(soil), t(au), par)
     torch.cuda.synchronize()
-    hp = par.cpu().numpy()
-    out, _ = oracle.grid_transient(doy, year, month, sw.cpu().numpy(), tc.cpu().numpy(),
-                                   pn.cpu().numpy(), hp[0], hp[1], hp[2], hp[3], hp[4:16],
-                                   Tt.cpu().numpy(), state0.cpu().numpy(), n_threads=8)
-    graz = grazing_mask(oracle, hp[0], hp[2], hp[3], doy, year)
-    okc = ~graz.any(0)
-    assert 0 < (~okc).sum() < 0.02 * n
-    okc &= oracle.fragile == 0  # second ill-conditioned class: noise-level drainage denominator
-    okc &= hp[8] >= 0.01        # third: pore-size index lambda < 0.01 (retention curve exponents
-    #                             > 100..10000: Theta^(1/lambda) is a step function, chaotic bucket)
-    assert okc.mean() > 0.97
-    for i, k in enumerate(names):
-        a, b = g[k].cpu().numpy(), out[i]
-        assert np.isfinite(a).all()
-        close(a[:, okc], b[:, okc], "well-conditioned." + k)
-    cal.close()
+    par = par.cpu().numpy()
+    ref = np.empty((13, n))
+    for i in range(n):
+        si, wmax = oracle.soil_info(soil[:, i], au[:, i], res[i])
+        ref[:12, i], ref[12, i] = si, wmax
+    assert n0 > 6000
+    assert np.array_equal(par[0], lat) and np.array_equal(par[1], elev) and np.array_equal(par[2], slop)
+    assert np.array_equal(par[3], asp - 180)
+    names = ("SAT", "WP", "FC", "Ksat", "lambda", "depth", "bub_press", "RES", "Au", "Ai", "ncellin",
+             "ncellout", "Wmax_R")
+    for k, nm_ in enumerate(names):
+        rel, ab = rel_err(par[4 + k], ref[k])
+        assert rel <= 1e-12, f"cellpar.{nm_}: rel {rel:.2e} abs {ab:.2e}"
+
+
+def test_hot_path_moist_surf_and_inf_GA(api, oracle):
+    """The day loop's OWN moist_surf()/inf_GA() (shared log/exp algebra, reciprocal divisions,
+    surface moisture only inside the ponding branch: splash_device.hpp) against the literal
+    restatement of src/SPLASH.cpp:1921-1961, 1963-2023 -- including every branch: no ponding,
+    saturated surface, tp guard, cap at P, dry end (wn = RES), wn < RES, wn = SAT."""
+    rng = np.random.default_rng(21)
+    n = 20000
+    st = oracle.synth_statics(5150, 100, 200, 0, n, 1)
+    par = np.empty((17, n))
+    for i in range(n):
+        si, wmax = oracle.soil_info(st["soil"][:, i], st["au"][:, i], st["resolution"][i])
+        par[4:16, i], par[16, i] = si, wmax
+    par[0], par[1], par[2], par[3] = st["lat"], st["elev"], st["slop"], st["asp"] - 180
+    SAT, RES, Ksat = par[4], par[11], par[7]
+    u = rng.random(n)
+    wn = RES + (SAT - RES) * u
+    pick = rng.integers(0, 10, n)
+    wn = np.where(pick == 0, RES, np.where(pick == 1, SAT, np.where(pick == 2, RES - 1.0, wn)))
+    kv = Ksat * rng.uniform(0.4, 1.6, n)
+    P = np.where(rng.random(n) < 0.2, 0.0, kv * 6.0 * np.exp(rng.normal(0.5, 1.5, n)))
+    th, inf = api.infiltration_probe(par, wn, kv, P)
+    L = oracle.lib
+    th_ref, inf_ref = np.empty(n), np.empty(n)
+    for i in range(n):
+        depth, bub, lam = par[9, i], par[10, i], par[8, i]
+        th_ref[i] = L.orc_moist_surf(depth, 10.0, bub, wn[i], SAT[i], RES[i], lam)
+        inf_ref[i] = L.orc_inf_GA(bub, th_ref[i], kv[i], SAT[i] / (depth * 1000.0), lam, P[i], 6.0,
+                                  st["slop"][i])
+    ponding = P / 6.0 > kv
+    assert 0.2 < ponding.mean() < 0.8 and (inf_ref < P).mean() > 0.1 and (inf_ref == P).mean() > 0.1
+    r1, a1 = rel_err(th, th_ref)
+    r2, a2 = rel_err(inf, inf_ref)
+    print(f"moist_surf rel {r1:.2e}, inf_GA rel {r2:.2e}")
+    assert r1 <= 1e-11 and r2 <= 1e-9
+
+
+def test_basin_totals_are_exact_and_split_independent(api, oracle):
+    """K7: monthly water-balance totals per basin id.  The accumulators are fixed-point integers
+    (include/splash_hip.h), so the totals are (i) the exact sums of the cells' monthly values,
+    (ii) bitwise identical however the grid is cut into launches or spread over devices (here: two
+    workers on the one GPU), and an all-reduce of the limbs over ranks is exact."""
+    H, W, nt = 16, 64, 400
+    n = H * W
+    d = _synth(oracle, H, W, nt, 1, seed=606)
+    st = d["st"]
+    rng = np.random.default_rng(4)
+    nb = 7
+    # spatially coherent basins (blocks of columns) with a noisy border and a few cells outside any basin
+    basin = (np.arange(n) % W) * nb // W
+    flip = rng.random(n) < 0.1
+    basin[flip] = rng.integers(0, nb, flip.sum())
+    basin[rng.random(n) < 0.02] = -1
+    kw = dict(time_index=d["dates"], sim_control=dict(monthly_out=False), want_diag=True, basin=basin,
+              n_basin=nb)
+    args = (d["sw"], d["tc"], d["pn"], st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"],
+            st["resolution"])
+    g = api.splash_grid(*args, **kw)
+    g2 = api.splash_grid(*args, max_cells_per_launch=300, **kw)
+    g3 = api.splash_grid(*args, devices=[0, 0], **kw)
+    assert np.array_equal(g["diag_acc"], g2["diag_acc"]) and np.array_equal(g["diag_acc"], g3["diag_acc"])
+    for k in ("wn", "ro", "aet", "pet", "snow", "bflow", "cond", "netr", "sm_lim"):
+        assert np.array_equal(g[k], g3[k]), k
+    mid, nm = d["mid"], d["nm"]
+    last = np.array([np.where(mid == m)[0][-1] for m in range(nm)])
+    for b in range(nb):
+        cells = basin == b
+        assert (g["diag_cells"][b] == cells.sum()).all()
+        for k in ("aet", "ro", "bflow"):
+            ref = np.array([g[k][mid == m][:, cells].astype(np.longdouble).sum() for m in range(nm)])
+            assert np.allclose(g["diag"][k][b], ref.astype(float), rtol=1e-13, atol=1e-10), (b, k)
+        for k in ("wn", "snow"):
+            ref = g[k][last][:, cells].astype(np.longdouble).sum(1).astype(float)
+            assert np.allclose(g["diag"][k][b], ref, rtol=1e-13, atol=1e-10), (b, k)
+    # against the oracle's cells (tolerance of the series themselves)
+    o, aux = oracle.grid(d["doy"], d["year"], d["month"], mid, nm, d["sw"], d["tc"], d["pn"], st["lat"],
+                         st["elev"], st["slop"], st["asp"], st["soil"], st["au"], st["resolution"])
+    for b in range(nb):
+        cells = (basin == b) & (aux["critical"] == 0)
+        if cells.sum() == (basin == b).sum():
+            ref = np.array([o["aet"][mid == m][:, cells].sum() for m in range(nm)])
+            assert np.allclose(g["diag"]["aet"][b], ref, rtol=1e-6)
+    # host-side finalize of summed limbs == what the library returned
+    tot, cnt = api.diag_finalize_host(g["diag_acc"])
+    assert np.array_equal(tot[:, :, 1], g["diag"]["aet"])
+
+
+def test_single_precision_transport_is_lossless(api, oracle):
+    """forcing handed over as float32 (the reference's rasters are FLT4S; the synthetic forcing is
+    float-representable) gives bit-identical results to the float64 hand-over"""
+    H, W, nt = 4, 64, 400
+    d = _synth(oracle, H, W, nt, 1, seed=17)
+    st = d["st"]
+    f32 = [x.astype(np.float32) for x in (d["sw"], d["tc"], d["pn"])]
+    for a, b in zip(f32, (d["sw"], d["tc"], d["pn"])):
+        assert np.array_equal(a.astype(np.float64), b)
+    rest = (st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"], st["resolution"])
+    kw = dict(time_index=d["dates"], sim_control=dict(monthly_out=False))
+    g64 = api.splash_grid(d["sw"], d["tc"], d["pn"], *rest, **kw)
+    g32 = api.splash_grid(*f32, *rest, **kw)
+    for k in ("wn", "ro", "aet", "pet", "snow"):
+        assert np.array_equal(g64[k], g32[k]), k
+    # with NA cells too (gather path)
+    f32[1][:, 5] = np.nan
+    g32 = api.splash_grid(*f32, *rest, **kw)
+    assert np.isnan(g32["wn"][:, 5]).all() and np.array_equal(g32["wn"][:, 6:], g64["wn"][:, 6:])
 
 
 # ---------------------------------------------------------------- unSWC epilogue (SURVEY 8f-4)
@@ -644,10 +838,8 @@ def test_splash_grid_leap_year_calendar(api, oracle):
                         st["au"], st["resolution"], time_index=dates)  # monthly_out default TRUE
     o, aux = oracle.grid(doy, year, month, mid, nm, sw, tc, pn, st["lat"], st["elev"], st["slop"],
                          st["asp"], st["soil"], st["au"], st["resolution"], monthly_out=True)
-    ok = (aux["fragile"] == 0) & (aux["soil_info"][:, 4] >= 0.01)
-    assert g["wn"].shape == (nm, H * W) and ok.mean() > 0.9
-    for k in o:
-        close(g[k][:, ok], o[k][:, ok], "leap." + k)
+    assert g["wn"].shape == (nm, H * W)
+    print(assert_whole_pipeline(oracle, g, o, aux, st, doy, year, "leap", monthly_mid=mid))
 
 
 def test_polar_day_and_night(api, oracle):
@@ -666,13 +858,10 @@ def test_polar_day_and_night(api, oracle):
                         st["resolution"], time_index=dates, sim_control=dict(monthly_out=False))
     o, aux = oracle.grid(doy, year, month, mid, nm, sw, tc, pn, lat, st["elev"], st["slop"],
                          st["asp"], st["soil"], st["au"], st["resolution"])
-    from oracle.binding import grazing_mask
-    ok = (aux["fragile"] == 0) & (aux["soil_info"][:, 4] >= 0.01)
-    ok &= ~grazing_mask(oracle, lat, st["slop"], st["asp"] - 180, doy, year).any(0)
-    assert ok.mean() > 0.6 and (sw == 0).mean() > 0.05
+    assert (sw == 0).mean() > 0.05
     for k in o:
         assert np.isfinite(g[k]).all(), k
-        close(g[k][:, ok], o[k][:, ok], "polar." + k)
+    print(assert_whole_pipeline(oracle, g, o, aux, st, doy, year, "polar"))
 
 
 def test_config3_thirty_years_streamed_in_year_chunks(api, oracle):
@@ -720,13 +909,9 @@ def test_config3_thirty_years_streamed_in_year_chunks(api, oracle):
     sw, tc, pn = oracle.synth_forcing(seed, H, W, 0, n, 0, doy, st["lat"], st["elev"])
     o, aux = oracle.grid(doy, year, month, mid, nm, sw, tc, pn, st["lat"], st["elev"], st["slop"],
                          st["asp"], st["soil"], st["au"], st["resolution"], monthly_out=True)
-    from oracle.binding import grazing_mask
-    ok = (aux["fragile"] == 0) & (aux["soil_info"][:, 4] >= 0.01)
-    ok &= ~grazing_mask(oracle, st["lat"], st["slop"], st["asp"] - 180, doy[:366], year[:366]).any(0)
-    assert ok.mean() > 0.8
     assert np.array_equal(Tt.cpu().numpy(), aux["Tt"])
-    for k in names:
-        close(mon[k].cpu().numpy()[:, ok], o[k][:, ok], "30y." + k)
+    print(assert_whole_pipeline(oracle, {k: mon[k].cpu().numpy() for k in names}, o, aux, st, doy, year,
+                                "30y", names=names, monthly_mid=mid))
     cal.close()
 
 
@@ -755,13 +940,18 @@ def test_config4_cru_shaped_land_mask_with_grid_totals(api, oracle):
                         st["resolution"], time_index=dates, want_diag=True, want_aux=True)
     o, aux = oracle.grid(doy, year, month, mid, nm, sw, tc, pn, lat, elev, st["slop"], st["asp"],
                          soil, st["au"], st["resolution"], monthly_out=True)
-    ok = land & (aux["fragile"] == 0) & (np.where(land, aux["soil_info"][:, 4], 1.0) >= 0.01)
     for k in o:
         assert np.isnan(g[k][:, ~land]).all() and np.isnan(o[k][:, ~land]).all()
-        close(g[k][:, ok], o[k][:, ok], "cru." + k)
-    # grid totals over the land cells (what an all-reduce would sum across GPUs)
-    if (ok == land).all():
-        for k in ("aet", "ro", "bflow"):
+    r = assert_whole_pipeline(oracle, g, o, aux, st, doy, year, "cru", monthly_mid=mid)
+    ok = r.pop("ok")
+    print(r)
+    # grid totals over the land cells (what an all-reduce would sum across GPUs): exact sums of
+    # the GPU's own monthly values
+    assert (g["diag_cells"] == land.sum()).all()
+    for k in ("aet", "ro", "bflow"):
+        assert np.allclose(g["diag"][k], np.nansum(g[k].astype(np.longdouble), axis=1).astype(float),
+                           rtol=1e-12, atol=1e-9)
+        if (ok | ~land).all():
             assert np.allclose(g["diag"][k], np.nansum(o[k], axis=1), rtol=1e-9)
 
 

@@ -35,5 +35,6 @@ except Exception as e:
     print("no gpu:", e)
 sw = (wn - RES)/ (wmax - RES) if False else None
 import ctypes as C
-dbg = (C.c_double * 16).in_dll(oracle.lib, "orc_debug")
+oracle.lib.orc_debug_ptr.restype = C.POINTER(C.c_double * 16)
+dbg = oracle.lib.orc_debug_ptr().contents
 print('orc_debug Kb,Q,T,t_drain,q_in_f,q_in_o,R,Ksat_visc:', list(dbg)[:8])
