@@ -8,11 +8,11 @@ forcing, cellpar, Tt, spun-up state0 and the product's daily series) -- see DESI
                product's own state after day t-1, so a disagreement cannot propagate.  Only the
                cell-days on which the reference's own result is rounding noise (event bits of
                orc_grid_transient2; evidence in profiles/r02_conditioning.md) are set aside.
-  trajectory   the oracle carries its own state (what SPLASH::run_all does).  Strict except on a
-               grazing-sun day and from a cell's critical event on (a sticky infinite drainage time
-               the reference itself takes or not depending on the last bit of pow()); at most 5 % of
-               the critical-event cells may actually differ, and >= 1 - 1e-5 of ALL cell-days must
-               be within tolerance with nothing set aside.
+  trajectory   the oracle carries its own state (what SPLASH::run_all does).  Strict except from a
+               cell's grazing-sun day on and from a cell's critical event on (a sticky infinite
+               drainage time the reference itself takes or not depending on the last bit of pow());
+               at most 5 % of the critical-event cells may actually differ, and >= 1 - 1e-5 of ALL
+               cell-days must be within tolerance with nothing set aside.
 """
 import numpy as np
 
@@ -22,12 +22,40 @@ SERIES11 = ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "qin_prev
 EV_FRAGILE, EV_GRAZING, EV_RESIDUAL, EV_CRITICAL = 1, 2, 4, 8
 
 
-def _bad(a, b, rtol=RTOL, atol=ATOL):
+def _bad(a, b, rtol=RTOL, atol=ATOL, floor=None):
+    """|a - b| > rtol*|b| + atol (+ floor, an array: see aet_floor)"""
     with np.errstate(invalid="ignore"):
         d = np.abs(a - b)
-        out = ~(d <= rtol * np.abs(b) + atol)
+        lim = rtol * np.abs(b) + atol
+        if floor is not None:
+            lim = lim + np.nan_to_num(floor, nan=0.0, posinf=0.0)
+        out = ~(d <= lim)
     out &= ~((a == b) | (np.isnan(a) & np.isnan(b)))  # equal infinities / matching NaN are fine
     return out
+
+
+def aet_floor(pet_ref):
+    """Absolute floor of the aet comparison.  aet is an integral of the day's evaporative supply and
+    demand minus the snowmelt energy, clamped at 0 (src/EVAP.cpp:254-263); when it cancels to ~0
+    its rounding error is that of its terms, which are of the size of pet.  1e-7*pet keeps the
+    comparison two orders tighter than the tolerance relative to those terms."""
+    return 1e-7 * np.abs(pet_ref)
+
+
+def ro_floor(wn_ref):
+    """Absolute floor of the runoff comparison.  Dunne runoff is the bucket's overflow, ro_d = sm - SAT
+    (src/SPLASH.cpp:1383-1386): a difference of two numbers of the size of the column water, so its
+    absolute error is that of the bucket.  1e-10*wn (5e-8 mm for a 500 mm column) is five orders
+    tighter than the bucket's own tolerance and still far below any runoff that matters."""
+    return 1e-10 * np.abs(wn_ref)
+
+
+def _floor(k, ref):
+    if k == "aet" and "pet" in ref:
+        return aet_floor(ref["pet"])
+    if k == "ro" and "wn" in ref:
+        return ro_floor(ref["wn"])
+    return None
 
 
 def one_step_report(oracle, p, n_threads=0):
@@ -39,7 +67,7 @@ def one_step_report(oracle, p, n_threads=0):
     ref, _, ev, _ = oracle.grid_transient2(p["doy"], p["year"], p["month"], p["sw"], p["tc"], p["pn"],
                                            hp[0], hp[1], hp[2], hp[3], hp[4:16], p["Tt"], p["state0"],
                                            prev=prev, n_threads=n_threads)
-    bad = {k: _bad(g[k], ref[k]) for k in SERIES11}
+    bad = {k: _bad(g[k], ref[k], floor=_floor(k, ref)) for k in SERIES11}
     return dict(events=ev, bad=bad, ref=ref)
 
 
@@ -83,46 +111,54 @@ def trajectory_report(oracle, p, n_threads=0):
 
 
 def trajectory_summary(oracle, p, min_frac_all=1.0 - 1e-5, max_flip_frac=0.05, n_threads=0, names=OUT5):
-    """Strict for every cell-day that is neither a grazing-sun day nor at/after a critical event of
-    its cell (where the reference takes a sticky infinite drainage time or not depending on the last
-    bit of pow(), profiles/r02_conditioning.md).  The cells with a critical event may differ from
-    that day on, but only `max_flip_frac` of them; and `min_frac_all` of ALL cell-days, nothing set
-    aside, must be within tolerance.  Returns the figures plus 'violations' (list of messages)."""
+    """Strict for every cell-day that is not at/after a conditioning event of its cell:
+      * a grazing-sun day (the reference's radiation of that day is rounding noise, and the day
+        leaves a slightly different bucket behind: the cell is set aside from that day on);
+      * a critical event (the reference takes a sticky infinite drainage time or not depending on the
+        last bit of pow(), profiles/r02_conditioning.md): such cells MAY differ from that day on,
+        but only `max_flip_frac` of them do.
+    And `min_frac_all` of ALL cell-days, nothing set aside, must be within tolerance.
+    Returns the figures plus 'violations' (list of messages)."""
     hp = p["par"]
+    want = tuple(dict.fromkeys(tuple(names) + ("pet", "wn")))
     ref, st1, ev, _ = oracle.grid_transient2(p["doy"], p["year"], p["month"], p["sw"], p["tc"], p["pn"],
                                              hp[0], hp[1], hp[2], hp[3], hp[4:16], p["Tt"], p["state0"],
-                                             names=names, n_threads=n_threads)
-    graz = (ev & EV_GRAZING) != 0
-    after = np.cumsum((ev & (EV_CRITICAL | EV_RESIDUAL)) != 0, axis=0) > 0
-    flagged = after.any(0)
+                                             names=want, n_threads=n_threads)
+    graz_after = np.cumsum((ev & EV_GRAZING) != 0, axis=0) > 0
+    crit_after = np.cumsum((ev & (EV_CRITICAL | EV_RESIDUAL)) != 0, axis=0) > 0
+    flagged = crit_after.any(0)
     frac_all, worst, viol = {}, {}, []
     flipped = np.zeros(flagged.shape, bool)
-    bads = {}
     for k in names:
-        b = bads[k] = _bad(p["out"][k], ref[k])
+        b = _bad(p["out"][k], ref[k], floor=_floor(k, ref))
         frac_all[k] = 1.0 - float(b.mean())
         if frac_all[k] < min_frac_all:
             viol.append(f"only {frac_all[k]:.8f} of ALL cell-days within tolerance for {k}")
-        bm = b & ~graz & ~after
+        bm = b & ~graz_after & ~crit_after
         if bm.any():
             t, c = np.argwhere(bm)[0]
             viol.append(f"{k} out of tolerance on {int(bm.sum())} cell-days outside the mask; first: day {t} "
                         f"cell {c}: product {p['out'][k][t, c]!r} ref {ref[k][t, c]!r}")
-        flipped |= (b & after).any(0)
+        flipped |= (b & crit_after & ~graz_after).any(0)
         if not np.isfinite(p["out"][k]).all():
             viol.append(f"{k} has non-finite values")
-    keep = ~graz & ~(after & flipped[None, :])
+    keep = ~graz_after & ~(crit_after & flipped[None, :])
     for k in names:
         a, f = p["out"][k], ref[k]
         e = np.where(keep, np.maximum(np.abs(a - f) - ATOL, 0.0) / np.maximum(np.abs(f), 1e-300), 0.0)
+        fl = _floor(k, ref)
+        if fl is not None:
+            e = np.where(np.abs(a - f) <= fl + ATOL, 0.0, e)
         worst[k] = float(e.max())
     if flipped.sum() > max(3, max_flip_frac * flagged.sum()):
         viol.append(f"{int(flipped.sum())} of {int(flagged.sum())} critical-event cells differ")
-    set_aside = int(graz.sum() + (after & flipped[None, :]).sum())
+    set_aside = int((~keep).sum())
     if set_aside > 5e-3 * ev.size:
         viol.append(f"{set_aside} of {ev.size} cell-days set aside")
     return dict(cell_days=int(ev.size), tolerance=RTOL, set_aside_cell_days=set_aside,
-                grazing_cell_days=int(graz.sum()), critical_event_cells=int(flagged.sum()),
+                grazing_cell_days=int(((ev & EV_GRAZING) != 0).sum()),
+                cells_after_a_grazing_day=int(graz_after.any(0).sum()),
+                critical_event_cells=int(flagged.sum()),
                 critical_event_cells_that_differ=int(flipped.sum()),
                 fraction_of_all_cell_days_within_tolerance=frac_all, max_rel_err=worst,
                 max_abs_dwn_mm=float(np.abs(p["out"]["wn"] - ref["wn"])[keep].max()), violations=viol)
@@ -140,7 +176,7 @@ def assert_whole_pipeline(oracle, g, ref, aux, statics, doy, year, name="", name
     oracle's splash.grid restatement, each from its own spin-up.
 
     Strict for every cell in which the oracle met no critical event (aux['critical'] == 0): all
-    cell-days within tolerance except grazing-sun days.  Cells with a critical event (a few per
+    cell-days within tolerance except from a grazing-sun day of the cell on.  Cells with a critical event (a few per
     cent on the synthetic soils) take a sticky infinite drainage time or not depending on the last
     bit of pow() -- the reference built against another libm flips ~1.5 % of them
     (profiles/r02_conditioning.md) -- so they are allowed to differ, but only `max_flip_frac` of them.
@@ -150,6 +186,7 @@ def assert_whole_pipeline(oracle, g, ref, aux, statics, doy, year, name="", name
     flagged = aux["critical"] > 0
     graz = grazing_mask(oracle, statics["lat"], statics["slop"], statics["asp"] - 180.0, doy, year,
                         hs_deg=HS_LIM_DEG)
+    graz = np.cumsum(graz, axis=0) > 0  # a grazing day leaves a different bucket behind: from that day on
     if monthly_mid is not None:
         nm = int(monthly_mid[-1]) + 1
         gm = np.zeros((nm, graz.shape[1]), bool)
@@ -161,7 +198,8 @@ def assert_whole_pipeline(oracle, g, ref, aux, statics, doy, year, name="", name
     for k in names:
         a, b = np.asarray(g[k]).reshape(ref[k].shape), ref[k]
         assert (np.isnan(a) == np.isnan(b)).all(), f"{name}: NaN pattern of {k} differs"
-        bad = _bad(a, b) & ~graz
+        fl = _floor(k, ref) if monthly_mid is None else None
+        bad = _bad(a, b, floor=fl) & ~graz
         bad_cell |= bad.any(0)
         ok = ~bad_cell
         e = np.where(graz | np.isnan(b), 0.0, np.maximum(np.abs(a - b) - ATOL, 0.0) / np.maximum(np.abs(b), 1e-300))
@@ -172,5 +210,6 @@ def assert_whole_pipeline(oracle, g, ref, aux, statics, doy, year, name="", name
     assert flips <= max(3, max_flip_frac * flagged.sum()), \
         f"{name}: {flips} of {int(flagged.sum())} critical-event cells differ"
     assert bad_cell.mean() <= 5e-3, f"{name}: {bad_cell.mean():.2e} of the cells set aside"
+    assert graz.mean() <= 2e-2, f"{name}: {graz.mean():.2e} of the cell-days after a grazing-sun day"
     return dict(cells=int(flagged.size), critical_event_cells=int(flagged.sum()), set_aside=flips,
                 grazing_cell_days=int(graz.sum()), max_rel_err=worst, ok=~bad_cell)

@@ -34,12 +34,15 @@ static inline double orc_pert(double r, double x, double y, unsigned salt)
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     z ^= z >> 31;
+#ifndef ORC_PERTURB_ULPS
+#define ORC_PERTURB_ULPS 1 /* amplitude; 4 models a library of a few ulp (e.g. a 2.5-ulp acos) */
+#endif
     if (!(r == r) || r == 0.0 || isinf(r) || x == 0.0) return r;
-    switch (z & 3) {
-    case 1: return nextafter(r, INFINITY);
-    case 2: return nextafter(r, -INFINITY);
-    default: return r;
-    }
+    double dir = ((z & 3) == 1) ? INFINITY : (((z & 3) == 2) ? -INFINITY : 0.0);
+    if (dir == 0.0) return r;
+    int steps = 1 + (int)((z >> 8) % ORC_PERTURB_ULPS);
+    for (int i = 0; i < steps; i++) r = nextafter(r, dir);
+    return r;
 }
 static inline double p_pow(double x, double y)
 {

@@ -6,11 +6,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def library_path():
-    return os.path.join(_HERE, "librsplash_hip.so")
+    # SPLASH_HIP_LIBRARY: load another build of the library (A/B timing of kernel variants)
+    return os.environ.get("SPLASH_HIP_LIBRARY") or os.path.join(_HERE, "librsplash_hip.so")
 
 
 def build_library(force=False, verbose=False):
     """Compile every HIP source of the package for gfx950; returns the .so path."""
+    if os.environ.get("SPLASH_HIP_LIBRARY"):
+        return library_path()
     csrc = os.path.join(_HERE, "csrc")
     cmd = ["make", "-C", csrc]
     if force:

@@ -68,6 +68,45 @@ static int need_device(char* err, size_t errlen)
     return 0;
 }
 
+// ------------------------------------------------------------------ per-device context
+// Lookup tables of the float viscosity routine (30 MB per device, built on first use by running the
+// routine itself for every float of its two argument ranges; never freed).
+#include <mutex>
+namespace {
+struct DevCtx {
+    float *rtab = nullptr, *ttab = nullptr;
+};
+DevCtx g_ctx[64];
+std::mutex g_ctx_mu;
+
+int visc_tables(ViscTables& vt)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return fail(SPLASH_ENODEV, nullptr, 0, "no current HIP device");
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    DevCtx& c = g_ctx[dev];
+    if (!c.rtab) {
+        float *r = nullptr, *t = nullptr;
+        hipError_t e = hipMalloc((void**)&r, visc_table_floats_r() * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&t, visc_table_floats_t() * sizeof(float));
+        if (e == hipSuccess) e = launch_visc_tables(r, t, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            if (r) (void)hipFree(r);
+            if (t) (void)hipFree(t);
+            return fail(e == hipErrorOutOfMemory ? SPLASH_ENOMEM : SPLASH_EHIP, nullptr, 0,
+                        "viscosity tables: %s", hipGetErrorString(e));
+        }
+        c.rtab = r;
+        c.ttab = t;
+    }
+    vt.rtab = c.rtab;
+    vt.ttab = c.ttab;
+    return SPLASH_OK;
+}
+} // namespace
+
 // ------------------------------------------------------------------ calendar
 // Orbit of one calendar day: the day-static part of SOLAR::calculate_daily_fluxes
 // (src/SOLAR.cpp:98-124 with berger_tls :291-350 and julian_day :352-374), evaluated on the host
@@ -324,6 +363,7 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
     a.passes = passes;
     a.meta = (int*)(w + o_meta);
     a.ai = (double*)(w + o_ai);
+    if (int rc = visc_tables(a.vt)) return rc;
     // pass budgets per phase; the last one covers the 1000-pass worst case of a spin-up
     // (src/SPLASH.cpp:1697).  With `passes` the first spin-up is iterated to its end as well (only
     // to count its passes), otherwise it is a single pass: see k_spin_phase.
@@ -417,6 +457,7 @@ extern "C" int splash_dev_run_all(const splash_calendar* cal, int t0, int nt, si
     a.basin = out->basin;
     a.n_basin = out->basin ? out->n_basin : 1;
     a.nmonth_cal = cal->nmonth;
+    if (int rc = visc_tables(a.vt)) return rc;
     HIP_TRY(launch_run_all(a, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
 }
@@ -507,10 +548,12 @@ extern "C" int splash_dev_evap_batch(size_t m, const double* lat, const double* 
     HIP_TRY(hipMemcpy(dorb.p, orb.data(), 3 * m * 8, hipMemcpyHostToDevice), nullptr, 0);
     HIP_TRY(dout.alloc(11 * m * 8), nullptr, 0);
     const double* o = dorb.as<double>();
+    ViscTables vt{};
+    if (int rc = visc_tables(vt)) return rc;
     HIP_TRY(launch_evap_batch(m, buf[0].as<double>(), buf[1].as<double>(), buf[2].as<double>(), o,
                               o + m, o + 2 * m, buf[3].as<double>(), buf[4].as<double>(),
                               buf[5].as<double>(), buf[6].as<double>(), buf[7].as<double>(),
-                              buf[8].as<double>(), dout.as<double>(), nullptr), nullptr, 0);
+                              buf[8].as<double>(), dout.as<double>(), vt, nullptr), nullptr, 0);
     HIP_TRY(hipMemcpy(out, dout.p, 11 * m * 8, hipMemcpyDeviceToHost), nullptr, 0);
     return SPLASH_OK;
 }

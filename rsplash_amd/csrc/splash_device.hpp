@@ -95,6 +95,7 @@ struct CellConst {
     double patm;
     float patm_f;
     double visc0;           // viscosity at tw = 0 (every day with tc < 0)
+    ViscTables vt;          // per-device lookup tables of the float viscosity (uniform pointers)
     // SPLASH soil column
     double SAT, RES, Au, Ai, inv_Ai;
     double d1000, inv_d1000; // depth*1000 and its inverse
@@ -102,7 +103,7 @@ struct CellConst {
     double theta_s, inv_theta_s, theta_r, dtheta, inv_dtheta; // dtheta = theta_s - theta_r
     double inv_lambda, e3l1; // 1/lambda, 3*lambda+1
     double lambda;
-    double bub, bpr, z_bpr; // bubbling pressure [mm], [cm], 10 cm / bpr
+    double bub, bpr, inv_bpr; // bubbling pressure [mm], [cm], 1 / bpr
     double Wmax, wm_th, inv_wr; // src/SPLASH.cpp:1029, Wmax/(depth*1000), 1/(Wmax-RES)
     double int_perm;        // Ksat/fluidity
     double tan2_slop, inv_cos2; // tan^2(slop), 1/cos^2(slop)
@@ -120,16 +121,29 @@ __device__ __forceinline__ double dsin_deg(double x) { return sin(x * kPir); }
 
 // src/EVAP.cpp:338-389 (Chen et al. 1977) in Horner form for the FP64 path (the evaluation-order
 // faithful form below is only needed where the result is rounded to float)
-__device__ __forceinline__ double density_h2o_fast(double tc, double p)
+struct DensityPolys { // temperature polynomials of Chen et al. (1977), src/EVAP.cpp:338-384
+    double po1000, ko, ca, cb;
+};
+__device__ __forceinline__ DensityPolys density_polys(double tc)
 {
     double po = horner3(-(1.00659e-18), tc, (5.044070e-16), -(1.11663e-13), (1.471150e-11));
     po = horner5(po, tc, -(1.35439e-9), (1.022130e-7), -(9.08659e-6), (6.788260e-5), 0.99983952);
-    const double ko = horner5((1.035530e-7), tc, -(4.91564e-5), 0.01281, -2.29995, 148.1830, 19652.17);
-    const double ca = horner4((8.584e-10), tc, -(7.655e-7), (1.324e-4), (5.223e-4), 3.26138);
-    const double cb = horner4((4.3220e-12), tc, -(1.0100e-9), (8.69900e-8), -(5.8948e-6), (7.2061e-5));
+    DensityPolys q;
+    q.po1000 = (1.0e3) * po;
+    q.ko = horner5((1.035530e-7), tc, -(4.91564e-5), 0.01281, -2.29995, 148.1830, 19652.17);
+    q.ca = horner4((8.584e-10), tc, -(7.655e-7), (1.324e-4), (5.223e-4), 3.26138);
+    q.cb = horner4((4.3220e-12), tc, -(1.0100e-9), (8.69900e-8), -(5.8948e-6), (7.2061e-5));
+    return q;
+}
+__device__ __forceinline__ double density_from_polys(const DensityPolys& q, double p)
+{
     const double pbar = (1.0e-5) * p;
-    const double num = (ko + ca * pbar + cb * (pbar * pbar)); // ~2e4
-    return num * frcp(num - pbar) * ((1.0e3) * po);
+    const double num = (q.ko + q.ca * pbar + q.cb * (pbar * pbar)); // ~2e4
+    return num * frcp(num - pbar) * q.po1000;
+}
+__device__ __forceinline__ double density_h2o_fast(double tc, double p)
+{
+    return density_from_polys(density_polys(tc), p);
 }
 
 // src/EVAP.cpp:338-389 (Chen et al. 1977).  Contraction is off so that the value later rounded
@@ -267,76 +281,188 @@ __device__ __forceinline__ void pow_int_cr(double x, double& p2, double& p3, dou
 // src/EVAP.cpp:405-462 -- Huber et al. (2009) viscosity in the reference's float/double mix.
 // Every rounding point of the C++ original is kept: a `float` variable is a rounding to float;
 // an expression containing a double literal is evaluated in double.
+//
+// The routine factors into three pure functions of FLOAT arguments:
+//   visc_tbar_part(tbar)  -> mu0, ctbar            (:416-424, :439)   tbar = (float)((tw+273.15)/647.096)
+//   visc_rbar_part(rbar)  -> coef2[0..5]           (:441-448)         rbar = rho/322
+//   visc_combine(...)     -> mu                    (:443, :449-459)
+// A float has few values in the range these arguments can take (2.9e6 and 2.4e5 for water between
+// 0 and 60 degC), so the first two are TABULATED once per device by running exactly this code for
+// every float of the range (k_visc_tables): the day loop then replaces ~250 instructions by two
+// gathers, and the result is the same bits by construction.  Outside the tables' range, and in the
+// (rare) cases where a cheaper evaluation of an argument cannot be proved to round to the same
+// float, the whole routine is evaluated directly (viscosity_h2o).
+// (struct ViscTables { rtab [NR][8]: coef2[0..5] + 2 padding; ttab [NT][2]: mu0, ctbar } is
+// declared in splash_kernels.hpp; index = bits(argument) - first)
+constexpr uint32_t kViscR0 = 0x40436000u; // rbar = 3.05273...  (rho = 982.98: water at ~60.5 degC)
+constexpr uint32_t kViscNR = 0x00039000u; // up to rbar = 3.10840 (rho = 1000.9)
+constexpr uint32_t kViscT0 = 0x3ed81c00u; // tbar = 0.422089   (tw = -0.018 degC; tw = 0 is 0x3ed81fac)
+constexpr uint32_t kViscNT = 0x002bc400u; // up to tbar = 0.51514 (tw = 60.2 degC)
+
+__device__ __forceinline__ void visc_tbar_part(float tbar, float& mu0_out, float& ctbar_out)
+{
+#pragma clang fp contract(off)
+    float tbarx = (float)sqrt((double)tbar);                           // :417 pow(tbar,0.5)
+    float tbar2 = tbar * tbar;                                         // :418
+    float tbar3 = tbar * tbar * tbar;                                  // :419
+    float mu0 = (float)(1.67752 + 2.20462 / (double)tbar + 0.6366564 / (double)tbar2 -
+                        0.241605 / (double)tbar3);                     // :423
+    mu0 = (float)(1e2 * (double)tbarx / (double)mu0);                  // :424
+    mu0_out = mu0;
+    ctbar_out = (float)((1.0 / (double)tbar) - 1.0);                   // :439
+}
+
+__device__ __forceinline__ void visc_rbar_part(float rbar, float (&c)[6])
+{
+#pragma clang fp contract(off)
+    // Table 3 of Huber et al. (:427-435); the literals are rounded to float as in the
+    // reference's `float h_array[7][6]`.  Zero entries add exactly 0 and are skipped.
+    double rb = (double)rbar - 1.0;                                    // pow(rbar - 1.0, j) base
+    // Integer powers as the correctly rounded value of the exact power (what glibc's pow returns
+    // except within ~0.01 ulp of a rounding tie): a float-rounding of the running sum flips on a
+    // 1-ulp(double) difference about once per 1e8 cell-days, which at grid scale is every run.
+    double rb2, rb3, rb4, rb5, rb6;
+    pow_int_cr(rb, rb2, rb3, rb4, rb5, rb6);
+#define H(v) ((double)(float)(v))
+#define ACC(c2, h, pw_) c2 = (float)((double)(c2) + H(h) * (pw_))
+    float c2;
+    c2 = 0.0f;
+    ACC(c2, 0.520094, 1.0); ACC(c2, 0.222531, rb); ACC(c2, -0.281378, rb2);
+    ACC(c2, 0.161913, rb3); ACC(c2, -0.0325372, rb4);
+    c[0] = c2;
+    c2 = 0.0f;
+    ACC(c2, 0.0850895, 1.0); ACC(c2, 0.999115, rb); ACC(c2, -0.906851, rb2);
+    ACC(c2, 0.257399, rb3);
+    c[1] = c2;
+    c2 = 0.0f;
+    ACC(c2, -1.08374, 1.0); ACC(c2, 1.88797, rb); ACC(c2, -0.772479, rb2);
+    c[2] = c2;
+    c2 = 0.0f;
+    ACC(c2, -0.289555, 1.0); ACC(c2, 1.26613, rb); ACC(c2, -0.489837, rb2);
+    ACC(c2, 0.0698452, rb4); ACC(c2, -0.00435673, rb6);
+    c[3] = c2;
+    c2 = 0.0f;
+    ACC(c2, -0.257040, rb2); ACC(c2, 0.00872102, rb5);
+    c[4] = c2;
+    c2 = 0.0f;
+    ACC(c2, 0.120573, rb); ACC(c2, -0.000593264, rb6);
+    c[5] = c2;
+#undef ACC
+#undef H
+}
+
+__device__ __forceinline__ float visc_combine(float rbar, float mu0, float ctbar, const float (&c)[6])
+{
+#pragma clang fp contract(off)
+    const float mu_ast = 1e-6f;
+    double cd_ = (double)ctbar;
+    double ct2, ct3, ct4, ct5, ct6;
+    pow_int_cr(cd_, ct2, ct3, ct4, ct5, ct6);                         // coef1 = (float)pow(ctbar, i), :443
+    float mu1 = 0.0f;
+    mu1 = mu1 + 1.0f * c[0];                                          // :449, i = 0..5
+    mu1 = mu1 + (float)cd_ * c[1];
+    mu1 = mu1 + (float)ct2 * c[2];
+    mu1 = mu1 + (float)ct3 * c[3];
+    mu1 = mu1 + (float)ct4 * c[4];
+    mu1 = mu1 + (float)ct5 * c[5];
+    mu1 = expf_glibc(rbar * mu1);                                      // :451
+    float mu_bar = mu0 * mu1;                                          // :456
+    return mu_bar * mu_ast;                                            // :459
+}
+
 __device__ __forceinline__ float viscosity_h2o(float tc, float p)
 {
 #pragma clang fp contract(off)
     const float tk_ast = 647.096f;
     const float rho_ast = 322.0f;
-    const float mu_ast = 1e-6f;
-
     float rho = (float)density_h2o((double)tc, (double)p);            // :413
     float tbar = (float)(((double)tc + 273.15) / (double)tk_ast);      // :416
-    float tbarx = (float)sqrt((double)tbar);                           // :417 pow(tbar,0.5)
-    float tbar2 = tbar * tbar;                                         // :418
-    float tbar3 = tbar * tbar * tbar;                                  // :419
     float rbar = rho / rho_ast;                                        // :420
+    float mu0, ctbar, c[6];
+    visc_tbar_part(tbar, mu0, ctbar);
+    visc_rbar_part(rbar, c);
+    return visc_combine(rbar, mu0, ctbar, c);
+}
 
-    float mu0 = (float)(1.67752 + 2.20462 / (double)tbar + 0.6366564 / (double)tbar2 -
-                        0.241605 / (double)tbar3);                     // :423
-    mu0 = (float)(1e2 * (double)tbarx / (double)mu0);                  // :424
+// (double) -> float with a proof obligation: `v` approximates, to ~1e-15 relative, a real number
+// whose correctly rounded float is wanted (the reference rounds a slightly different double
+// approximation of the same real).  The two round alike unless v lies within 2^-43 relative of a
+// float rounding boundary (a midpoint of two adjacent floats: low 29 mantissa bits = 0x10000000);
+// then `risky` is raised and the caller falls back to the reference's own evaluation.
+__device__ __forceinline__ float to_float_checked(double v, bool& risky)
+{
+    const uint32_t lo = (uint32_t)(unsigned long long)__double_as_longlong(v) & 0x1FFFFFFFu;
+    risky |= (lo - (0x10000000u - 512u)) < 1024u;
+    return (float)v;
+}
 
-    // Table 3 of Huber et al. (:427-435); the literals are rounded to float as in the
-    // reference's `float h_array[7][6]`.  Zero entries add exactly 0 and are skipped.
-    float ctbar = (float)((1.0 / (double)tbar) - 1.0);                 // :439
-    double cd_ = (double)ctbar;
-    double rb = (double)rbar - 1.0;                                    // pow(rbar - 1.0, j) base
-    // Integer powers as the correctly rounded value of the exact power (what glibc's pow returns
-    // except within ~0.01 ulp of a rounding tie): a float-rounding of the running sum flips on a
-    // 1-ulp(double) difference about once per 1e8 cell-days, which at grid scale is every run.
-    double rb2, rb3, rb4, rb5, rb6, ct2, ct3, ct4, ct5;
-    pow_int_cr(rb, rb2, rb3, rb4, rb5, rb6);
-    {
-        double ct6;
-        pow_int_cr(cd_, ct2, ct3, ct4, ct5, ct6);
+// The temperature-only part of a cell-day that needs memory: water density (double path) and the
+// table entries of the float viscosity.  It is evaluated at the TOP of the day, before the next
+// day's forcing is requested, so that the two gathers (L2 / Infinity-Cache hits, ~1 us) are in
+// flight during the radiation part of the day step and return before the forcing prefetch
+// (vector-memory loads return in order).
+struct DayPre {
+    double pw;          // density_h2o(tc, patm), src/EVAP.cpp:113
+    float c[6];         // coef2[0..5] of the viscosity (table)
+    float mu0, ctbar;   // (table)
+    float rbar;
+    int mode;           // 0: tc < 0 (viscosity at tw = 0 is a cell constant)  1: tables  2: direct
+};
+
+__device__ __forceinline__ DayPre day_prefetch(const CellConst& c, double tc)
+{
+#pragma clang fp contract(off)
+    DayPre q;
+    const DensityPolys dq = density_polys(tc);
+#if defined(SPL_ABLATE) && SPL_ABLATE == 5
+    q.pw = 1000.0 - 0.1 * tc;
+#else
+    q.pw = density_from_polys(dq, c.patm);
+#endif
+    q.mode = 0;
+    q.rbar = q.mu0 = q.ctbar = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) q.c[k] = 0.0f;
+#if !(defined(SPL_ABLATE) && SPL_ABLATE == 1)
+    if (!(tc < 0.0)) { // tw = tc (src/EVAP.cpp:100-105)
+        const float tcf = (float)tc;
+        // forcing that is not float-representable, or no tables: the routine is evaluated directly
+        bool risky = ((double)tcf != tc) || c.vt.rtab == nullptr;
+        // density at the float-rounded pressure (:413): same temperature polynomials
+        const double pbar = (1.0e-5) * (double)c.patm_f;
+        const double num = (dq.ko + dq.ca * pbar + dq.cb * (pbar * pbar));
+        const float rho = to_float_checked(num * frcp(num - pbar) * dq.po1000, risky);
+        const float rbar = to_float_checked((double)rho * (1.0 / 322.0), risky);          // :420
+        const float tbar = to_float_checked(((double)tcf + 273.15) * (1.0 / 647.09600830078125), risky); // :416
+        const uint32_t ir = __float_as_uint(rbar) - kViscR0, it = __float_as_uint(tbar) - kViscT0;
+        risky |= (ir >= kViscNR) | (it >= kViscNT);
+        q.mode = risky ? 2 : 1;
+        q.rbar = rbar;
+        if (!risky) {
+            const float4 a = *reinterpret_cast<const float4*>(c.vt.rtab + (size_t)ir * 8);
+            const float2 b = *reinterpret_cast<const float2*>(c.vt.rtab + (size_t)ir * 8 + 4);
+            const float2 t = *reinterpret_cast<const float2*>(c.vt.ttab + (size_t)it * 2);
+            q.c[0] = a.x; q.c[1] = a.y; q.c[2] = a.z; q.c[3] = a.w; q.c[4] = b.x; q.c[5] = b.y;
+            q.mu0 = t.x;
+            q.ctbar = t.y;
+        }
     }
+#endif
+    return q;
+}
 
-#define H(v) ((double)(float)(v))
-#define ACC(c2, h, pw_) c2 = (float)((double)(c2) + H(h) * (pw_))
-    float mu1 = 0.0f, c2;
-    // i = 0: coef1 = pow(ctbar,0) = 1
-    c2 = 0.0f;
-    ACC(c2, 0.520094, 1.0); ACC(c2, 0.222531, rb); ACC(c2, -0.281378, rb2);
-    ACC(c2, 0.161913, rb3); ACC(c2, -0.0325372, rb4);
-    mu1 = mu1 + 1.0f * c2;
-    // i = 1
-    c2 = 0.0f;
-    ACC(c2, 0.0850895, 1.0); ACC(c2, 0.999115, rb); ACC(c2, -0.906851, rb2);
-    ACC(c2, 0.257399, rb3);
-    mu1 = mu1 + (float)cd_ * c2;
-    // i = 2
-    c2 = 0.0f;
-    ACC(c2, -1.08374, 1.0); ACC(c2, 1.88797, rb); ACC(c2, -0.772479, rb2);
-    mu1 = mu1 + (float)ct2 * c2;
-    // i = 3
-    c2 = 0.0f;
-    ACC(c2, -0.289555, 1.0); ACC(c2, 1.26613, rb); ACC(c2, -0.489837, rb2);
-    ACC(c2, 0.0698452, rb4); ACC(c2, -0.00435673, rb6);
-    mu1 = mu1 + (float)ct3 * c2;
-    // i = 4
-    c2 = 0.0f;
-    ACC(c2, -0.257040, rb2); ACC(c2, 0.00872102, rb5);
-    mu1 = mu1 + (float)ct4 * c2;
-    // i = 5
-    c2 = 0.0f;
-    ACC(c2, 0.120573, rb); ACC(c2, -0.000593264, rb6);
-    mu1 = mu1 + (float)ct5 * c2;
-#undef ACC
-#undef H
-
-    mu1 = expf_glibc(rbar * mu1);                                      // :451
-    float mu_bar = mu0 * mu1;                                          // :456
-    float mu = mu_bar * mu_ast;                                        // :459
-    return mu;
+// viscosity of the day [Pa s] from the prefetched pieces
+__device__ __forceinline__ double day_viscosity(const CellConst& c, const DayPre& q, double tc)
+{
+    double visc = c.visc0;
+    if (q.mode == 1) {
+        SPL_SITE();
+        visc = (double)visc_combine(q.rbar, q.mu0, q.ctbar, q.c);
+    } else if (q.mode == 2) {
+        SPL_SITE();
+        visc = (double)viscosity_h2o((float)tc, c.patm_f);
+    }
+    return visc;
 }
 
 // src/EVAP.cpp:491-515
@@ -361,8 +487,9 @@ __device__ __forceinline__ double specific_heat(double tc)
 // between the two spin-ups (R/splash.point.R:150).  Runs once per kernel per cell, so it uses
 // the library pow/exp/log throughout.
 __device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, size_t ld,
-                                  size_t cell, double cellout)
+                                  size_t cell, double cellout, ViscTables vt = ViscTables{nullptr, nullptr})
 {
+    c.vt = vt;
     const double lat = par[P_LAT * ld + cell], elv = par[P_ELV * ld + cell];
     const double slop = par[P_SLOP * ld + cell], asp = par[P_ASP * ld + cell];
     const double SAT = par[P_SAT * ld + cell], WP = par[P_WP * ld + cell];
@@ -403,7 +530,7 @@ __device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, 
     c.lambda = lambda;
     c.bub = bub;
     c.bpr = bub / 10; // src/SPLASH.cpp:1940
-    c.z_bpr = 10.0 / c.bpr;
+    c.inv_bpr = 1.0 / c.bpr;
     c.deep = (depth >= 2.0);
 
     // src/SPLASH.cpp:971-993
@@ -500,8 +627,9 @@ __device__ __forceinline__ void hour_angle(double cosv, bool at_one_is_zero, dou
 // src/SOLAR.cpp:77-267 + src/EVAP.cpp:82-264 for one cell-day.
 // sw is the supply fraction (src/SPLASH.cpp:1042-1048), snow already includes today's snowfall.
 // Angles are kept in radians (the reference converts to degrees and back at every use).
-__device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, double sw,
-                                         double sw_in, double tc, double snow, double nd, Etr& o)
+__device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, const DayPre& pre,
+                                         double sw, double sw_in, double tc, double snow, double nd,
+                                         Etr& o)
 {
     // ----- SOLAR
     const double sw_s = sw > 1.0 ? 1.0 : sw; // :92
@@ -575,24 +703,14 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
         const double q = u * frcp(u - 33.91);
         lv = q * q * 1.91846e6;
     }
-#if defined(SPL_ABLATE) && SPL_ABLATE == 5
-    const double pw = 1000.0 - 0.1 * tc;
-#else
-    const double pw = density_h2o_fast(tc, c.patm);                   // :113
-#endif
+    const double pw = pre.pw;                                         // :113
     const double g = (kMa * specific_heat(tc) * c.patm) * frcp(kMv * lv); // psychro :486
     const double lvpw = lv * pw;
     // econ = s/(lv*pw*(s+g)) (:117) and s/(lv*pw*(s+0.24g)) (:129) from one reciprocal
     const double sg1 = s + g, sg2 = s + 0.24 * g;
     const double inv_e = frcp(lvpw * sg1 * sg2);
     const double econ = s * sg2 * inv_e;
-    double visc = c.visc0;                                            // :100-105, :120
-#if !(defined(SPL_ABLATE) && SPL_ABLATE == 1)
-    if (!(tc < 0.0)) {
-        SPL_SITE();
-        visc = (double)viscosity_h2o((float)tc, c.patm_f);
-    }
-#endif
+    const double visc = day_viscosity(c, pre, tc);                    // :100-105, :120
     const double cn = (1.0e3) * econ * fabs(rnn_d) * 0.1;             // :124
     const double eet_d = (1.0e3) * (s * sg1 * inv_e) * rn_d;          // :129
     const double rx = (3.6e6) * econ;                                 // :145
@@ -644,21 +762,30 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
 }
 
 // ---- SPLASH helpers ---------------------------------------------------------------------------
-// Theta = (theta - theta_r)/(theta_s - theta_r) for a column holding w mm.  The reference forms
-// theta = w/(depth*1000) with the same expression as theta_r and theta_s, so Theta is EXACTLY 0
-// at w == RES and EXACTLY 1 at w == SAT, and its code is discontinuous there (Theta = 0 puts the
-// water table at the column base, wtd = depth; Theta = 1 at the surface, wtd = 0; one ulp beyond
-// either end lands in the `wtd < 0 || isnan -> 0.01` guard).  The buckets are clamped to
-// [RES, SAT] every day, so both ends are hit constantly: they are reproduced exactly, and the
-// multiply-by-reciprocal form is only used strictly inside the interval.
+// a / b correctly rounded, given y = RN(1/b) (an IEEE division done once per cell): q = a*y is
+// within an ulp, its exact residual r = a - b*q (one FMA) corrects it, and RN(q + r*y) is the
+// correctly rounded quotient (Markstein's division step).  Three issue slots.
+__device__ __forceinline__ double div_cr(double a, double b, double y)
+{
+    const double q = a * y;
+    const double r = fma(-b, q, a);
+    return fma(r, y, q);
+}
+
+// Theta = (theta - theta_r)/(theta_s - theta_r) for a column holding w mm, with the reference's own
+// operations and roundings: theta = w/(depth*1000), then one subtraction and one division
+// (src/SPLASH.cpp:1406-1408).  Bit-identical to the reference for a given w, and it has to be:
+// Theta is raised to 1/lambda, and the synthetic and real soils reach lambda ~ 1e-4, so an ulp of
+// Theta is 1e-12 of the transmittance -- enough, in such a cell, to move the next day's bucket by
+// an ulp and start a visibly different trajectory a few hundred days later (the bucket is a
+// steep map there: d(bflow)/d(wn) ~ bflow/(lambda * column range)).  A reciprocal-multiply Theta
+// agrees to 2-3 ulp only.  As in the reference, Theta is EXACTLY 0 at w == RES and EXACTLY 1 at
+// w == SAT (theta_r and theta_s are the same quotients), where its code is discontinuous
+// (Theta = 0 puts the water table at the column base, Theta = 1 at the surface).
 __device__ __forceinline__ double rel_saturation(const CellConst& c, double w)
 {
-    double th = (w * c.inv_d1000 - c.theta_r) * c.inv_dtheta;
-    th = th < 0.0 ? 0.0 : th; // rounding of the reciprocal form only (w >= RES)
-    th = th > 1.0 ? 1.0 : th;
-    th = (w == c.RES) ? 0.0 : th;
-    th = (w == c.SAT) ? 1.0 : th;
-    return th;
+    const double th = div_cr(w, c.d1000, c.inv_d1000);
+    return div_cr(th - c.theta_r, c.dtheta, c.inv_dtheta);
 }
 
 // src/SPLASH.cpp:1921-1961 with z = 10 cm (call at :1265): Brooks-Corey water content of the
@@ -667,7 +794,11 @@ __device__ __forceinline__ double rel_saturation(const CellConst& c, double w)
 __device__ __forceinline__ double moist_surf(const CellConst& c, double wn)
 {
     const double L = flog(rel_saturation(c, wn));
-    const double head_ratio = fexp(-L * c.inv_lambda) + c.z_bpr;
+    // the potential itself is formed (not just its ratio to bpr) so that it overflows to -inf
+    // where the reference's bpr/pow(Theta, 1/lambda) does (1/lambda reaches 1e4: Theta^(1/lambda)
+    // underflows for quite ordinary Theta), which sends theta to theta_r there
+    const double psi = c.bpr * fexp(-L * c.inv_lambda);
+    const double head_ratio = (psi + 10.0) * c.inv_bpr;
     double theta_BC = c.dtheta * fexp(-c.lambda * flog(head_ratio)) + c.theta_r;
     if (wn < c.RES) { // theta_mean < theta_r
         theta_BC = c.theta_r;
@@ -771,9 +902,9 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
 }
 
 // ---- the day step: src/SPLASH.cpp:920-1588 (== quick_run :150-918) ----------------------------
-__device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, double sw_in,
-                                         double tc, double pn, double snowfall, State& st,
-                                         DayOut& o)
+__device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, const DayPre& pre,
+                                         double sw_in, double tc, double pn, double snowfall,
+                                         State& st, DayOut& o)
 {
     const double wn = st.wn;
     double snow = st.snow, qin = st.qin, td = st.td, nd = st.nd;
@@ -794,7 +925,7 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     snow += snowfall;
 
     Etr ev;
-    evap_day(c, d, sw, sw_in, tc, snow, nd, ev); // :1235
+    evap_day(c, d, pre, sw, sw_in, tc, snow, nd, ev); // :1235
     snow -= ev.snowmelt;                          // :1240
     const double snowmelt = ev.snowmelt - ev.sublimation; // :1243
 
@@ -846,14 +977,16 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     if (c.deep) { // depth >= 2.0: vertical drainage corrections :1433-1450
         SPL_SITE();
         // :984-990 clamp of the start-of-day volumetric content, :1267 theta_m
-        double theta_i = wn * c.inv_d1000;
-        if (wn >= c.SAT) { // theta_i >= theta_s (division by depth*1000 is monotone)
+        // (both quotients with the reference's rounding: the exponent 3 + 2/lambda reaches 1e4, so
+        // an ulp of the base is 1e-12 of Kunsat -- see rel_saturation)
+        double theta_i = div_cr(wn, c.d1000, c.inv_d1000);
+        if (theta_i >= c.theta_s) {
             theta_i = c.theta_s - 0.001;
-        } else if (wn <= c.RES) {
+        } else if (theta_i <= c.theta_r) {
             theta_i = c.theta_r + 0.001;
         }
         const double theta_m = SPL_MAX(c.wm_th, theta_i);
-        const double Kunsat = Ksat_visc * fpow((theta_m * c.inv_theta_s), c.kun_exp); // :1275
+        const double Kunsat = Ksat_visc * fpow(div_cr(theta_m, c.theta_s, c.inv_theta_s), c.kun_exp); // :1275
         T_uns += Kunsat * 24.0;
         T_sat = Ksat_visc * 24.0 * ((Acs_out + c.Ai) * c.inv_Ai);
     } else {

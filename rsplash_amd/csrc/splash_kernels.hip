@@ -220,16 +220,17 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     if (a.fresh) {
         stage = 1;
         count = 1;
-        cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci]);
+        cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci], a.vt);
         e = State{c.RES, 0.0, 0.0, 0.0, 0.0}; // wn_vec(n,RES), others 0, read at [n-1] (:1633-1648)
-        day_step(c, day_const(d0), sw0, tc0, rain0, snf0, e, o);
-        pet_sum = o.pet;
-        p_sum = rain0 + snf0;
+        day_step(c, day_const(d0), day_prefetch(c, tc0), sw0, tc0, rain0, snf0, e, o);
+        // sum(initial_AI$pet, na.rm = T) / sum(Pinit, na.rm = T), R/splash.point.R:150
+        pet_sum = (o.pet == o.pet) ? o.pet : 0.0;
+        p_sum = (rain0 + snf0 == rain0 + snf0) ? rain0 + snf0 : 0.0;
     } else {
         const int m = a.meta[ci];
         stage = m >> 16;
         count = m & 0xFFFF;
-        cell_setup(c, a.par, a.ldp, ci, stage == 1 ? a.par[P_CELLOUT * a.ldp + ci] : a.ai[ci]);
+        cell_setup(c, a.par, a.ldp, ci, stage == 1 ? a.par[P_CELLOUT * a.ldp + ci] : a.ai[ci], a.vt);
         e = State{a.state[ci], a.state[a.lds + ci], a.state[2 * a.lds + ci],
                   a.state[3 * a.lds + ci], a.state[4 * a.lds + ci]};
     }
@@ -251,22 +252,24 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         double swv, tcv, pnv;
         f.raw(1, swv, tcv, pnv);
         for (int i = 1; i < a.n; i++) {
+            const DayPre pre = day_prefetch(c, tcv);
             double swn = swv, tcn = tcv, pnn = pnv;
             if (i + 1 < a.n) f.raw(i + 1, swn, tcn, pnn);
             const DayRec d = day_rec(days, i);
             double rain, snf;
             f.split(d, i, tcv, pnv, rain, snf);
-            day_step(c, day_const(d), swv, tcv, rain, snf, cur, o);
+            day_step(c, day_const(d), pre, swv, tcv, rain, snf, cur, o);
             if (acc) { // pet_vec is only filled in the first pass (:1667), Pinit = rain + snow
-                pet_sum += o.pet;
-                p_sum += rain + snf;
+                const double pday = rain + snf;
+                pet_sum += (o.pet == o.pet) ? o.pet : 0.0; // na.rm = T
+                p_sum += (pday == pday) ? pday : 0.0;
             }
             swv = swn;
             tcv = tcn;
             pnv = pnn;
         }
         State nxt = cur; // the closing day-1 step (:1674/:1729) == day 1 of the next pass
-        day_step(c, day_const(d0), sw0, tc0, rain0, snf0, nxt, o);
+        day_step(c, day_const(d0), day_prefetch(c, tc0), sw0, tc0, rain0, snf0, nxt, o);
         double diff_sm = nxt.wn - e.wn; // end_sm - start_sm, :1678-1688
         if (diff_sm < 0) diff_sm = e.wn - nxt.wn;
         if (!done) {
@@ -300,12 +303,12 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 if (a.passes) a.passes[ci] = count;
                 const double AI = a.ai[ci];
                 a.par[P_CELLOUT * a.ldp + ci] = AI; // soil_info[12] <- AI (1-based): ncellout
-                cell_setup(c, a.par, a.ldp, ci, AI);
+                cell_setup(c, a.par, a.ldp, ci, AI, a.vt);
                 stage = 2;
                 count = 1;
                 s_chk_count[threadIdx.x] = -1;
                 e = State{c.RES, 0.0, 0.0, 0.0, 0.0};
-                day_step(c, day_const(d0), sw0, tc0, rain0, snf0, e, o);
+                day_step(c, day_const(d0), day_prefetch(c, tc0), sw0, tc0, rain0, snf0, e, o);
             } else {
                 a.state[ci] = cur.wn; // initial$sm[365] etc., R/splash.point.R:164-172
                 a.state[a.lds + ci] = cur.snow;
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(64) void k_spin_up_mod(SpinArgs a, double* const* s
             double swv, tcv, pnv, rain, snf;
             f.raw(i, swv, tcv, pnv);
             f.split(a.days[i], i, tcv, pnv, rain, snf);
-            day_step(c, day_const(a.days[i]), swv, tcv, rain, snf, cur, o);
+            day_step(c, day_const(a.days[i]), day_prefetch(c, tcv), swv, tcv, rain, snf, cur, o);
             if (i == 0) start_sm = cur.wn;
             const size_t k = (size_t)i * sld;
             series[0][k] = cur.wn;
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(64) void k_spin_up_mod(SpinArgs a, double* const* s
         double sw0, tc0, pn0, rain0, snf0;
         f.raw(0, sw0, tc0, pn0);
         f.split(a.days[0], 0, tc0, pn0, rain0, snf0);
-        day_step(c, day_const(a.days[0]), sw0, tc0, rain0, snf0, nxt, o);
+        day_step(c, day_const(a.days[0]), day_prefetch(c, tc0), sw0, tc0, rain0, snf0, nxt, o);
         double diff_sm = nxt.wn - start_sm; // :1678-1688
         if (diff_sm < 0) diff_sm = start_sm - nxt.wn;
         if (!((diff_sm > 1.0) && (count < 1000))) break; // :1697
@@ -386,11 +389,27 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Sum of a 32-bit integer over the 64 lanes with DPP adds (no LDS traffic, 6 VALU + 1 readlane;
+// the total is returned to every lane): two quad permutes and two row rotations leave every lane
+// of a 16-lane row with its row's total, row_bcast:15 / :31 carry the row totals to lane 63.
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);  // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false); // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Sum of a 64-bit integer with |v| < 2^44 over the 64 lanes: three 16-bit digits (the top one
+// signed), each summed in 32 bits without overflow, recombined.
 __device__ __forceinline__ long long wave_sum_i64(long long v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    const int d0 = (int)(v & 0xFFFF), d1 = (int)((v >> 16) & 0xFFFF), d2 = (int)(v >> 32);
+    return (long long)wave_sum_i32(d0) + ((long long)wave_sum_i32(d1) << 16) +
+           ((long long)wave_sum_i32(d2) << 32);
 }
 
 // K7: add one cell's monthly figures to the (basin, month) record of exact fixed-point limbs
@@ -400,46 +419,59 @@ __device__ __forceinline__ long long wave_sum_i64(long long v)
 // do not depend on which lane, wave, block, launch or GPU adds first.  Wavefronts whose cells
 // share one basin (the usual case: basins are spatially coherent) reduce in registers and issue
 // one atomic per limb; mixed wavefronts add lane by lane.
-__device__ __forceinline__ void diag_add(long long* __restrict__ acc, const int* __restrict__ basin,
-                                         int n_basin, int nmonth_cal, int month_id, size_t cell,
-                                         bool valid, const double (&w)[SPLASH_NDIAG_K],
-                                         bool month_end)
+constexpr int kDiagRec = (SPLASH_NDIAG_K + 1) * 2;
+constexpr int kDiagLdsMonths = 16; // months of a launch that the per-workgroup accumulators cover
+
+__device__ __forceinline__ void diag_add(long long* __restrict__ acc, unsigned long long* s_acc,
+                                         int wg_basin, const int* __restrict__ basin, int n_basin,
+                                         int nmonth_cal, int month_id, int month_rel, size_t cell,
+                                         bool valid, const double (*w)[kBlock], bool month_end)
 {
-    constexpr int REC = (SPLASH_NDIAG_K + 1) * 2;
+    // w: the lane's six monthly figures in LDS (w[q][threadIdx.x]).  One quantity at a time, in a
+    // rolled loop: this runs twelve times a year, and unrolled its 14 limbs would claim 28 of the
+    // day loop's 256 registers at the point where it is inlined.
+    // Where a whole workgroup lies in one basin (wg_basin >= 0: the usual case, decided once per
+    // launch) the wave sums go to per-workgroup accumulators in LDS (s_acc[month][limb]) that are
+    // flushed to the global record once, at the end of the launch: 32 768 wavefronts adding to the
+    // same fourteen addresses every month end would otherwise queue up in the L2 atomic units.
     const int b = basin ? basin[cell] : 0;
     const bool in = valid && (unsigned)b < (unsigned)n_basin;
-    long long limb[REC];
-    long long skipped = 0;
-#pragma unroll
-    for (int q = 0; q < SPLASH_NDIAG_K; q++) {
-        const double v = w[q];
-        const bool ok = in && (fabs(v) < 1048576.0); // false for NaN/inf too
-        const double a = rint(v * 65536.0);
-        const double r = v - a * (1.0 / 65536.0);
-        limb[2 * q] = ok ? (long long)a : 0;
-        limb[2 * q + 1] = ok ? (long long)rint(r * 281474976710656.0) : 0;
-        skipped += (in && !ok) ? 1 : 0;
-    }
-    limb[2 * SPLASH_NDIAG_K] = (in && month_end) ? 1 : 0;
-    limb[2 * SPLASH_NDIAG_K + 1] = skipped;
     const int b0 = __builtin_amdgcn_readfirstlane(in ? b : -1);
     // uniform: every participating lane has the first lane's basin (lanes that do not take part
     // carry zeros and may be summed along)
     const bool uniform = __all(!in || b == b0) && b0 >= 0;
-    if (uniform) {
-        unsigned long long* rec =
-            (unsigned long long*)acc + ((size_t)b0 * nmonth_cal + month_id) * REC;
-#pragma unroll
-        for (int q = 0; q < REC; q++) {
-            const long long s = wave_sum_i64(limb[q]);
-            if ((threadIdx.x & 63) == 0 && s != 0) atomicAdd(rec + q, (unsigned long long)s);
+    const bool to_lds = wg_basin >= 0 && month_rel < kDiagLdsMonths;
+    unsigned long long* rec =
+        (unsigned long long*)acc + ((size_t)(uniform ? b0 : (in ? b : 0)) * nmonth_cal + month_id) * kDiagRec;
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    long long skipped = 0;
+#pragma unroll 1
+    for (int q = 0; q <= SPLASH_NDIAG_K; q++) {
+        long long l0, l1;
+        if (q < SPLASH_NDIAG_K) {
+            const double v = w[q][threadIdx.x];
+            const bool ok = in && (fabs(v) < 1048576.0); // false for NaN/inf too
+            const double a = rint(v * 65536.0);
+            const double r = v - a * (1.0 / 65536.0);
+            l0 = ok ? (long long)a : 0;
+            l1 = ok ? (long long)rint(r * 281474976710656.0) : 0;
+            skipped += (in && !ok) ? 1 : 0;
+        } else {
+            l0 = (in && month_end) ? 1 : 0;
+            l1 = skipped;
         }
-    } else if (in) {
-        unsigned long long* rec =
-            (unsigned long long*)acc + ((size_t)b * nmonth_cal + month_id) * REC;
-#pragma unroll
-        for (int q = 0; q < REC; q++)
-            if (limb[q] != 0) atomicAdd(rec + q, (unsigned long long)limb[q]);
+        if (to_lds || uniform) {
+            l0 = wave_sum_i64(l0);
+            l1 = wave_sum_i64(l1);
+            if (lane0) {
+                unsigned long long* dst = to_lds ? s_acc + month_rel * kDiagRec : rec;
+                if (l0 != 0) atomicAdd(dst + 2 * q, (unsigned long long)l0);
+                if (l1 != 0) atomicAdd(dst + 2 * q + 1, (unsigned long long)l1);
+            }
+        } else if (in) {
+            if (l0 != 0) atomicAdd(rec + 2 * q, (unsigned long long)l0);
+            if (l1 != 0) atomicAdd(rec + 2 * q + 1, (unsigned long long)l1);
+        }
     }
 }
 
@@ -485,7 +517,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
               (unsigned)(ci * sizeof(double))};
     const DayTable days = day_table(a.days);
     CellConst c;
-    cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci]);
+    cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci], a.vt);
     const double wmax_r = a.par[P_WMAXR * a.ldp + ci];
     const double lim_den = wmax_r - c.RES;
     State st{a.state[ci], a.state[a.lds + ci], a.state[2 * a.lds + ci], a.state[3 * a.lds + ci],
@@ -501,22 +533,44 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
     }
 
     double acc[9]; // monthly accumulators in output order
-    double dg[4];  // monthly flux totals: precip, aet, ro, bflow
+    // monthly flux totals of the water balance (precip, aet, ro, bflow) accumulate in LDS, one
+    // slot per lane: the day loop is register bound (256 VGPRs, spilling), and four running sums
+    // kept in registers cost more in spills than four LDS adds per day do
+    __shared__ double s_dg[DIAG ? SPLASH_NDIAG_K : 1][DIAG ? kBlock : 1];
+    __shared__ unsigned long long s_acc[DIAG ? kDiagLdsMonths * kDiagRec : 1];
+    __shared__ int s_wgb[2];
+    int wg_basin = -1; // the one basin of this workgroup's cells, or -1 if they are mixed
 #pragma unroll
     for (int k = 0; k < 9; k++) acc[k] = 0.0;
+    if constexpr (DIAG) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) dg[k] = 0.0;
+        for (int k = 0; k < 4; k++) s_dg[k][threadIdx.x] = 0.0;
+        for (int k = threadIdx.x; k < kDiagLdsMonths * kDiagRec; k += kBlock) s_acc[k] = 0ull;
+        if (threadIdx.x == 0) {
+            s_wgb[0] = 0x7fffffff;
+            s_wgb[1] = -0x7fffffff;
+        }
+        __syncthreads();
+        const int b = a.basin ? a.basin[ci] : 0;
+        if (valid) {
+            atomicMin(&s_wgb[0], b);
+            atomicMax(&s_wgb[1], b);
+        }
+        __syncthreads();
+        if (s_wgb[0] == s_wgb[1] && (unsigned)s_wgb[0] < (unsigned)a.n_basin) wg_basin = s_wgb[0];
+    }
 
     double swv, tcv, pnv;
     f.raw(0, swv, tcv, pnv);
     for (int t = 0; t < a.nt; t++) {
         const DayRec d = day_rec(days, t);
+        const DayPre pre = day_prefetch(c, tcv);       // table gathers of today's viscosity first,
         double swn = swv, tcn = tcv, pnn = pnv;
-        if (t + 1 < a.nt) f.raw(t + 1, swn, tcn, pnn); // next day's forcing in flight
+        if (t + 1 < a.nt) f.raw(t + 1, swn, tcn, pnn); // then next day's forcing in flight
         double rain, snf;
         f.split(d, t, tcv, pnv, rain, snf);
         DayOut o;
-        day_step(c, day_const(d), swv, tcv, rain, snf, st, o);
+        day_step(c, day_const(d), pre, swv, tcv, rain, snf, st, o);
 
         double lim = 0.0;
         if (omask & (1u << 8)) { // R/splash.point.R:197-200 (only when sm_lim is requested)
@@ -548,12 +602,17 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
 #pragma unroll
             for (int q = 0; q < 9; q++) acc[q] += v[q];
         }
+#ifndef SPL_DIAG_NODAY
         if (DIAG) {
-            dg[0] += rain + snf;
-            dg[1] += o.aet;
-            dg[2] += o.ro;
-            dg[3] += o.bflow;
+            // ds_add_f64 without return: fire and forget, no LDS round trip on the critical path
+            // (each slot has one writer, so the "atomic" is only a way to name the instruction)
+            const double inc[4] = {rain + snf, o.aet, o.ro, o.bflow};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                (void)__hip_atomic_fetch_add(&s_dg[k][threadIdx.x], inc[k], __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+#endif
         const bool month_end = (d.flags & 1) != 0;
         if (month_end || t == a.nt - 1) {
             const int m = d.month_id - a.month0;
@@ -573,16 +632,18 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
                     acc[q] = 0.0;
                 }
             }
-            if (DIAG) {
+#ifndef SPL_DIAG_NOMONTH
+            if constexpr (DIAG) {
                 // flux totals of the (part of the) month inside this call; the storages wn and
                 // snow and the cell-month count only at the month's real last day
-                const double w[SPLASH_NDIAG_K] = {dg[0], dg[1], dg[2], dg[3],
-                                                  month_end ? st.wn : 0.0, month_end ? st.snow : 0.0};
-                diag_add(a.diag_acc, a.basin, a.n_basin, a.nmonth_cal, d.month_id, ci, valid, w,
-                         month_end);
+                s_dg[4][threadIdx.x] = month_end ? st.wn : 0.0;
+                s_dg[5][threadIdx.x] = month_end ? st.snow : 0.0;
+                diag_add(a.diag_acc, s_acc, wg_basin, a.basin, a.n_basin, a.nmonth_cal, d.month_id,
+                         d.month_id - a.month0, ci, valid, s_dg, month_end);
 #pragma unroll
-                for (int q = 0; q < 4; q++) dg[q] = 0.0;
+                for (int q = 0; q < 4; q++) s_dg[q][threadIdx.x] = 0.0;
             }
+#endif
         }
         swv = swn;
         tcv = tcn;
@@ -594,6 +655,20 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
         a.state[2 * a.lds + ci] = st.qin;
         a.state[3 * a.lds + ci] = st.td;
         a.state[4 * a.lds + ci] = st.nd;
+    }
+    if constexpr (DIAG) { // flush the workgroup's accumulators: one global atomic per limb
+        __syncthreads();
+        if (wg_basin >= 0) {
+            const int nm = a.nmonth < kDiagLdsMonths ? a.nmonth : kDiagLdsMonths;
+            for (int k = threadIdx.x; k < nm * kDiagRec; k += kBlock) {
+                const unsigned long long v = s_acc[k];
+                if (v != 0ull)
+                    atomicAdd((unsigned long long*)a.diag_acc +
+                                  ((size_t)wg_basin * a.nmonth_cal + a.month0 + k / kDiagRec) * kDiagRec +
+                                  k % kDiagRec,
+                              v);
+            }
+        }
     }
 }
 
@@ -614,7 +689,7 @@ __global__ __launch_bounds__(64) void k_run_all_mod(RunArgs a)
         f.raw(t, swv, tcv, pnv);
         f.split(d, t, tcv, pnv, rain, snf);
         DayOut o;
-        day_step(c, day_const(d), swv, tcv, rain, snf, st, o);
+        day_step(c, day_const(d), day_prefetch(c, tcv), swv, tcv, rain, snf, st, o);
         size_t k = (size_t)t * a.ldo + cell;
         const double v[8] = {st.wn, o.ro, o.pet, o.aet, st.snow, o.cond, o.bflow, o.netr};
 #pragma unroll
@@ -704,6 +779,29 @@ __global__ __launch_bounds__(kBlock) void k_unswc(size_t ncell, int nt,
     }
 }
 
+// ================================================================ viscosity tables ============
+// every float of the two argument ranges through the routine's own code (splash_device.hpp)
+__global__ __launch_bounds__(kBlock) void k_visc_tables(float* __restrict__ rtab,
+                                                       float* __restrict__ ttab)
+{
+    lds_tables_init();
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < kViscNR) {
+        float c[6];
+        visc_rbar_part(__uint_as_float(kViscR0 + i), c);
+        float* o = rtab + (size_t)i * 8;
+#pragma unroll
+        for (int k = 0; k < 6; k++) o[k] = c[k];
+        o[6] = o[7] = 0.0f;
+    }
+    if (i < kViscNT) {
+        float mu0, ctbar;
+        visc_tbar_part(__uint_as_float(kViscT0 + i), mu0, ctbar);
+        ttab[(size_t)i * 2] = mu0;
+        ttab[(size_t)i * 2 + 1] = ctbar;
+    }
+}
+
 // ================================================================ test hooks ===================
 // SOLAR+EVAP for independent rows (src/EVAP.cpp:82-264)
 __global__ __launch_bounds__(kBlock) void k_evap_batch(size_t m, const double* lat,
@@ -712,12 +810,13 @@ __global__ __launch_bounds__(kBlock) void k_evap_batch(size_t m, const double* l
                                                       const double* cd, const double* sw_in,
                                                       const double* tc, const double* slop,
                                                       const double* asp, const double* snow,
-                                                      const double* nd, double* out)
+                                                      const double* nd, double* out, ViscTables vt)
 {
     lds_tables_init();
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
     CellConst c;
+    c.vt = vt;
     double sl = sin(lat[i] * kPir), cl = cos(lat[i] * kPir);
     double ss = sin(slop[i] * kPir), cs = cos(slop[i] * kPir);
     double sa = sin(asp[i] * kPir), ca = cos(asp[i] * kPir);
@@ -733,7 +832,7 @@ __global__ __launch_bounds__(kBlock) void k_evap_batch(size_t m, const double* l
     c.visc0 = (double)viscosity_h2o(0.0f, c.patm_f);
     DayConst d{dr[i], sd[i], cd[i], 0.0, 1.0};
     Etr e;
-    evap_day(c, d, sw[i], sw_in[i], tc[i], snow[i], nd[i], e);
+    evap_day(c, d, day_prefetch(c, tc[i]), sw[i], sw_in[i], tc[i], snow[i], nd[i], e);
     double* o = out + i * 11;
     o[0] = e.cond;
     o[1] = e.pet; // eet == pet (src/EVAP.cpp:140)
@@ -1037,6 +1136,15 @@ hipError_t launch_diag_finalize(const long long* acc, int n_rec, double* diag, d
     return hipGetLastError();
 }
 
+size_t visc_table_floats_r() { return (size_t)kViscNR * 8; }
+size_t visc_table_floats_t() { return (size_t)kViscNT * 2; }
+hipError_t launch_visc_tables(float* rtab, float* ttab, hipStream_t s)
+{
+    const uint32_t nmax = kViscNR > kViscNT ? kViscNR : kViscNT;
+    hipLaunchKernelGGL(k_visc_tables, dim3(nblk(nmax, kBlock)), dim3(kBlock), 0, s, rtab, ttab);
+    return hipGetLastError();
+}
+
 hipError_t launch_widen_f32(const float* src, size_t n, double* dst, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
@@ -1050,11 +1158,11 @@ hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, con
                              const double* dr, const double* sd, const double* cd,
                              const double* sw_in, const double* tc, const double* slop,
                              const double* asp, const double* snow, const double* nd, double* out,
-                             hipStream_t s)
+                             ViscTables vt, hipStream_t s)
 {
     if (m == 0) return hipSuccess;
     hipLaunchKernelGGL(k_evap_batch, dim3(nblk(m, kBlock)), dim3(kBlock), 0, s, m, lat, elv, sw, dr,
-                       sd, cd, sw_in, tc, slop, asp, snow, nd, out);
+                       sd, cd, sw_in, tc, slop, asp, snow, nd, out, vt);
     return hipGetLastError();
 }
 

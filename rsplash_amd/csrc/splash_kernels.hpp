@@ -26,6 +26,15 @@ struct DayRec {
     int doy;             // day of year (synthetic generator)
 };
 
+// per-device lookup tables of the float viscosity routine (splash_device.hpp, k_visc_tables)
+struct ViscTables {
+    const float* rtab; // [kViscNR][8]: coef2[0..5], 2 x padding   (index: bits(rbar) - kViscR0)
+    const float* ttab; // [kViscNT][2]: mu0, ctbar                  (index: bits(tbar) - kViscT0)
+};
+size_t visc_table_floats_r();
+size_t visc_table_floats_t();
+hipError_t launch_visc_tables(float* rtab, float* ttab, hipStream_t s);
+
 struct SpinArgs {
     const DayRec* days; // first 365 days
     int n;
@@ -61,6 +70,7 @@ struct SpinPhaseArgs {
     double* ai;             // [ncell] aridity index
     int budget;             // passes per job in this phase
     int fresh;              // phase 0
+    ViscTables vt;
 };
 
 struct RunArgs {
@@ -87,6 +97,7 @@ struct RunArgs {
     const int* basin; // [ncell] or NULL
     int n_basin;
     int nmonth_cal;   // months in the whole calendar (row stride of diag_acc)
+    ViscTables vt;
 };
 
 hipError_t launch_soil_hydro(size_t ncell, const double* lat, const double* elev,
@@ -106,7 +117,7 @@ hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, con
                              const double* dr, const double* sd, const double* cd,
                              const double* sw_in, const double* tc, const double* slop,
                              const double* asp, const double* snow, const double* nd, double* out,
-                             hipStream_t s);
+                             ViscTables vt, hipStream_t s);
 hipError_t launch_unswc(size_t ncell, int nt, const double* wn, size_t ldw, const double* soil,
                         double uns_depth, double* wn_z, double* wtd, double* theta, size_t ldo,
                         hipStream_t s);
