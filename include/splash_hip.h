@@ -169,6 +169,27 @@ int splash_dev_evap_batch(size_t m, const double* lat, const double* elv, const 
                           const double* slop, const double* asp, const double* snow,
                           const double* nd, double* out, void* stream);
 
+/* ---------------------------------------------------------------- static rasters */
+/* What splash.grid derives from the elevation raster before the loop, for a north-up
+ * longitude/latitude grid of H rows x W columns (row-major, NaN = NA, elevation in metres):
+ * slope and aspect in degrees (raster::terrain(opt=c('slope','aspect'), unit='degrees'): Horn's
+ * 3x3 differences, aspect clockwise from north, NA on the outer ring and next to NA cells, which
+ * R/splash.grid.R:107 turns into 0 where an elevation exists: na_to_zero), cell-centre latitude
+ * (:101-103), resolution = sqrt(cell area) in metres (:98) and the D8 flow direction code
+ * (raster::terrain(opt='flowdir'), R/upslope_area.R:31).  ymax = northern edge, yres/xres = cell
+ * size, all in degrees.  Device pointers; outputs [H*W], any may be NULL.  The arithmetic of
+ * raster::terrain / raster::area is not in the reference tree: this follows the published
+ * algorithms (parity unpinned). */
+int splash_dev_terrain(int H, int W, const double* elev, double ymax, double yres, double xres,
+                       int na_to_zero, double* slope_deg, double* aspect_deg, double* lat,
+                       double* resolution_m, double* flowdir, void* stream);
+/* ncellflow (R/upslope_area.R:140-165): count of the 3x3 neighbours whose flow code equals
+ * codes9[position] (window in row order; device pointer to 9 doubles, e.g. 2,1,128,4,0,64,8,16,32
+ * for inout='in', met='top' and the reverse for 'out'); 0 -> 1; NA if the window is all NA.
+ * pad = 0: outer ring NA (raster::focal's default); pad = 1: NA outside the grid. */
+int splash_dev_ncellflow(int H, int W, const double* flowdir, const double* codes9, int pad,
+                         double* ncell, void* stream);
+
 /* ---------------------------------------------------------------- unSWC epilogue */
 /* R/unsSWC.R:14-88 / R/unsSWC.grid.R: from the column water content wn [mm] (output of the path
  * above), the water held between the surface and uns_depth [m] (wn_z, mm), the water-table depth

@@ -124,6 +124,8 @@ class Oracle:
             [C.POINTER(_dp), C.c_int, _ip]
         L.orc_grid_transient2.argtypes = [C.c_int, C.c_int, _ip, _ip, _ip] + [_dp] * 10 + \
             [_dp, C.POINTER(_dp), C.c_void_p, C.c_double, C.c_void_p, C.c_int]
+        L.orc_terrain.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_double, C.c_double, C.c_int] + [_dp] * 5
+        L.orc_ncellflow.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
         L.orc_synth_statics.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int] + \
             [_dp] * 7
         L.orc_synth_forcing.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
@@ -335,6 +337,20 @@ class Oracle:
                                      ev.ctypes.data, float(hs_lim_deg),
                                      hs.ctypes.data if want_hs else None, n_threads)
         return out, st, ev, hs
+
+    def terrain(self, elev, ymax, yres, xres, na_to_zero=True):
+        """R/splash.grid.R:96-110 + flow direction and ncellflow of R/upslope_area.R:31-33, 140-165"""
+        e, ep = _d(elev)
+        H, W = e.shape
+        o = {k: np.empty((H, W)) for k in ("slope", "aspect", "lat", "resolution", "flowdir")}
+        self.lib.orc_terrain(H, W, ep, ymax, yres, xres, int(na_to_zero),
+                             *[o[k].ctypes.data_as(_dp) for k in ("slope", "aspect", "lat", "resolution", "flowdir")])
+        for name, codes in (("ncellin", (2, 1, 128, 4, 0, 64, 8, 16, 32)),
+                            ("ncellout", (32, 16, 8, 64, 0, 4, 128, 1, 2))):
+            c9, c9p = _d(np.array(codes, dtype=np.float64))
+            o[name] = np.empty((H, W))
+            self.lib.orc_ncellflow(H, W, o["flowdir"].ctypes.data_as(_dp), c9p, 0, o[name].ctypes.data_as(_dp))
+        return o
 
     def synth_statics(self, seed, H, W, cell0, ncell, terrain):
         lat, elev, slop, asp, res = (np.empty(ncell) for _ in range(5))

@@ -1633,6 +1633,99 @@ void orc_grid_transient2(int ncell, int nt, const int* doy, const int* year, con
     }
 }
 
+/* ------------------------------------------------------------------ static rasters
+ * PARITY UNPINNED: raster::terrain, raster::area and raster::focal are not part of the reference
+ * tree (DESCRIPTION:10 imports them) and no R runs here.  orc_terrain restates the published
+ * algorithms those functions document (Horn 1981 for slope/aspect on a lon/lat grid with metric
+ * cell spacing per row, D8 steepest descent with raster's power-of-two codes); orc_ncellflow
+ * restates R/upslope_area.R:140-165, which IS reference code, assuming raster::focal hands the
+ * window to `fun` in row order. */
+void orc_terrain(int H, int W, const double* elev, double ymax, double yres, double xres,
+                 int na_to_zero, double* slope, double* aspect, double* lat_o, double* res_o,
+                 double* flowdir)
+{
+    const double Rearth = 6378137.0;
+    for (int r = 0; r < H; r++) {
+        const double lat = ymax - ((double)r + 0.5) * yres;
+        const double dy = Rearth * (yres * G_pir);
+        const double dx = Rearth * cos(lat * G_pir) * (xres * G_pir);
+        for (int c = 0; c < W; c++) {
+            size_t i = (size_t)r * W + c;
+            double z = elev[i];
+            if (lat_o) lat_o[i] = isnan(z) ? NAN : lat;
+            if (res_o) res_o[i] = isnan(z) ? NAN : sqrt(dx * dy);
+            double sl = NAN, as = NAN, fd = NAN;
+            if (r > 0 && r < H - 1 && c > 0 && c < W - 1 && !isnan(z)) {
+                double a = elev[i - W - 1], b = elev[i - W], cc = elev[i - W + 1];
+                double d = elev[i - 1], f = elev[i + 1];
+                double g = elev[i + W - 1], h = elev[i + W], k = elev[i + W + 1];
+                double sum8 = a + b + cc + d + f + g + h + k;
+                if (!isnan(sum8)) {
+                    double zx = ((cc + 2.0 * f + k) - (a + 2.0 * d + g)) / (8.0 * dx);
+                    double zy = ((a + 2.0 * b + cc) - (g + 2.0 * h + k)) / (8.0 * dy);
+                    sl = atan(sqrt(zx * zx + zy * zy)) / G_pir;
+                    if (zx == 0.0 && zy == 0.0) {
+                        as = 90.0;
+                    } else {
+                        as = atan2(-zx, -zy) / G_pir;
+                        if (as < 0.0) as += 360.0;
+                    }
+                }
+                double dd = sqrt(dx * dx + dy * dy);
+                double nb[8] = {f, k, h, g, d, a, b, cc};
+                double dist[8] = {dx, dd, dy, dd, dx, dd, dy, dd};
+                double best = -INFINITY;
+                int code = 0, any = 0;
+                for (int q = 0; q < 8; q++) {
+                    if (!isnan(nb[q])) {
+                        double drop = (z - nb[q]) / dist[q];
+                        if (drop > best) {
+                            best = drop;
+                            code = 1 << q;
+                        }
+                        any = 1;
+                    }
+                }
+                if (any) fd = (double)code;
+            }
+            if (na_to_zero && !isnan(z)) { /* R/splash.grid.R:107 */
+                if (isnan(sl)) sl = 0.0;
+                if (isnan(as)) as = 0.0;
+            }
+            if (slope) slope[i] = sl;
+            if (aspect) aspect[i] = as;
+            if (flowdir) flowdir[i] = fd;
+        }
+    }
+}
+
+/* R/upslope_area.R:140-165 (compare() under raster::focal with a 3x3 window of ones) */
+void orc_ncellflow(int H, int W, const double* fd, const double* codes9, int pad, double* out)
+{
+    for (int r = 0; r < H; r++) {
+        for (int c = 0; c < W; c++) {
+            size_t i = (size_t)r * W + c;
+            if ((r == 0 || r == H - 1 || c == 0 || c == W - 1) && !pad) {
+                out[i] = NAN;
+                continue;
+            }
+            int nna = 0, nmatch = 0;
+            for (int q = 0; q < 9; q++) {
+                int rr = r + q / 3 - 1, cc = c + q % 3 - 1;
+                double v = NAN;
+                if (rr >= 0 && rr < H && cc >= 0 && cc < W) v = fd[(size_t)rr * W + cc];
+                if (isnan(v)) {
+                    nna++; /* length(x[is.na(x)]), :150 */
+                } else if (v == codes9[q]) {
+                    nmatch++; /* comp <- x[!is.na(x)] == flow[!is.na(x)], :153-154 */
+                }
+            }
+            if (nmatch == 0) nmatch = 1; /* nmatch[nmatch==0] <- 1, :157 */
+            out[i] = (nna == 9) ? NAN : (double)nmatch;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ synthetic inputs */
 
 static inline uint64_t mix64(uint64_t z)

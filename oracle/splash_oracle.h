@@ -174,6 +174,12 @@ void orc_grid_transient2(int ncell, int nt, const int* doy, const int* year, con
 double orc_last_hs(void);
 double* orc_debug_ptr(void);
 
+/* ---- static rasters; parity unpinned, see the definitions ---- */
+void orc_terrain(int H, int W, const double* elev, double ymax, double yres, double xres,
+                 int na_to_zero, double* slope, double* aspect, double* lat, double* resolution,
+                 double* flowdir);
+void orc_ncellflow(int H, int W, const double* flowdir, const double* codes9, int pad, double* out);
+
 /* ---- synthetic inputs (SURVEY.md 8d spec; splitmix64 counter RNG) ---- */
 double orc_synth_u(uint64_t seed, uint64_t stream, uint64_t cell, uint64_t day);
 /* statics for cells [cell0, cell0+ncell) of an H x W grid (row-major cell index).

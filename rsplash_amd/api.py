@@ -462,3 +462,41 @@ def dev_synth_forcing(seed, cal, t0, nt, cell0, ncell, lat, elev, sw_in, tc, pn,
     check(lib.splash_dev_synth_forcing(seed, cal.h, t0, nt, cell0, ncell, _ptr(lat), _ptr(elev),
                                        _ptr(sw_in), _ptr(tc), _ptr(pn), ldf, stream),
           "splash_dev_synth_forcing")
+
+
+# ---------------------------------------------------------------------------- static rasters
+FLOW_IN_TOP = (2, 1, 128, 4, 0, 64, 8, 16, 32)     # matrix(c(...), nrow=3), R/upslope_area.R:142
+FLOW_OUT_TOP = tuple(reversed(FLOW_IN_TOP))        # :144
+
+
+def dev_terrain(H, W, elev, ymax, yres, xres, slope=None, aspect=None, lat=None, resolution=None,
+                flowdir=None, na_to_zero=True, stream=None):
+    """R/splash.grid.R:96-110 on a device-resident lon/lat elevation raster [H*W] (see
+    include/splash_hip.h: splash_dev_terrain)"""
+    check(lib.splash_dev_terrain(int(H), int(W), _ptr(elev), float(ymax), float(yres), float(xres),
+                                 int(bool(na_to_zero)), _ptr(slope), _ptr(aspect), _ptr(lat),
+                                 _ptr(resolution), _ptr(flowdir), stream), "splash_dev_terrain")
+
+
+def dev_ncellflow(H, W, flowdir, codes9, out, pad=False, stream=None):
+    """R/upslope_area.R:140-165; codes9: device tensor of the 9 window codes in row order"""
+    check(lib.splash_dev_ncellflow(int(H), int(W), _ptr(flowdir), _ptr(codes9), int(bool(pad)),
+                                   _ptr(out), stream), "splash_dev_ncellflow")
+
+
+def terrain(elev, ymax, yres, xres, na_to_zero=True):
+    """host arrays: elev [H, W] -> dict(slope, aspect, lat, resolution, flowdir, ncellin, ncellout),
+    the static rasters splash.grid prepares before its loop (upslope AREA excepted: sink filling and
+    flow accumulation are topmodel/TauDEM code outside the reference tree)"""
+    import torch
+    e = torch.as_tensor(np.ascontiguousarray(elev, dtype=np.float64), device="cuda")
+    H, W = e.shape
+    o = {k: torch.empty(H * W, dtype=torch.float64, device="cuda")
+         for k in ("slope", "aspect", "lat", "resolution", "flowdir", "ncellin", "ncellout")}
+    dev_terrain(H, W, e, ymax, yres, xres, o["slope"], o["aspect"], o["lat"], o["resolution"],
+                o["flowdir"], na_to_zero)
+    for name, codes in (("ncellin", FLOW_IN_TOP), ("ncellout", FLOW_OUT_TOP)):
+        c9 = torch.tensor(codes, dtype=torch.float64, device="cuda")
+        dev_ncellflow(H, W, o["flowdir"], c9, o[name])
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy().reshape(H, W) for k, v in o.items()}

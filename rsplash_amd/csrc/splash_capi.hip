@@ -305,9 +305,18 @@ extern "C" int splash_dev_snow_threshold(size_t ncell, int nt, const double* tc,
     return SPLASH_OK;
 }
 
-// workspace of splash_dev_spin_up: two worklists, job records, aridity index, phase counters
+// workspace of splash_dev_spin_up: two worklists, job records, aridity index, phase counters, and
+// the last phase's cache of state-independent day terms (room for 1/128 of the cells, at least
+// 4096: the cells that need more than a few dozen passes are a few per thousand)
+static size_t spin_cache_cap(size_t ncell)
+{
+    size_t cap = std::max<size_t>(4096, ncell / 128);
+    cap = std::min(cap, ncell);
+    return (cap + 63) & ~(size_t)63;
+}
+
 static size_t spin_work_layout(size_t ncell, size_t* o_wl_b, size_t* o_meta, size_t* o_ai,
-                               size_t* o_cnt)
+                               size_t* o_cnt, size_t* o_cache = nullptr)
 {
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -317,10 +326,12 @@ static size_t spin_work_layout(size_t ncell, size_t* o_wl_b, size_t* o_meta, siz
     };
     take(ncell * 4); // wl_a at 0
     size_t wl_b = take(ncell * 4), meta = take(ncell * 4), ai = take(ncell * 8), cnt = take(64);
+    size_t cache = take(spin_cache_cap(ncell) * spin_cache_bytes_per_slot());
     if (o_wl_b) *o_wl_b = wl_b;
     if (o_meta) *o_meta = meta;
     if (o_ai) *o_ai = ai;
     if (o_cnt) *o_cnt = cnt;
+    if (o_cache) *o_cache = cache;
     return off;
 }
 
@@ -341,8 +352,8 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
     if (int rc = need_device(nullptr, 0)) return rc;
     if (ncell == 0) return SPLASH_OK;
     hipStream_t s = (hipStream_t)stream;
-    size_t o_wl_b, o_meta, o_ai, o_cnt;
-    spin_work_layout(ncell, &o_wl_b, &o_meta, &o_ai, &o_cnt);
+    size_t o_wl_b, o_meta, o_ai, o_cnt, o_cache;
+    spin_work_layout(ncell, &o_wl_b, &o_meta, &o_ai, &o_cnt, &o_cache);
     char* w = (char*)work;
     uint32_t* wl[2] = {(uint32_t*)w, (uint32_t*)(w + o_wl_b)};
     uint32_t* cnt = (uint32_t*)(w + o_cnt);
@@ -376,6 +387,8 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
         a.n_in = ph == 0 ? nullptr : cnt + (ph - 1);
         a.wl_out = wl[ph & 1];
         a.n_out = cnt + ph;
+        a.cache = (ph == 3) ? (double*)(w + o_cache) : nullptr;
+        a.cache_cap = spin_cache_cap(ncell);
         HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
     }
     return SPLASH_OK;
@@ -486,6 +499,29 @@ extern "C" int splash_dev_synth_forcing(uint64_t seed, const splash_calendar* ca
     if (int rc = need_device(nullptr, 0)) return rc;
     HIP_TRY(launch_synth_forcing(seed, cal->dev + t0, t0, nt, cell0, ncell, lat, elev, sw_in, tc,
                                  pn, ldf, (hipStream_t)stream), nullptr, 0);
+    return SPLASH_OK;
+}
+
+// static rasters before the loop: R/splash.grid.R:96-110, R/upslope_area.R:31-33
+extern "C" int splash_dev_terrain(int H, int W, const double* elev, double ymax, double yres,
+                                  double xres, int na_to_zero, double* slope_deg, double* aspect_deg,
+                                  double* lat, double* resolution_m, double* flowdir, void* stream)
+{
+    REQ(elev && H > 0 && W > 0, "terrain: NULL elevation or empty grid");
+    REQ(yres > 0 && xres > 0, "terrain: cell size must be positive (degrees)");
+    REQ(slope_deg || aspect_deg || lat || resolution_m || flowdir, "terrain: no output requested");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    HIP_TRY(launch_terrain(H, W, elev, ymax, yres, xres, na_to_zero, slope_deg, aspect_deg, lat,
+                           resolution_m, flowdir, (hipStream_t)stream), nullptr, 0);
+    return SPLASH_OK;
+}
+
+extern "C" int splash_dev_ncellflow(int H, int W, const double* flowdir, const double* codes9,
+                                    int pad, double* ncell, void* stream)
+{
+    REQ(flowdir && codes9 && ncell && H > 0 && W > 0, "ncellflow: NULL argument or empty grid");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    HIP_TRY(launch_ncellflow(H, W, flowdir, codes9, pad, ncell, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
 }
 
@@ -668,7 +704,8 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
     HIP_TRY(hipMemGetInfo(&free_b, &total_b), err, errlen);
     const size_t per_cell = (size_t)nt * 3 * 8 + (f32 ? (size_t)nt * 4 : 0) +
                             (size_t)nt_out * n_out * 8 +
-                            (SPLASH_NPAR + SPLASH_NSTATE + 6 + 5 + 3 + 1 + 4 + 4 + 1) * 8 + 64;
+                            (SPLASH_NPAR + SPLASH_NSTATE + 6 + 5 + 3 + 1 + 4 + 4 + 1) * 8 + 64 +
+                            spin_cache_bytes_per_slot() / 128 + 8;
     size_t nb_max = (size_t)((double)free_b * 0.85 / (double)std::max(share, 1)) / per_cell;
     if (P.max_cells) nb_max = std::min(nb_max, P.max_cells);
     if (nb_max == 0) return fail(SPLASH_ENOMEM, err, errlen, "grid_run: not enough device memory");

@@ -624,15 +624,48 @@ __device__ __forceinline__ void hour_angle(double cosv, bool at_one_is_zero, dou
 #endif
 }
 
-// src/SOLAR.cpp:77-267 + src/EVAP.cpp:82-264 for one cell-day.
+// src/SOLAR.cpp:77-267 + src/EVAP.cpp:82-264 for one cell-day, in two parts.
+//
+// day_terms():  everything that depends only on the cell, the calendar day and the day's forcing
+//   -- the slope geometry and the sunset angle, the cloud factor and net longwave, the water
+//   properties (saturation slope, latent heat, density, psychrometric constant, viscosity) and
+//   what follows from them -- 17 numbers.  They do not depend on the state (soil water, snow pack),
+//   so a spin-up pass after the first finds the same 17 numbers for every day of the year: the
+//   tail of the spin-up (cells that run hundreds of passes, alone on their SIMD, paying the full
+//   instruction latency of every day step) stores them once and reads them back (k_spin_phase).
+// evap_update(): the state-dependent rest (albedo, net radiation and its cross-over angle, the
+//   supply-limited evaporation, snowmelt).
+// Both callers go through terms_fence(), which pins every term to a register as a finished
+// double, so that the compiler cannot contract a multiply of day_terms() into an add of the
+// update: the results are bit-identical whether the terms were computed or loaded.
 // sw is the supply fraction (src/SPLASH.cpp:1042-1048), snow already includes today's snowfall.
 // Angles are kept in radians (the reference converts to degrees and back at every use).
-__device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, const DayPre& pre,
-                                         double sw, double sw_in, double tc, double snow, double nd,
-                                         Etr& o)
+struct DayTerms {
+    double ru, rv, ruv;   // slope-corrected geometry, ru/rv (src/SOLAR.cpp:139-140)
+    double hs, sin_hs;    // sunset angle on the slope and its sine (:149-159)
+    double xrw;           // rw = (1 - albedo) * xrw (:220-224)
+    double rnl;           // net longwave (:203)
+    double s, g;          // saturation slope, psychrometric constant (src/EVAP.cpp:111, 115)
+    double econ, inv_econ, eetc; // :117, its reciprocal, 1e3*s/(lv*pw*(s+0.24g)) (:129)
+    double pw, ipk;       // water density, 1/(pw*kfus) when tc >= 3 (:113, :233-236)
+    double kv, ikv24;     // Ksat_visc and 1/(24*Ksat_visc) (src/SPLASH.cpp:1260-1261, :1281)
+    double tc;
+};
+constexpr int kNTerms = 17;
+
+__device__ __forceinline__ void terms_fence(DayTerms& T)
+{
+#define SPL_PIN(x) asm volatile("" : "+v"(x))
+    SPL_PIN(T.ru); SPL_PIN(T.rv); SPL_PIN(T.ruv); SPL_PIN(T.hs); SPL_PIN(T.sin_hs); SPL_PIN(T.xrw);
+    SPL_PIN(T.rnl); SPL_PIN(T.s); SPL_PIN(T.g); SPL_PIN(T.econ); SPL_PIN(T.inv_econ); SPL_PIN(T.eetc);
+    SPL_PIN(T.pw); SPL_PIN(T.ipk); SPL_PIN(T.kv); SPL_PIN(T.ikv24); SPL_PIN(T.tc);
+#undef SPL_PIN
+}
+
+__device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d, const DayPre& pre,
+                                          double sw_in, double tc, DayTerms& T)
 {
     // ----- SOLAR
-    const double sw_s = sw > 1.0 ? 1.0 : sw; // :92
     const double a = d.sd * c.ka, b = d.cd * c.kb, cc = d.cd * c.kc;
     const double b2c2 = b * b + cc * cc;
     const double dd = b2c2 - a * a;
@@ -665,31 +698,18 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     } else if (sf > 1.0) {
         sf = 1.0;
     }
-    const double rnl = (0.0883289 + (1.0 - kB) * sf) * (kA + 1.95974 * tc); // :203
-
-    const double alb_v = kAlbSw - 0.17 * sw_s; // :215
-    double alb = alb_v;                        // snow-free: sfc = 0 => alb = alb_v exactly
-    if (snow > 0.0 || isnan(snow)) {           // :208-219
-        const double max_alb_snw = (1.0 - 0.443700) + (0.443700 * fexp(-0.895189 * nd));
-        const double sfc = snow * frcp(140.0 + snow);
-        alb = alb_v * (1.0 - sfc) + sfc * max_alb_snw;
-    }
-    double rw; // :220-224
+    T.rnl = (0.0883289 + (1.0 - kB) * sf) * (kA + 1.95974 * tc); // :203
+    // rw = (1 - alb) * xrw, :220-224
     if ((sw_in == 0.0) || (hs == 0.0)) {
-        rw = (1.0 - alb) * tau * d.dr * kGsc;
+        T.xrw = tau * d.dr * kGsc;
     } else {
-        rw = (1.0 - alb) * (r_in) / ((86400.0 / kPI) * geo);
+        T.xrw = (r_in) / ((86400.0 / kPI) * geo);
     }
-
-    const double inv_rwrv = 1.0 / (rw * rv);
-    const double xn = (rnl - rw * ru) * inv_rwrv; // :231
-    double hn, sin_hn; // xn >= 1: net radiation negative all day (hn = 0)
-    hour_angle(xn, true, hn, sin_hn);
-    const double rn_d = (hn * (rw * ru - rnl) + rw * rv * sin_hn) * (86400.0 / kPI); // :245-246
-    double rnn_d = rw * rv * (sin_hs - sin_hn);                                       // :252-255
-    rnn_d += rw * ru * (hs - hn);
-    rnn_d -= rnl * (kPI - hn);
-    rnn_d *= (86400.0 / kPI);
+    T.ru = ru;
+    T.rv = rv;
+    T.ruv = ruv;
+    T.hs = hs;
+    T.sin_hs = sin_hs;
 
     // ----- EVAP
     double s; // sat_slope :299-301 (tc + 237.3 > 0 for any air temperature above -237 C)
@@ -709,10 +729,48 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     // econ = s/(lv*pw*(s+g)) (:117) and s/(lv*pw*(s+0.24g)) (:129) from one reciprocal
     const double sg1 = s + g, sg2 = s + 0.24 * g;
     const double inv_e = frcp(lvpw * sg1 * sg2);
-    const double econ = s * sg2 * inv_e;
+    T.econ = s * sg2 * inv_e;
+    T.inv_econ = frcp(T.econ);
+    T.eetc = (1.0e3) * (s * sg1 * inv_e);                             // :129
+    T.s = s;
+    T.g = g;
+    T.pw = pw;
+    T.ipk = 0.0;                                                      // :233-236
+    if (tc >= 3.0) {
+        T.ipk = frcp(pw * kKfus);
+    }
     const double visc = day_viscosity(c, pre, tc);                    // :100-105, :120
+    T.kv = c.int_perm * ((pw * kG) * frcp(visc)) * 3.6;               // src/SPLASH.cpp:1260-1261
+    T.ikv24 = frcp(T.kv * 24);
+    T.tc = tc;
+}
+
+__device__ __forceinline__ void evap_update(const CellConst& c, const DayTerms& T, double sw,
+                                            double snow, double nd, Etr& o)
+{
+    const double ru = T.ru, rv = T.rv, rnl = T.rnl, s = T.s, g = T.g, econ = T.econ;
+    const double sw_s = sw > 1.0 ? 1.0 : sw; // :92
+    const double alb_v = kAlbSw - 0.17 * sw_s; // :215
+    double alb = alb_v;                        // snow-free: sfc = 0 => alb = alb_v exactly
+    if (snow > 0.0 || isnan(snow)) {           // :208-219
+        const double max_alb_snw = (1.0 - 0.443700) + (0.443700 * fexp(-0.895189 * nd));
+        const double sfc = snow * frcp(140.0 + snow);
+        alb = alb_v * (1.0 - sfc) + sfc * max_alb_snw;
+    }
+    const double rw = (1.0 - alb) * T.xrw; // :220-224
+
+    const double inv_rwrv = 1.0 / (rw * rv);
+    const double xn = (rnl - rw * ru) * inv_rwrv; // :231
+    double hn, sin_hn; // xn >= 1: net radiation negative all day (hn = 0)
+    hour_angle(xn, true, hn, sin_hn);
+    const double rn_d = (hn * (rw * ru - rnl) + rw * rv * sin_hn) * (86400.0 / kPI); // :245-246
+    double rnn_d = rw * rv * (T.sin_hs - sin_hn);                                     // :252-255
+    rnn_d += rw * ru * (T.hs - hn);
+    rnn_d -= rnl * (kPI - hn);
+    rnn_d *= (86400.0 / kPI);
+
     const double cn = (1.0e3) * econ * fabs(rnn_d) * 0.1;             // :124
-    const double eet_d = (1.0e3) * (s * sg1 * inv_e) * rn_d;          // :129
+    const double eet_d = T.eetc * rn_d;                               // :129
     const double rx = (3.6e6) * econ;                                 // :145
     const double pet_max = rx * ((rw * (ru + rv)) - rnl);             // :148
 
@@ -722,22 +780,21 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     if (sup < 0.0 || isnan(sup)) {
         sup = 0.0;
     }
-    const double inv_econ = frcp(econ);
-    const double cos_hi = (sup * (inv_econ * (1.0 / 3.6e6)) + rnl) * inv_rwrv - ruv; // :208
+    const double cos_hi = (sup * (T.inv_econ * (1.0 / 3.6e6)) + rnl) * inv_rwrv - T.ruv; // :208
     double hi, sin_hi; // cos_hi >= 1: supply exceeds demand (hi = 0)
     hour_angle(cos_hi, true, hi, sin_hi);
 
     double snowmelt = 0.0, sublimation = 0.0, melt_enrg = 0.0; // :233-249
-    if (tc >= 3.0) {
-        const double m = (rn_d * frcp(pw * kKfus)) * 1000.0;
+    if (T.tc >= 3.0) {
+        const double m = (rn_d * T.ipk) * 1000.0;
         snowmelt = SPL_MIN(snow, m);
-        melt_enrg = (snowmelt * 1.0e-3) * pw * kKfus;
+        melt_enrg = (snowmelt * 1.0e-3) * T.pw * kKfus;
     }
     {
         const double AE = rn_d - melt_enrg;
         const double sub_c = (AE * econ) * 1000.0;
         sublimation = SPL_MIN(snowmelt, sub_c);
-        melt_enrg += ((sublimation * 1.0e-3) * inv_econ);
+        melt_enrg += ((sublimation * 1.0e-3) * T.inv_econ);
     }
 
     double aet_d = sup * hi; // :254-263
@@ -754,11 +811,23 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     o.aet = aet_d;
     o.snowmelt = snowmelt;
     o.sublimation = sublimation;
-    o.pw = pw;
+    o.pw = T.pw;
     o.rn_d = rn_d;
-    o.visc = visc;
+    o.visc = 0.0; // filled by evap_day() for the test hook; the water balance uses T.kv
     o.econ = econ;
     o.pet_max = pet_max;
+}
+
+// SOLAR + EVAP in one go (test hook k_evap_batch: src/EVAP.cpp:82-264 row by row)
+__device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, const DayPre& pre,
+                                         double sw, double sw_in, double tc, double snow, double nd,
+                                         Etr& o)
+{
+    DayTerms T;
+    day_terms(c, d, pre, sw_in, tc, T);
+    terms_fence(T);
+    evap_update(c, T, sw, snow, nd, o);
+    o.visc = day_viscosity(c, pre, tc);
 }
 
 // ---- SPLASH helpers ---------------------------------------------------------------------------
@@ -902,9 +971,10 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
 }
 
 // ---- the day step: src/SPLASH.cpp:920-1588 (== quick_run :150-918) ----------------------------
-__device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, const DayPre& pre,
-                                         double sw_in, double tc, double pn, double snowfall,
-                                         State& st, DayOut& o)
+// day_update(): the water balance given the day's state-independent terms (computed by day_terms()
+// or read back from the spin-up's cache) and the day's rain and snowfall.
+__device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K, double pn,
+                                           double snowfall, State& st, DayOut& o)
 {
     const double wn = st.wn;
     double snow = st.snow, qin = st.qin, td = st.td, nd = st.nd;
@@ -925,12 +995,12 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     snow += snowfall;
 
     Etr ev;
-    evap_day(c, d, pre, sw, sw_in, tc, snow, nd, ev); // :1235
+    evap_update(c, K, sw, snow, nd, ev);          // :1235
     snow -= ev.snowmelt;                          // :1240
     const double snowmelt = ev.snowmelt - ev.sublimation; // :1243
 
     // :1260-1272
-    const double Ksat_visc = c.int_perm * ((ev.pw * kG) * frcp(ev.visc)) * 3.6;
+    const double Ksat_visc = K.kv;
     const double inflow = pn + ev.cond + snowmelt;
     const double infi = inf_GA(c, wn, Ksat_visc, inflow);
     const double ro_h_arg = inflow - infi;
@@ -938,7 +1008,7 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     double R = infi - ev.aet;
 
     // :1275-1284
-    const double hyd_grad_z = (infi * frcp(Ksat_visc * 24)) - 1.0;
+    const double hyd_grad_z = (infi * K.ikv24) - 1.0;
     const double hyd_grad_out = fsqrt(hyd_grad_z * hyd_grad_z + c.tan2_slop);
 
     // :1291-1326 (cell-static part folded into kb_coef); Kb and log(Kb) keep the reference's
@@ -1064,6 +1134,20 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     o.cond = ev.cond;
     o.bflow = T2;
     o.netr = ev.rn_d * 1.0e-6; // src/SPLASH.cpp:1907
+}
+
+// FENCE = true (the spin-up): the terms are finished doubles before the update uses them, exactly
+// as when they are read back from the cache.  FENCE = false (run_all): the compiler may fuse and
+// reorder across the seam (3 % faster: the 17 terms need not all be live at once).
+template <bool FENCE = false>
+__device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, const DayPre& pre,
+                                         double sw_in, double tc, double pn, double snowfall,
+                                         State& st, DayOut& o)
+{
+    DayTerms T;
+    day_terms(c, d, pre, sw_in, tc, T);
+    if (FENCE) terms_fence(T);
+    day_update(c, T, pn, snowfall, st, o);
 }
 
 // ---- rain / snow split: R/splash.point.R:120-128, 521-578 -------------------------------------

@@ -193,6 +193,45 @@ __device__ __forceinline__ bool same_bits(double a, double b)
 // list, so the long-running cells end up packed into few dense waves.
 //   job stage 1: spin-up #1 (cellout as given); its first pass also yields the aridity index
 //   job stage 2: spin-up #2 with cellout := AI (R/splash.point.R:150)
+// One cached record: the 17 state-independent terms of a cell-day (DayTerms) + the day's rain and
+// snowfall; the cache is [365][kNRec][cap] doubles, slot = position of the job in the worklist, so
+// that the 64 lanes of a wavefront read 512 contiguous bytes per field.
+constexpr int kNRec = kNTerms + 2;
+struct DayRecord {
+    DayTerms T;
+    double rain, snf;
+};
+__device__ __forceinline__ void rec_store(double* __restrict__ base, size_t cap, int day, size_t slot,
+                                          const DayRecord& r)
+{
+    double* p = base + ((size_t)day * kNRec) * cap + slot;
+    const double v[kNRec] = {r.T.ru, r.T.rv, r.T.ruv, r.T.hs, r.T.sin_hs, r.T.xrw, r.T.rnl, r.T.s, r.T.g,
+                             r.T.econ, r.T.inv_econ, r.T.eetc, r.T.pw, r.T.ipk, r.T.kv, r.T.ikv24,
+                             r.T.tc, r.rain, r.snf};
+#pragma unroll
+    for (int k = 0; k < kNRec; k++) p[(size_t)k * cap] = v[k];
+}
+__device__ __forceinline__ DayRecord rec_load(const double* __restrict__ base, size_t cap, int day,
+                                              size_t slot)
+{
+    const double* p = base + ((size_t)day * kNRec) * cap + slot;
+    double v[kNRec];
+#pragma unroll
+    for (int k = 0; k < kNRec; k++) v[k] = p[(size_t)k * cap];
+    DayRecord r;
+    r.T.ru = v[0]; r.T.rv = v[1]; r.T.ruv = v[2]; r.T.hs = v[3]; r.T.sin_hs = v[4]; r.T.xrw = v[5];
+    r.T.rnl = v[6]; r.T.s = v[7]; r.T.g = v[8]; r.T.econ = v[9]; r.T.inv_econ = v[10]; r.T.eetc = v[11];
+    r.T.pw = v[12]; r.T.ipk = v[13]; r.T.kv = v[14]; r.T.ikv24 = v[15]; r.T.tc = v[16];
+    r.rain = v[17];
+    r.snf = v[18];
+    return r;
+}
+
+// CACHED (the last phase: the jobs that run hundreds of passes): the first pass of the launch
+// stores every day's record, the later ones read them back and only evaluate the state-dependent
+// update -- the same bits (terms_fence), less than half the instructions, and no forcing reads.
+// Jobs beyond the cache's capacity run the plain way.
+template <bool CACHED>
 __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPhaseArgs a)
 {
     const size_t nin = a.n_in ? (size_t)*a.n_in : a.ncell;
@@ -202,18 +241,15 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     const bool valid = slot < nin;
     const size_t sl = valid ? slot : nin - 1;
     const size_t ci = a.wl_in ? (size_t)a.wl_in[sl] : sl;
+    const bool cached = CACHED && a.cache != nullptr && sl < a.cache_cap;
 
     Forcing f{a.sw, a.tc, a.pn, nullptr, a.ldf, a.Tt[ci],
               a.par[P_ELV * a.ldp + ci] * 0.0004596581, fabs(a.par[P_LAT * a.ldp + ci]) * 0.0110592101,
               (unsigned)(ci * sizeof(double))};
     const DayTable days = day_table(a.days);
     const DayRec d0 = day_rec(days, 0);
-    double sw0, tc0, pn0, rain0, snf0;
-    f.raw(0, sw0, tc0, pn0);
-    f.split(d0, 0, tc0, pn0, rain0, snf0);
 
     int stage, count;
-    State e;
     CellConst c;
     DayOut o;
     double pet_sum = 0.0, p_sum = 0.0;
@@ -221,19 +257,63 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         stage = 1;
         count = 1;
         cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci], a.vt);
-        e = State{c.RES, 0.0, 0.0, 0.0, 0.0}; // wn_vec(n,RES), others 0, read at [n-1] (:1633-1648)
-        day_step(c, day_const(d0), day_prefetch(c, tc0), sw0, tc0, rain0, snf0, e, o);
-        // sum(initial_AI$pet, na.rm = T) / sum(Pinit, na.rm = T), R/splash.point.R:150
-        pet_sum = (o.pet == o.pet) ? o.pet : 0.0;
-        p_sum = (rain0 + snf0 == rain0 + snf0) ? rain0 + snf0 : 0.0;
     } else {
         const int m = a.meta[ci];
         stage = m >> 16;
         count = m & 0xFFFF;
         cell_setup(c, a.par, a.ldp, ci, stage == 1 ? a.par[P_CELLOUT * a.ldp + ci] : a.ai[ci], a.vt);
-        e = State{a.state[ci], a.state[a.lds + ci], a.state[2 * a.lds + ci],
-                  a.state[3 * a.lds + ci], a.state[4 * a.lds + ci]};
     }
+    // The job's start-of-pass state (the state after day 1 of the current pass) is only needed
+    // when a pass ends: it waits in LDS, like the checkpoint of the cycle detector below, so that
+    // the day loop has the registers to itself (CellConst alone is 45 doubles).
+    __shared__ double s_e[5][kBlock];
+    __shared__ double s_chk[5][kBlock];
+    __shared__ int s_chk_count[kBlock];
+    s_chk_count[threadIdx.x] = -1;
+    // day 1 of the year is evaluated at the end of every pass (the closing step, :1674 == day 1 of
+    // the next pass): from the cache when there is one, from the forcing otherwise
+    auto day_one = [&](State& st_, DayOut& o_, double* p_day) {
+        DayRecord r;
+        if (CACHED && cached && p_day == nullptr) {
+            r = rec_load(a.cache, a.cache_cap, 0, sl);
+        } else {
+            double sw0, tc0, pn0;
+            f.raw(0, sw0, tc0, pn0);
+            f.split(d0, 0, tc0, pn0, r.rain, r.snf);
+            day_terms(c, day_const(d0), day_prefetch(c, tc0), sw0, tc0, r.T);
+            terms_fence(r.T);
+            if (CACHED && cached) rec_store(a.cache, a.cache_cap, 0, sl, r);
+        }
+        if (p_day) *p_day = r.rain + r.snf;
+        day_update(c, r.T, r.rain, r.snf, st_, o_);
+    };
+    State cur;
+    double e_wn;
+    if (a.fresh) {
+        cur = State{c.RES, 0.0, 0.0, 0.0, 0.0}; // wn_vec(n,RES), others 0, read at [n-1] (:1633-1648)
+        double p0;
+        day_one(cur, o, &p0);
+        // sum(initial_AI$pet, na.rm = T) / sum(Pinit, na.rm = T), R/splash.point.R:150
+        pet_sum = (o.pet == o.pet) ? o.pet : 0.0;
+        p_sum = (p0 == p0) ? p0 : 0.0;
+    } else {
+        cur = State{a.state[ci], a.state[a.lds + ci], a.state[2 * a.lds + ci],
+                    a.state[3 * a.lds + ci], a.state[4 * a.lds + ci]};
+        if (CACHED && cached) { // fill day 1's record (the closing steps of this launch read it)
+            State tmp = cur;
+            double p0;
+            day_one(tmp, o, &p0);
+        }
+    }
+    auto park_e = [&](const State& st_) {
+        s_e[0][threadIdx.x] = st_.wn;
+        s_e[1][threadIdx.x] = st_.snow;
+        s_e[2][threadIdx.x] = st_.qin;
+        s_e[3][threadIdx.x] = st_.td;
+        s_e[4][threadIdx.x] = st_.nd;
+    };
+    park_e(cur);
+    e_wn = cur.wn;
     // Exact-cycle detection (Brent): the day-1 state of a pass determines everything after it, so
     // if it ever repeats bit for bit (period lam), the passes up to the 1000-pass cap
     // (src/SPLASH.cpp:1697) only go round that cycle -- the stopping rule cannot fire inside it, or
@@ -242,36 +322,47 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     // an exact 2- or 3-cycle after a few dozen passes.  The checkpoint lives in LDS (one compare
     // per pass); it restarts with every phase, moving to the current state whenever the number of
     // passes since the phase began is a power of two.
-    __shared__ double s_chk[5][kBlock];
-    __shared__ int s_chk_count[kBlock];
-    s_chk_count[threadIdx.x] = -1;
     bool done = !valid;
     for (int it = 0; it < a.budget; it++) {
         const bool acc = a.fresh && it == 0; // first pass of spin-up #1 (uniform)
-        State cur = e;
-        double swv, tcv, pnv;
-        f.raw(1, swv, tcv, pnv);
-        for (int i = 1; i < a.n; i++) {
-            const DayPre pre = day_prefetch(c, tcv);
-            double swn = swv, tcn = tcv, pnn = pnv;
-            if (i + 1 < a.n) f.raw(i + 1, swn, tcn, pnn);
-            const DayRec d = day_rec(days, i);
-            double rain, snf;
-            f.split(d, i, tcv, pnv, rain, snf);
-            day_step(c, day_const(d), pre, swv, tcv, rain, snf, cur, o);
-            if (acc) { // pet_vec is only filled in the first pass (:1667), Pinit = rain + snow
-                const double pday = rain + snf;
-                pet_sum += (o.pet == o.pet) ? o.pet : 0.0; // na.rm = T
-                p_sum += (pday == pday) ? pday : 0.0;
+        // cur = state after day 1 of this pass (== the parked start-of-pass state)
+        if (CACHED && cached && it > 0) {
+            // read-back pass: next day's record is requested a day ahead
+            DayRecord r = rec_load(a.cache, a.cache_cap, 1, sl);
+            for (int i = 1; i < a.n; i++) {
+                DayRecord rn = r;
+                if (i + 1 < a.n) rn = rec_load(a.cache, a.cache_cap, i + 1, sl);
+                day_update(c, r.T, r.rain, r.snf, cur, o);
+                r = rn;
             }
-            swv = swn;
-            tcv = tcn;
-            pnv = pnn;
+        } else {
+            double swv, tcv, pnv;
+            f.raw(1, swv, tcv, pnv);
+            for (int i = 1; i < a.n; i++) {
+                const DayPre pre = day_prefetch(c, tcv);
+                double swn = swv, tcn = tcv, pnn = pnv;
+                if (i + 1 < a.n) f.raw(i + 1, swn, tcn, pnn);
+                const DayRec d = day_rec(days, i);
+                DayRecord r;
+                f.split(d, i, tcv, pnv, r.rain, r.snf);
+                day_terms(c, day_const(d), pre, swv, tcv, r.T);
+                terms_fence(r.T);
+                if (CACHED && cached) rec_store(a.cache, a.cache_cap, i, sl, r);
+                day_update(c, r.T, r.rain, r.snf, cur, o);
+                if (acc) { // pet_vec is only filled in the first pass (:1667), Pinit = rain + snow
+                    const double pday = r.rain + r.snf;
+                    pet_sum += (o.pet == o.pet) ? o.pet : 0.0; // na.rm = T
+                    p_sum += (pday == pday) ? pday : 0.0;
+                }
+                swv = swn;
+                tcv = tcn;
+                pnv = pnn;
+            }
         }
         State nxt = cur; // the closing day-1 step (:1674/:1729) == day 1 of the next pass
-        day_step(c, day_const(d0), day_prefetch(c, tc0), sw0, tc0, rain0, snf0, nxt, o);
-        double diff_sm = nxt.wn - e.wn; // end_sm - start_sm, :1678-1688
-        if (diff_sm < 0) diff_sm = e.wn - nxt.wn;
+        day_one(nxt, o, nullptr);
+        double diff_sm = nxt.wn - e_wn; // end_sm - start_sm, :1678-1688
+        if (diff_sm < 0) diff_sm = e_wn - nxt.wn;
         if (!done) {
             if (acc) a.ai[ci] = pet_sum / p_sum; // R/splash.point.R:150
             // :1697.  Spin-up #1 only feeds the aridity index, and that uses the PET of its first
@@ -280,35 +371,39 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             // count is asked for, it stops after that pass.
             const bool cont = (diff_sm > 1.0) && (count < 1000) && (stage == 2 || a.passes);
             if (cont) {
-                e = nxt;
                 count++;
                 const int cc = s_chk_count[threadIdx.x];
-                const bool same = cc >= 0 && same_bits(e.wn, s_chk[0][threadIdx.x]) &&
-                                  same_bits(e.snow, s_chk[1][threadIdx.x]) &&
-                                  same_bits(e.qin, s_chk[2][threadIdx.x]) &&
-                                  same_bits(e.td, s_chk[3][threadIdx.x]) &&
-                                  same_bits(e.nd, s_chk[4][threadIdx.x]);
+                const bool same = cc >= 0 && same_bits(nxt.wn, s_chk[0][threadIdx.x]) &&
+                                  same_bits(nxt.snow, s_chk[1][threadIdx.x]) &&
+                                  same_bits(nxt.qin, s_chk[2][threadIdx.x]) &&
+                                  same_bits(nxt.td, s_chk[3][threadIdx.x]) &&
+                                  same_bits(nxt.nd, s_chk[4][threadIdx.x]);
                 if (same) {
                     count = 1000 - ((1000 - count) % (count - cc));
                     s_chk_count[threadIdx.x] = -1; // the remaining < lam passes run plainly
                 } else if (((it + 1) & it) == 0) { // it + 1 = passes in this phase: 1, 2, 4, 8, ...
-                    s_chk[0][threadIdx.x] = e.wn;
-                    s_chk[1][threadIdx.x] = e.snow;
-                    s_chk[2][threadIdx.x] = e.qin;
-                    s_chk[3][threadIdx.x] = e.td;
-                    s_chk[4][threadIdx.x] = e.nd;
+                    s_chk[0][threadIdx.x] = nxt.wn;
+                    s_chk[1][threadIdx.x] = nxt.snow;
+                    s_chk[2][threadIdx.x] = nxt.qin;
+                    s_chk[3][threadIdx.x] = nxt.td;
+                    s_chk[4][threadIdx.x] = nxt.nd;
                     s_chk_count[threadIdx.x] = count;
                 }
+                cur = nxt;
+                park_e(cur);
+                e_wn = cur.wn;
             } else if (stage == 1) {
                 if (a.passes) a.passes[ci] = count;
                 const double AI = a.ai[ci];
                 a.par[P_CELLOUT * a.ldp + ci] = AI; // soil_info[12] <- AI (1-based): ncellout
-                cell_setup(c, a.par, a.ldp, ci, AI, a.vt);
+                cell_setup(c, a.par, a.ldp, ci, AI, a.vt); // (the day terms do not depend on cellout)
                 stage = 2;
                 count = 1;
                 s_chk_count[threadIdx.x] = -1;
-                e = State{c.RES, 0.0, 0.0, 0.0, 0.0};
-                day_step(c, day_const(d0), day_prefetch(c, tc0), sw0, tc0, rain0, snf0, e, o);
+                cur = State{c.RES, 0.0, 0.0, 0.0, 0.0};
+                day_one(cur, o, nullptr);
+                park_e(cur);
+                e_wn = cur.wn;
             } else {
                 a.state[ci] = cur.wn; // initial$sm[365] etc., R/splash.point.R:164-172
                 a.state[a.lds + ci] = cur.snow;
@@ -318,15 +413,17 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 if (a.passes) a.passes[a.ncell + ci] = count;
                 done = true;
             }
+        } else {
+            cur = nxt; // finished lanes just keep stepping (their results are already stored)
         }
         if (__all(done)) break;
     }
-    if (!done) { // park the job and queue the cell for the next phase
-        a.state[ci] = e.wn;
-        a.state[a.lds + ci] = e.snow;
-        a.state[2 * a.lds + ci] = e.qin;
-        a.state[3 * a.lds + ci] = e.td;
-        a.state[4 * a.lds + ci] = e.nd;
+    if (!done) { // park the job (its start-of-pass state) and queue the cell for the next phase
+        a.state[ci] = s_e[0][threadIdx.x];
+        a.state[a.lds + ci] = s_e[1][threadIdx.x];
+        a.state[2 * a.lds + ci] = s_e[2][threadIdx.x];
+        a.state[3 * a.lds + ci] = s_e[3][threadIdx.x];
+        a.state[4 * a.lds + ci] = s_e[4][threadIdx.x];
         a.meta[ci] = (stage << 16) | count;
         const uint32_t k = atomicAdd(a.n_out, 1u);
         a.wl_out[k] = (uint32_t)ci;
@@ -1059,7 +1156,10 @@ hipError_t launch_snow_threshold(size_t ncell, int nt, const double* tc, size_t 
 hipError_t launch_spin_phase(const SpinPhaseArgs& a, hipStream_t s)
 {
     if (a.ncell == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_spin_phase, dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
+    if (a.cache)
+        hipLaunchKernelGGL(k_spin_phase<true>, dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_spin_phase<false>, dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1136,6 +1236,7 @@ hipError_t launch_diag_finalize(const long long* acc, int n_rec, double* diag, d
     return hipGetLastError();
 }
 
+size_t spin_cache_bytes_per_slot() { return (size_t)365 * kNRec * sizeof(double); }
 size_t visc_table_floats_r() { return (size_t)kViscNR * 8; }
 size_t visc_table_floats_t() { return (size_t)kViscNT * 2; }
 hipError_t launch_visc_tables(float* rtab, float* ttab, hipStream_t s)
@@ -1228,6 +1329,146 @@ hipError_t launch_synth_forcing(uint64_t seed, const DayRec* days, int t0, int n
     unsigned gy = nt < 64 ? (unsigned)nt : 64u;
     hipLaunchKernelGGL(k_synth_forcing, dim3(nblk(ncell, kBlock), gy), dim3(kBlock), 0, s, seed,
                        days, t0, nt, cell0, ncell, lat, elev, sw_in, tc, pn, ldf);
+    return hipGetLastError();
+}
+
+// ================================================================ static rasters
+// What splash.grid derives from the elevation raster before the loop (R/splash.grid.R:96-110,
+// R/upslope_area.R:31-33, 140-165) on a north-up longitude/latitude grid, row-major, NaN = NA:
+//   slope, aspect   Horn (1981) 3x3 finite differences as raster::terrain(opt=c('slope','aspect'),
+//                   unit='degrees', neighbors=8) defines them: cell spacing in metres from the
+//                   row's latitude on a sphere of radius 6378137 m, aspect clockwise from north, flat
+//                   cells 90 degrees, NA where a neighbour is missing -- which R/splash.grid.R:107
+//                   then turns into 0 for cells that have an elevation (applied here when
+//                   na_to_zero is set)
+//   lat             cell-centre latitude (R/splash.grid.R:101-103)
+//   resolution      sqrt(cell area) in metres (:98: sqrt(raster::area(elev))*1000)
+//   flowdir         D8 code of the steepest descent among the 8 neighbours as raster::terrain(opt=
+//                   'flowdir') encodes it (1 E, 2 SE, 4 S, 8 SW, 16 W, 32 NW, 64 N, 128 NE; the
+//                   smallest rise when every neighbour is higher; ties: first in that order,
+//                   where raster draws at random)
+// One lane per cell; the 3x3 neighbourhood is read straight from global memory (each row is read
+// by three consecutive workgroup rows: L2 hits), 8 B in + up to 40 B out per cell: HBM bound.
+// The arithmetic of raster::terrain / raster::area lives in a package that is not vendored in the
+// reference: this restates the published algorithm, parity unpinned.
+__global__ __launch_bounds__(kBlock) void k_terrain(int H, int W, const double* __restrict__ elev,
+                                                   double ymax, double yres, double xres,
+                                                   int na_to_zero, double* __restrict__ slope,
+                                                   double* __restrict__ aspect,
+                                                   double* __restrict__ lat_o,
+                                                   double* __restrict__ res_o,
+                                                   double* __restrict__ flowdir)
+{
+    const size_t n = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int r = (int)(i / W), cidx = (int)(i % W);
+    const double Rearth = 6378137.0;
+    const double lat = ymax - ((double)r + 0.5) * yres;
+    const double dy = Rearth * (yres * kPir);
+    const double dx = Rearth * cos(lat * kPir) * (xres * kPir);
+    const double z = elev[i];
+    if (lat_o) lat_o[i] = (z == z) ? lat : __builtin_nan("");
+    if (res_o) res_o[i] = (z == z) ? sqrt(dx * dy) : __builtin_nan("");
+    const bool inner = r > 0 && r < H - 1 && cidx > 0 && cidx < W - 1;
+    double sl = __builtin_nan(""), as = __builtin_nan(""), fd = __builtin_nan("");
+    if (inner && z == z) {
+        const double a = elev[i - W - 1], b = elev[i - W], c = elev[i - W + 1];
+        const double d = elev[i - 1], f = elev[i + 1];
+        const double g = elev[i + W - 1], h = elev[i + W], k = elev[i + W + 1];
+        const double sum8 = a + b + c + d + f + g + h + k; // NaN if any neighbour is NA
+        if (sum8 == sum8) {
+            const double zx = ((c + 2.0 * f + k) - (a + 2.0 * d + g)) / (8.0 * dx); // eastward
+            const double zy = ((a + 2.0 * b + c) - (g + 2.0 * h + k)) / (8.0 * dy); // northward
+            sl = atan(sqrt(zx * zx + zy * zy)) / kPir;
+            if (zx == 0.0 && zy == 0.0) {
+                as = 90.0;
+            } else {
+                as = atan2(-zx, -zy) / kPir; // azimuth of the downslope direction
+                if (as < 0.0) as += 360.0;
+            }
+        }
+        // D8: largest drop per unit distance (diagonals are sqrt(dx^2+dy^2) away)
+        const double dd = sqrt(dx * dx + dy * dy);
+        const double nb[8] = {f, k, h, g, d, a, b, c};             // E SE S SW W NW N NE
+        const double dist[8] = {dx, dd, dy, dd, dx, dd, dy, dd};
+        double best = -__builtin_inf();
+        int code = 0;
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (nb[q] == nb[q]) {
+                const double drop = (z - nb[q]) / dist[q];
+                if (drop > best) {
+                    best = drop;
+                    code = 1 << q;
+                }
+                any = true;
+            }
+        }
+        if (any) fd = (double)code;
+    }
+    if (na_to_zero && z == z) { // terraines[is.na(terraines) & !is.na(elev)] <- 0, R/splash.grid.R:107
+        if (sl != sl) sl = 0.0;
+        if (as != as) as = 0.0;
+    }
+    if (slope) slope[i] = sl;
+    if (aspect) aspect[i] = as;
+    if (flowdir) flowdir[i] = fd;
+}
+
+// ncellflow (R/upslope_area.R:140-165): how many of a cell's 3x3 neighbourhood carry the flow code
+// given for their window position (codes[9], window in row order: the matrix(c(2,1,128,4,0,64,8,16,
+// 32), nrow=3) of 'in'/'top', its reverse for 'out').  NA when the whole window is NA; positions
+// that are NA do not count; a count of 0 becomes 1 (:157).  Edge cells see NA outside the grid
+// (pad = 1, focal(pad=TRUE)) or are NA themselves (pad = 0: raster::focal's default).
+__global__ __launch_bounds__(kBlock) void k_ncellflow(int H, int W, const double* __restrict__ fd,
+                                                     const double* __restrict__ codes, int pad,
+                                                     double* __restrict__ out)
+{
+    const size_t n = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int r = (int)(i / W), c = (int)(i % W);
+    const bool edge = r == 0 || r == H - 1 || c == 0 || c == W - 1;
+    if (edge && !pad) {
+        out[i] = __builtin_nan("");
+        return;
+    }
+    int nna = 0, nmatch = 0;
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        const int rr = r + q / 3 - 1, cc = c + q % 3 - 1;
+        double v = __builtin_nan("");
+        if (rr >= 0 && rr < H && cc >= 0 && cc < W) v = fd[(size_t)rr * W + cc];
+        if (v != v) {
+            nna++;
+        } else if (v == codes[q]) {
+            nmatch++;
+        }
+    }
+    double res = (double)(nmatch == 0 ? 1 : nmatch);
+    if (nna == 9) res = __builtin_nan("");
+    out[i] = res;
+}
+
+hipError_t launch_terrain(int H, int W, const double* elev, double ymax, double yres, double xres,
+                          int na_to_zero, double* slope, double* aspect, double* lat, double* res,
+                          double* flowdir, hipStream_t s)
+{
+    const size_t n = (size_t)H * W;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_terrain, dim3(nblk(n, kBlock)), dim3(kBlock), 0, s, H, W, elev, ymax, yres,
+                       xres, na_to_zero, slope, aspect, lat, res, flowdir);
+    return hipGetLastError();
+}
+
+hipError_t launch_ncellflow(int H, int W, const double* fd, const double* codes, int pad,
+                            double* out, hipStream_t s)
+{
+    const size_t n = (size_t)H * W;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ncellflow, dim3(nblk(n, kBlock)), dim3(kBlock), 0, s, H, W, fd, codes, pad, out);
     return hipGetLastError();
 }
 

@@ -71,7 +71,10 @@ struct SpinPhaseArgs {
     int budget;             // passes per job in this phase
     int fresh;              // phase 0
     ViscTables vt;
+    double* cache;          // last phase: [365][19][cache_cap] records of the day terms, or NULL
+    size_t cache_cap;       // jobs (worklist positions) the cache has room for
 };
+size_t spin_cache_bytes_per_slot();
 
 struct RunArgs {
     const DayRec* days; // day t0 onwards
@@ -112,6 +115,11 @@ hipError_t launch_run_all(const RunArgs& a, hipStream_t s);
 hipError_t launch_run_all_mod(const RunArgs& a, hipStream_t s);
 hipError_t launch_diag_finalize(const long long* acc, int n_rec, double* diag, double* counts,
                                 hipStream_t s);
+hipError_t launch_terrain(int H, int W, const double* elev, double ymax, double yres, double xres,
+                          int na_to_zero, double* slope, double* aspect, double* lat, double* res,
+                          double* flowdir, hipStream_t s);
+hipError_t launch_ncellflow(int H, int W, const double* fd, const double* codes, int pad,
+                            double* out, hipStream_t s);
 hipError_t launch_widen_f32(const float* src, size_t n, double* dst, hipStream_t s);
 hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, const double* sw,
                              const double* dr, const double* sd, const double* cd,

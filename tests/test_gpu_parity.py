@@ -1051,3 +1051,30 @@ def test_bench_line_keeps_the_contract():
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0
     assert d["value"] > 0 and abs(d["value"] - 64 * 64 * 365 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+
+
+# ---------------------------------------------------------------- static rasters
+def test_terrain_and_ncellflow_vs_oracle(api, oracle):
+    """slope/aspect (Horn), latitude, resolution, D8 flow direction and ncellflow
+    (R/splash.grid.R:96-110, R/upslope_area.R:31-33, 140-165) on a rough lon/lat DEM with NA
+    patches, against the oracle's restatement (published algorithms: parity unpinned)."""
+    rng = np.random.default_rng(12)
+    H, W = 301, 517
+    y, x = np.mgrid[0:H, 0:W]
+    z = 800 + 600 * np.sin(x / 37.0) * np.cos(y / 23.0) + 40 * rng.standard_normal((H, W))
+    z[rng.random((H, W)) < 0.03] = np.nan
+    z[100:140, 200:260] = np.nan            # a lake of NA
+    z[180:200, 300:330] = 500.0             # a plateau: flat cells (aspect 90, ties in the D8 choice)
+    for na0 in (True, False):
+        g = api.terrain(z, 47.5, 0.01, 0.0125, na_to_zero=na0)
+        o = oracle.terrain(z, 47.5, 0.01, 0.0125, na_to_zero=na0)
+        for k in ("flowdir", "ncellin", "ncellout"):
+            assert np.array_equal(g[k], o[k], equal_nan=True), k
+        for k in ("lat", "resolution"):  # (device cos / fused multiply-add: an ulp)
+            assert np.allclose(g[k], o[k], rtol=1e-14, atol=0, equal_nan=True), k
+        for k in ("slope", "aspect"):
+            assert np.array_equal(np.isnan(g[k]), np.isnan(o[k])), k
+            m = ~np.isnan(o[k])
+            assert np.allclose(g[k][m], o[k][m], rtol=1e-12, atol=1e-10), k
+    assert (g["aspect"][185:195, 305:325] == 90.0).all() and (g["slope"][185:195, 305:325] == 0).all()
+    assert np.isnan(g["slope"][0]).all() and 0 < np.nanmax(g["slope"]) < 60

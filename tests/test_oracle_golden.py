@@ -283,3 +283,50 @@ def test_minigrid_golden_is_reproduced_by_the_oracle(oracle, minigrid):
     for k, v in res.items():
         assert np.array_equal(v, g[k]), k
     assert np.array_equal(aux["passes2"], g["passes2"]) and np.array_equal(aux["AI"], g["AI"])
+
+
+def test_terrain_and_ncellflow_hand_cases(oracle):
+    """static rasters: hand-computable cases of the restated algorithms.
+    An inclined plane has the slope and aspect of its gradient everywhere inside; ncellflow counts
+    the neighbours whose flow code points at the centre (R/upslope_area.R:140-165)."""
+    H, W = 7, 9
+    yres = xres = 0.01
+    ymax = 0.0 + H * yres / 2  # rows around the equator: dx ~ dy
+    R = 6378137.0
+    dy = R * np.radians(yres)
+    rows, cols = np.mgrid[0:H, 0:W]
+    # plane rising 1 m per cell towards the east: downslope faces west (270), slope atan(1/dx)
+    t = oracle.terrain(cols.astype(float), ymax, yres, xres, na_to_zero=False)
+    lat_c = ymax - (rows[:, 0] + 0.5) * yres
+    dx = R * np.cos(np.radians(lat_c)) * np.radians(xres)
+    inner = (slice(1, -1), slice(1, -1))
+    assert np.allclose(t["aspect"][inner], 270.0)
+    assert np.allclose(t["slope"][inner], np.degrees(np.arctan(1.0 / dx[1:-1]))[:, None], rtol=1e-12)
+    assert np.isnan(t["slope"][0]).all() and np.isnan(t["aspect"][:, 0]).all()   # outer ring NA
+    assert np.allclose(t["lat"][:, 0], lat_c) and np.allclose(t["resolution"][3], np.sqrt(dx[3] * dy))
+    assert (t["flowdir"][inner] == 16).all()                                      # steepest descent: west
+    # every inner cell receives from its eastern neighbour only (that one flows west = 16 ... the
+    # reference's 'in' matrix puts 64 at the window's right-hand position: no match -> 0 -> 1)
+    assert (t["ncellin"][2:-2, 2:-2] == 1).all()
+    # R/splash.grid.R:107: NA slopes of cells with an elevation become 0
+    t0 = oracle.terrain(cols.astype(float), ymax, yres, xres, na_to_zero=True)
+    assert (t0["slope"][0] == 0).all() and (t0["aspect"][:, -1] == 0).all()
+    # a pit in a plateau: all eight neighbours drain into the centre
+    z = np.full((5, 5), 10.0)
+    z[2, 2] = 0.0
+    t = oracle.terrain(z, 0.025, 0.01, 0.01, na_to_zero=False)
+    fd = t["flowdir"]
+    assert fd[1, 1] == 2 and fd[1, 2] == 4 and fd[1, 3] == 8 and fd[2, 1] == 1 and fd[2, 3] == 16
+    assert fd[3, 1] == 128 and fd[3, 2] == 64 and fd[3, 3] == 32
+    c_in = np.array([2, 4, 8, 1, 0, 16, 128, 64, 32], float)  # the geometrically meant window
+    out = np.empty((5, 5))
+    import ctypes as C
+    dp = C.POINTER(C.c_double)
+    oracle.lib.orc_ncellflow(5, 5, fd.ctypes.data_as(dp), c_in.ctypes.data_as(dp), 1, out.ctypes.data_as(dp))
+    assert out[2, 2] == 8
+    # NA handling: an all-NA window gives NA, NA positions do not count
+    fd2 = np.full((3, 3), np.nan)
+    oracle.lib.orc_ncellflow(3, 3, fd2.ctypes.data_as(dp), c_in.ctypes.data_as(dp), 1, out[:3, :3].copy().ctypes.data_as(dp))
+    o3 = np.empty((3, 3))
+    oracle.lib.orc_ncellflow(3, 3, fd2.ctypes.data_as(dp), c_in.ctypes.data_as(dp), 1, o3.ctypes.data_as(dp))
+    assert np.isnan(o3[1, 1])
