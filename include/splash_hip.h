@@ -65,6 +65,10 @@ enum {
 int splash_hip_abi_version(void);
 int splash_hip_device_count(void);            /* 0 when no device; never fails */
 const char* splash_hip_last_error(void);      /* thread-local text of the last failure */
+/* The host-buffer entry points keep their device buffers between calls (re-acquiring ~100 GB
+ * costs seconds); this returns the idle ones to the runtime.  SPLASH_HIP_NO_POOL=1 in the
+ * environment disables the retention altogether. */
+void splash_hip_release_cache(void);
 
 /* ---------------------------------------------------------------- calendar ---------------- */
 /* Per-day tables shared by all cells: orbit terms (src/SOLAR.cpp:98-124, 291-374), the month

@@ -105,7 +105,7 @@ def splash_point(sw_in, tc, pn, lat, elev, slop=0.0, asp=0.0, soil_data=None, Au
 def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=250.0,
                 time_index=None, sim_control=None, outputs=OUT_NAMES, device=0,
                 max_cells_per_launch=0, want_aux=False, want_diag=False, outdir=None, lon=None,
-                basin=None, n_basin=0, devices=None):
+                basin=None, n_basin=0, devices=None, out=None, want_state=True):
     """R/splash.grid.R:28 on arrays.  sw_in/tc/pn: [nt, ncell] (or [nt, H, W]) daily rasters;
     elev/lat/slop/asp: [ncell]; soil: [6, ncell]; Au: [3, ncell] (area, ncellin, ncellout) or
     None.  The static rasters the reference derives with raster/GDAL/TauDEM (lat, slope, aspect,
@@ -120,7 +120,9 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     on the device; the reference's rasters are FLT4S) -- the arithmetic is FP64 either way.
     basin/n_basin: optional integer basin id per cell -> want_diag totals per basin
     ([n_basin, nmonth] per quantity).  devices: list of HIP ordinals to split the cells over inside
-    the one call (one host thread per entry; the same ordinal may repeat)."""
+    the one call (one host thread per entry; the same ordinal may repeat).
+    out: dict name -> preallocated float64 array [nt_out, ...] to receive that series (what an R
+    caller's allocMatrix is); series not in `out` are allocated here."""
     if time_index is None:
         raise ValueError("time_index is required")
     monthly = True if sim_control is None else bool(sim_control.get("monthly_out", True))
@@ -161,12 +163,21 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
         gin.basin, gin.n_basin = bas.ctypes.data_as(_ip), nbas
     nm = int(month_ids(year, month)[-1]) + 1
     nt_out = nm if monthly else nt
-    res = {k: np.empty((nt_out,) + shp) for k in outputs}
+    res = {}
+    for k in outputs:
+        a = out.get(k) if out else None
+        if a is None:
+            a = np.empty((nt_out,) + shp)
+        elif a.shape != (nt_out,) + shp or a.dtype != np.float64 or not a.flags.c_contiguous:
+            raise ValueError(f"out[{k!r}] must be a C-contiguous float64 array of shape {(nt_out,) + shp}")
+        res[k] = a
     gout = _lib.GridOut()
     for i, k in enumerate(OUT_NAMES):
         gout.out[i] = res[k].ctypes.data_as(_dp) if k in res else None
-    state_end = np.empty((NSTATE,) + shp)
-    gout.state_end = state_end.ctypes.data_as(_dp)
+    state_end = None
+    if want_state:
+        state_end = np.empty((NSTATE,) + shp)
+        gout.state_end = state_end.ctypes.data_as(_dp)
     aux = diag = None
     if want_aux:
         aux = np.empty((4,) + shp)
@@ -191,7 +202,8 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
         latr = np.asarray(lat, dtype=np.float64).reshape(shp)[:, 0]
         lonv = np.arange(shp[1], dtype=np.float64) if lon is None else np.asarray(lon, dtype=np.float64)
         res["files"] = _io.write_bricks(outdir, res, lonv, latr, time_index, monthly)
-    res["state_end"] = state_end
+    if want_state:
+        res["state_end"] = state_end
     if want_aux:
         res["aux"] = dict(Tt=aux[0], AI=aux[1], passes1=aux[2], passes2=aux[3])
     if want_diag:

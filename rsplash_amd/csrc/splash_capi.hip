@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -69,15 +71,77 @@ static int need_device(char* err, size_t errlen)
 }
 
 // ------------------------------------------------------------------ per-device context
-// Lookup tables of the float viscosity routine (30 MB per device, built on first use by running the
-// routine itself for every float of its two argument ranges; never freed).
+// Lookup table of the float viscosity routine (7.5 MB per device, built on first use by running the
+// routine itself for every float of its argument range; never freed).
 #include <mutex>
 namespace {
+struct PoolSlot {
+    void* p;
+    size_t bytes;
+    bool busy;
+};
 struct DevCtx {
-    float *rtab = nullptr, *ttab = nullptr;
+    float* rtab = nullptr;
+    // Device buffers of the host-buffer entry points are kept between calls: releasing and
+    // re-acquiring ~100 GB costs 4 s per call on this runtime (measured: tools/bench_host_path.py),
+    // more than the call's computation.  splash_hip_release_cache() returns them.
+    std::vector<PoolSlot> pool;
 };
 DevCtx g_ctx[64];
 std::mutex g_ctx_mu;
+
+void pool_release_idle(DevCtx& c)
+{
+    for (auto it = c.pool.begin(); it != c.pool.end();) {
+        if (!it->busy) {
+            (void)hipFree(it->p);
+            it = c.pool.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
+hipError_t pool_alloc(void** out, size_t bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || getenv("SPLASH_HIP_NO_POOL")) return hipMalloc(out, bytes);
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    DevCtx& c = g_ctx[dev];
+    PoolSlot* best = nullptr;
+    for (auto& s : c.pool)
+        if (!s.busy && s.bytes >= bytes && s.bytes <= bytes + bytes / 4 + 4096 &&
+            (!best || s.bytes < best->bytes))
+            best = &s;
+    if (best) {
+        best->busy = true;
+        *out = best->p;
+        return hipSuccess;
+    }
+    e = hipMalloc(out, bytes);
+    if (e != hipSuccess) { // make room and try once more
+        (void)hipGetLastError();
+        pool_release_idle(c);
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess) c.pool.push_back(PoolSlot{*out, bytes, true});
+    return e;
+}
+
+void pool_free(void* p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    for (int d = 0; d < 64; d++)
+        for (auto& s : g_ctx[d].pool)
+            if (s.p == p) {
+                s.busy = false;
+                return;
+            }
+    (void)hipFree(p); // not pooled (SPLASH_HIP_NO_POOL)
+}
 
 int visc_tables(ViscTables& vt)
 {
@@ -87,25 +151,34 @@ int visc_tables(ViscTables& vt)
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     DevCtx& c = g_ctx[dev];
     if (!c.rtab) {
-        float *r = nullptr, *t = nullptr;
+        float* r = nullptr;
         hipError_t e = hipMalloc((void**)&r, visc_table_floats_r() * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&t, visc_table_floats_t() * sizeof(float));
-        if (e == hipSuccess) e = launch_visc_tables(r, t, nullptr);
+        if (e == hipSuccess) e = launch_visc_tables(r, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) {
             if (r) (void)hipFree(r);
-            if (t) (void)hipFree(t);
             return fail(e == hipErrorOutOfMemory ? SPLASH_ENOMEM : SPLASH_EHIP, nullptr, 0,
-                        "viscosity tables: %s", hipGetErrorString(e));
+                        "viscosity table: %s", hipGetErrorString(e));
         }
         c.rtab = r;
-        c.ttab = t;
     }
     vt.rtab = c.rtab;
-    vt.ttab = c.ttab;
     return SPLASH_OK;
 }
 } // namespace
+
+extern "C" void splash_hip_release_cache(void)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < 64; d++) {
+        if (g_ctx[d].pool.empty()) continue;
+        if (hipSetDevice(d) != hipSuccess) continue;
+        pool_release_idle(g_ctx[d]);
+    }
+    (void)hipSetDevice(cur);
+}
 
 // ------------------------------------------------------------------ calendar
 // Orbit of one calendar day: the day-static part of SOLAR::calculate_daily_fluxes
@@ -544,11 +617,8 @@ namespace {
 
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf()
-    {
-        if (p) (void)hipFree(p);
-    }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    ~DevBuf() { pool_free(p); }
+    hipError_t alloc(size_t bytes) { return pool_alloc(&p, bytes ? bytes : 8); }
     template <class T>
     T* as() const
     {
@@ -713,6 +783,7 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
     nb_max = std::min(nb_max, kMaxCellsPerLaunch);
     if (nb_max > 256) nb_max -= nb_max % 256;
 
+    const double t_w0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     DevBuf d_force, d_f32, d_out, d_par, d_state, d_stat, d_tt, d_pass, d_acc, d_swork, d_basin;
     HIP_TRY(d_force.alloc((size_t)nt * 3 * nb_max * 8), err, errlen);
     if (f32) HIP_TRY(d_f32.alloc((size_t)nt * nb_max * 4), err, errlen);
@@ -739,9 +810,16 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
         if (f32) stage32.resize((size_t)nt * nb_max);
     }
 
+    if (getenv("SPLASH_TRACE"))
+        fprintf(stderr, "[splash] device %d: calendar + allocations %.3f s\n", device,
+                std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_w0);
     hipStream_t s = nullptr;
     bool prefaulted = false;
+    // SPLASH_TRACE=1: wall-clock of the stages of every block on stderr (host-path tuning aid)
+    const bool trace = getenv("SPLASH_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (size_t b0 = v0; b0 < v1; b0 += nb_max) {
+        double t_a = now();
         const size_t nb = std::min(nb_max, v1 - b0);
         const size_t* idx = P.idx + b0; // idx[j] = grid cell of the block's j-th cell
         const size_t c0 = idx[0];       // dense: the block is cells [c0, c0+nb)
@@ -798,6 +876,7 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
                     err, errlen);
         }
 
+        double t_b = now();
         double* par = d_par.as<double>();
         double* state = d_state.as<double>();
         double* Tt = d_tt.as<double>();
@@ -830,7 +909,9 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
             prefault_outputs(out->out, SPLASH_NOUT, N, c0, v1 - b0, (size_t)nt_out);
             prefaulted = true;
         }
+        double t_c = now();
         HIP_TRY(hipStreamSynchronize(s), err, errlen);
+        double t_d = now();
 
         for (int k = 0; k < SPLASH_NOUT; k++) {
             if (!out->out[k]) continue;
@@ -864,6 +945,10 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
                 out->aux[3 * N + idx[j]] = hpass[nb + j];
             }
         }
+        if (trace)
+            fprintf(stderr, "[splash] device %d block %zu cells: host->device %.3f s, queue+prefault %.3f s, "
+                            "kernels (rest) %.3f s, device->host %.3f s\n",
+                    device, nb, t_b - t_a, t_c - t_b, t_d - t_c, now() - t_d);
     }
     if (P.want_diag)
         HIP_TRY(hipMemcpy(acc, d_acc.p, acc_bytes, hipMemcpyDeviceToHost), err, errlen);
@@ -876,6 +961,7 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
                                const splash_grid_out* out, char* err, size_t errlen)
 {
     if (!in || !out) return fail(SPLASH_EINVAL, err, errlen, "grid_run: NULL in/out");
+    const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     const bool f64 = in->sw_in && in->tc && in->pn;
     const bool f32 = !in->sw_in && !in->tc && !in->pn && in->sw_in_f32 && in->tc_f32 && in->pn_f32;
     if (!in->doy || !in->year || !in->month || !(f64 || f32) || !in->lat || !in->elev ||
@@ -962,6 +1048,7 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
     if (P.nv == 0) return SPLASH_OK;
     for (int k = 0; k < SPLASH_NOUT; k++) P.n_out += out->out[k] ? 1 : 0;
 
+    const double t_scan = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     // contiguous ranges of equal valid-cell count, one per worker (cells are independent: the
     // split changes nothing in the results, totals included -- they are exact integer sums)
     const int nw = (int)devs.size();
@@ -992,6 +1079,11 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
             for (size_t i = 0; i < total.size(); i++) total[i] += acc[w][i];
         if (out->diag_acc) std::copy(total.begin(), total.end(), out->diag_acc);
         if (out->diag) splash_diag_finalize_host(total.data(), P.n_basin, P.nmonth, out->diag, nullptr);
+    }
+    if (getenv("SPLASH_TRACE")) {
+        const double t_end = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        fprintf(stderr, "[splash] grid_run: NA scan %.3f s, workers %.3f s, total %.3f s\n", t_scan - t_enter,
+                t_end - t_scan, t_end - t_enter);
     }
     return SPLASH_OK;
 }

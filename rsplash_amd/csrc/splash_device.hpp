@@ -286,18 +286,20 @@ __device__ __forceinline__ void pow_int_cr(double x, double& p2, double& p3, dou
 //   visc_tbar_part(tbar)  -> mu0, ctbar            (:416-424, :439)   tbar = (float)((tw+273.15)/647.096)
 //   visc_rbar_part(rbar)  -> coef2[0..5]           (:441-448)         rbar = rho/322
 //   visc_combine(...)     -> mu                    (:443, :449-459)
-// A float has few values in the range these arguments can take (2.9e6 and 2.4e5 for water between
-// 0 and 60 degC), so the first two are TABULATED once per device by running exactly this code for
-// every float of the range (k_visc_tables): the day loop then replaces ~250 instructions by two
-// gathers, and the result is the same bits by construction.  Outside the tables' range, and in the
-// (rare) cases where a cheaper evaluation of an argument cannot be proved to round to the same
-// float, the whole routine is evaluated directly (viscosity_h2o).
-// (struct ViscTables { rtab [NR][8]: coef2[0..5] + 2 padding; ttab [NT][2]: mu0, ctbar } is
-// declared in splash_kernels.hpp; index = bits(argument) - first)
+// A float has few values in the range rbar can take (2.3e5 for water between 0 and 60 degC), so
+// visc_rbar_part -- 21 float-rounded accumulations over correctly rounded integer powers -- is
+// TABULATED once per device by running exactly this code for every float of the range
+// (k_visc_tables, 7.5 MB): the day loop replaces ~130 instructions by one 32-byte gather, and the
+// result is the same bits by construction.  visc_tbar_part has a cheaper evaluation whose
+// roundings to float are each checked (visc_tbar_part_fast; a table of it would be 23 MB and miss
+// the L2: measured, 1 % faster in run_all, 6 % slower in the latency-bound spin-up tail, and
+// 29 GB of extra fabric traffic per launch).  Outside the table's range, and in the (rare) cases
+// where a cheaper evaluation cannot be proved to round to the same float, the whole routine is
+// evaluated directly (viscosity_h2o).
+// (struct ViscTables { rtab [NR][8]: coef2[0..5] + 2 padding } is declared in splash_kernels.hpp;
+// index = bits(rbar) - kViscR0)
 constexpr uint32_t kViscR0 = 0x40436000u; // rbar = 3.05273...  (rho = 982.98: water at ~60.5 degC)
 constexpr uint32_t kViscNR = 0x00039000u; // up to rbar = 3.10840 (rho = 1000.9)
-constexpr uint32_t kViscT0 = 0x3ed81c00u; // tbar = 0.422089   (tw = -0.018 degC; tw = 0 is 0x3ed81fac)
-constexpr uint32_t kViscNT = 0x002bc400u; // up to tbar = 0.51514 (tw = 60.2 degC)
 
 __device__ __forceinline__ void visc_tbar_part(float tbar, float& mu0_out, float& ctbar_out)
 {
@@ -396,6 +398,26 @@ __device__ __forceinline__ float to_float_checked(double v, bool& risky)
     return (float)v;
 }
 
+// visc_tbar_part() with reciprocal-based quotients and a fast square root, every rounding to float
+// checked (to_float_checked): ~60 instructions instead of three IEEE divisions, a correctly
+// rounded square root and two more divisions -- or instead of a 23 MB table whose gathers miss L2.
+__device__ __forceinline__ void visc_tbar_part_fast(float tbar, float& mu0_out, float& ctbar_out,
+                                                    bool& risky)
+{
+#pragma clang fp contract(off)
+    const float tbar2 = tbar * tbar;                                   // :418
+    const float tbar3 = tbar * tbar * tbar;                            // :419
+    const double t1 = (double)tbar, t2 = (double)tbar2, t3 = (double)tbar3;
+    // 1/t1, 1/t2, 1/t3 from one reciprocal of the product (all three ~0.1 .. 0.5)
+    const double r = frcp(t1 * t2 * t3);
+    const double i1 = r * (t2 * t3), i2 = r * (t1 * t3), i3 = r * (t1 * t2);
+    const float den = to_float_checked(1.67752 + 2.20462 * i1 + 0.6366564 * i2 - 0.241605 * i3, risky);
+    const float tbarx = to_float_checked(fsqrt(t1), risky);            // :417
+    mu0_out = to_float_checked(1e2 * (double)tbarx * frcp((double)den), risky); // :424
+    // :439: 1/tbar - 1 is ~1.0..1.4; the subtraction is exact enough (error of i1 is 2e-16 * 2.4)
+    ctbar_out = to_float_checked(i1 - 1.0, risky);
+}
+
 // The temperature-only part of a cell-day that needs memory: water density (double path) and the
 // table entries of the float viscosity.  It is evaluated at the TOP of the day, before the next
 // day's forcing is requested, so that the two gathers (L2 / Infinity-Cache hits, ~1 us) are in
@@ -404,7 +426,7 @@ __device__ __forceinline__ float to_float_checked(double v, bool& risky)
 struct DayPre {
     double pw;          // density_h2o(tc, patm), src/EVAP.cpp:113
     float c[6];         // coef2[0..5] of the viscosity (table)
-    float mu0, ctbar;   // (table)
+    float mu0, ctbar;
     float rbar;
     int mode;           // 0: tc < 0 (viscosity at tw = 0 is a cell constant)  1: tables  2: direct
 };
@@ -434,17 +456,15 @@ __device__ __forceinline__ DayPre day_prefetch(const CellConst& c, double tc)
         const float rho = to_float_checked(num * frcp(num - pbar) * dq.po1000, risky);
         const float rbar = to_float_checked((double)rho * (1.0 / 322.0), risky);          // :420
         const float tbar = to_float_checked(((double)tcf + 273.15) * (1.0 / 647.09600830078125), risky); // :416
-        const uint32_t ir = __float_as_uint(rbar) - kViscR0, it = __float_as_uint(tbar) - kViscT0;
-        risky |= (ir >= kViscNR) | (it >= kViscNT);
+        const uint32_t ir = __float_as_uint(rbar) - kViscR0;
+        risky |= (ir >= kViscNR);
+        visc_tbar_part_fast(tbar, q.mu0, q.ctbar, risky);
         q.mode = risky ? 2 : 1;
         q.rbar = rbar;
         if (!risky) {
             const float4 a = *reinterpret_cast<const float4*>(c.vt.rtab + (size_t)ir * 8);
             const float2 b = *reinterpret_cast<const float2*>(c.vt.rtab + (size_t)ir * 8 + 4);
-            const float2 t = *reinterpret_cast<const float2*>(c.vt.ttab + (size_t)it * 2);
             q.c[0] = a.x; q.c[1] = a.y; q.c[2] = a.z; q.c[3] = a.w; q.c[4] = b.x; q.c[5] = b.y;
-            q.mu0 = t.x;
-            q.ctbar = t.y;
         }
     }
 #endif
@@ -487,7 +507,7 @@ __device__ __forceinline__ double specific_heat(double tc)
 // between the two spin-ups (R/splash.point.R:150).  Runs once per kernel per cell, so it uses
 // the library pow/exp/log throughout.
 __device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, size_t ld,
-                                  size_t cell, double cellout, ViscTables vt = ViscTables{nullptr, nullptr})
+                                  size_t cell, double cellout, ViscTables vt = ViscTables{nullptr})
 {
     c.vt = vt;
     const double lat = par[P_LAT * ld + cell], elv = par[P_ELV * ld + cell];

@@ -877,9 +877,8 @@ __global__ __launch_bounds__(kBlock) void k_unswc(size_t ncell, int nt,
 }
 
 // ================================================================ viscosity tables ============
-// every float of the two argument ranges through the routine's own code (splash_device.hpp)
-__global__ __launch_bounds__(kBlock) void k_visc_tables(float* __restrict__ rtab,
-                                                       float* __restrict__ ttab)
+// every float of the argument range through the routine's own code (splash_device.hpp)
+__global__ __launch_bounds__(kBlock) void k_visc_tables(float* __restrict__ rtab)
 {
     lds_tables_init();
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -890,12 +889,6 @@ __global__ __launch_bounds__(kBlock) void k_visc_tables(float* __restrict__ rtab
 #pragma unroll
         for (int k = 0; k < 6; k++) o[k] = c[k];
         o[6] = o[7] = 0.0f;
-    }
-    if (i < kViscNT) {
-        float mu0, ctbar;
-        visc_tbar_part(__uint_as_float(kViscT0 + i), mu0, ctbar);
-        ttab[(size_t)i * 2] = mu0;
-        ttab[(size_t)i * 2 + 1] = ctbar;
     }
 }
 
@@ -1238,11 +1231,9 @@ hipError_t launch_diag_finalize(const long long* acc, int n_rec, double* diag, d
 
 size_t spin_cache_bytes_per_slot() { return (size_t)365 * kNRec * sizeof(double); }
 size_t visc_table_floats_r() { return (size_t)kViscNR * 8; }
-size_t visc_table_floats_t() { return (size_t)kViscNT * 2; }
-hipError_t launch_visc_tables(float* rtab, float* ttab, hipStream_t s)
+hipError_t launch_visc_tables(float* rtab, hipStream_t s)
 {
-    const uint32_t nmax = kViscNR > kViscNT ? kViscNR : kViscNT;
-    hipLaunchKernelGGL(k_visc_tables, dim3(nblk(nmax, kBlock)), dim3(kBlock), 0, s, rtab, ttab);
+    hipLaunchKernelGGL(k_visc_tables, dim3(nblk(kViscNR, kBlock)), dim3(kBlock), 0, s, rtab);
     return hipGetLastError();
 }
 

@@ -26,14 +26,12 @@ struct DayRec {
     int doy;             // day of year (synthetic generator)
 };
 
-// per-device lookup tables of the float viscosity routine (splash_device.hpp, k_visc_tables)
+// per-device lookup table of the float viscosity routine (splash_device.hpp, k_visc_tables)
 struct ViscTables {
     const float* rtab; // [kViscNR][8]: coef2[0..5], 2 x padding   (index: bits(rbar) - kViscR0)
-    const float* ttab; // [kViscNT][2]: mu0, ctbar                  (index: bits(tbar) - kViscT0)
 };
 size_t visc_table_floats_r();
-size_t visc_table_floats_t();
-hipError_t launch_visc_tables(float* rtab, float* ttab, hipStream_t s);
+hipError_t launch_visc_tables(float* rtab, hipStream_t s);
 
 struct SpinArgs {
     const DayRec* days; // first 365 days
