@@ -35,6 +35,7 @@ ORC = os.path.join(ROOT, "oracle", "splash_oracle.c")
 UNITS = [
     ("run_one_day", (920, 1588), "orc_run_one_day"),
     ("spin_up", (1594, 1749), "orc_spin_up"),
+    ("run_all", (1833, 1916), "run_all_strided"),
     ("moist_surf", (1921, 1961), "orc_moist_surf"),
     ("inf_GA", (1963, 2023), "orc_inf_GA"),
 ]
@@ -103,7 +104,7 @@ def norm(s, oracle):
         s = re.sub(r"\bmoist_surf\(", "orc_moist_surf(", s)
         s = re.sub(r"\binf_GA\(", "orc_inf_GA(", s)
         s = s.replace("this->", "")
-    s = s.replace("1.0e6", "1e6")
+    s = s.replace("1.0e6", "1e6").replace("*fstride", "")
     return s
 
 
@@ -117,21 +118,72 @@ def arithmetic(s):
         return False
     if m.group(1):
         return True
-    rhs = m.group(2)
+    rhs = re.sub(r"\[[^\]]*\]", "[]", m.group(2))
     return bool(re.search(r"[-+*/(]", rhs.lstrip("-")))
 
 
-# reference statements with no counterpart in the oracle, and why that is right
-DEAD = {
-    "run_one_day": {
-        r"^psi_m=|^wtd=|^z_uns=|^w_uns=|^w_z=|^if\(wtd<0\.0\|\|isnan\(wtd\)\)$|^if\(wtd>depth\)$":
-            None,  # handled positionally below (the same text is live further down)
-        r"^max_sw=": "dead local (-Wunused, SURVEY 8a A8): feeds nothing",
-        r"^AI=soil_info\[12\]": "feeds only max_sw (dead); out-of-bounds read in point mode (SURVEY trap 1)",
-        r"^To=|^T_qs=|^Acs_out_q0=|^Q_sat=|^Q_uns=": "dead locals (-Wunused, SURVEY 8a A8)",
-        r"^econ=dvap\.econ|^rn_d=dvap\.rn_d": "copies never read afterwards",
-    },
-}
+# Statements on one side only, and why that is right.  Anything not listed fails the check.
+DEAD = [  # reference only
+    (r"^(psi_m|wtd|z_uns|sat_swc|w_uns_z|w_uns_0|w_uns|w_z)=|^if\(wtd<0\.0\|\|isnan\(wtd\)\)$|^if\(wtd>depth\)$|^if\(wtd<=2\.0\)$",
+     "water held above 2 m, src/SPLASH.cpp:999-1022: computed, never used for a result (SURVEY 8a A8)"),
+    (r"^max_sw=|^AI=", "dead local (-Wunused); AI = soil_info[12] only feeds it (SURVEY trap 1)"),
+    (r"^dvap=evap\.get_vals\(\)", "member copy of the EVAP result (the oracle passes a struct)"),
+    (r"^(Acs_out_q0|psi_qs|wtd_qs|T_qs|To|To_sat|Q_uns|Q_sat)=|^To_uns\*=|^if\(wtd_qs", "dead locals "
+     "(-Wunused list of SURVEY 8a A8) and what only feeds them"),
+    (r"^Q=\(T\*Ai\)/1000$", "second evaluation after the last transmittance: never read (:1546)"),
+    (r"^theta_m=STDMAX\(Wmax/\(depth\*1000\.0\),theta_i\)$|^ro_h=STDMAX\(inflow-infi,0\.0\)$|"
+     r"^tdrain_out=STDMAX\(\(td\+t_drain\)/2,0\.0\)$|^qin_nday=STDMAX\(STDMAX\(q_in_o,q_in_f\),0\.0\)$",
+     "std::max of an expression: the oracle's macro evaluates its arguments twice, so it names them first"),
+    (r"^sm-=\(Drain_out\)$", "Drain_out = T (:1547), a plain copy"),
+    (r"^(theta_s|theta_r)=|^(start_wtd|end_wtd|diff_swe|diff_wtd)=|^if\(diff_swe<0\)|^if\(diff_wtd<0\)",
+     "spin_up: water-table and snow differences are computed but never gate the loop (:1697)"),
+    (r"^if\(i==0\)$|^(wn|snow|qin|td|nd)=\w+\[", "spin_up: previous-day bookkeeping (wrap-around read at i == 0)"),
+    (r"^(wn|swe|qin|td|nd)=\w|^\w+\[i\]=|^if\(i==0\)$|^n_end=", "run_all: series bookkeeping (first day from the *_last arguments, then the previous element); netr = rn_d/1e6 (:1907) is o[7] in the oracle"),
+]
+ORACLE_ONLY = [
+    (r"^wm_th=Wmax/\(depth\*1000\.0\)$|^theta_m=STDMAX\(wm_th,theta_i\)$|^ro_h_arg=inflow-infi$|"
+     r"^ro_h=STDMAX\(ro_h_arg,0\.0\)$|^td_arg=\(td\+t_drain\)/2$|^tdrain_out=STDMAX\(td_arg,0\.0\)$|"
+     r"^mx=STDMAX\(q_in_o,q_in_f\)$|^qin_nday=STDMAX\(mx,0\.0\)$", "named macro arguments (see above)"),
+    (r"^sm-=\(T\)$", "Drain_out = T"),
+    (r"^if\(Au>0\.0&&wtd>=depth&&", "conditioning monitors (orc_fragile_events / orc_critical_events): no effect on results"),
+    (r"^if\(dvap_out\)$|^if\((sm|snow|qin|tdrain|ro|snwage|pet)_o\)$", "optional outputs"),
+    (r"^\w+_vec=|^nb=sizeof|^p=\(i==0\)", "spin_up: one malloc'd block instead of std::vectors; previous-day index"),
+    (r"^k=\(size_t\)i\*ostride$|^if\(o\[\d+\]\)$|^if\(state_end\)$|^(wn|swe|qin|td|nd)=\w|^o\[7\]\[k\]=dv\.rn_d/1e6$", "run_all: strided outputs, optional series, the carried state; o[7] = netr_vec[i] = dvap.rn_d/1e6 (:1907)"),
+]
+
+
+def day_calls(stmts, oracle):
+    """the daily-step calls of a driver loop, arguments only, outputs and (lat, elv) removed:
+    quick_run(n, y, wn, sw_in, tc, pn, dsm, slop, asp, snow, snowfall, soil_info, qin, td, nd) <->
+    orc_run_one_day(lat, elv, n, y, wn, sw_in, tc, pn, slop, asp, snow, snowfall, soil_info, qin, td, nd, &dsm, NULL)"""
+    out = []
+    for s in stmts:
+        m = re.match(r"^(?:orc_run_one_day|quick_run|run_one_day)\((.*)\)$", s)
+        if not m:
+            continue
+        args, depth, cur = [], 0, ""
+        for ch in m.group(1):
+            if ch == "," and depth == 0:
+                args.append(cur)
+                cur = ""
+            else:
+                depth += (ch in "([") - (ch in ")]")
+                cur += ch
+        args.append(cur)
+        if oracle:
+            args = args[2:-2]
+        else:
+            args = [a for a in args if a not in ("dsm", "dsoil")]
+        out.append(",".join(x.replace("(i+1)", "i+1").replace("(i-1)", "i-1").replace("swe", "snow")
+                            for x in args))
+    return out
+
+
+def explained(stmt, table):
+    for pat, why in table:
+        if re.search(pat, stmt):
+            return why
+    return None
 
 
 def main():
@@ -149,6 +201,7 @@ def main():
         rbody = rbody[rbody.index("{") + 1:]
         rs = [norm(s, False) for s in statements(rbody)]
         os_ = [norm(s, True) for s in statements(oracle_function(orc_src, fn))]
+        rc, oc = day_calls(rs, False), day_calls(os_, True)
         rs = [s for s in rs if arithmetic(s)]
         os_ = [s for s in os_ if arithmetic(s)]
         sm = difflib.SequenceMatcher(None, rs, os_, autojunk=False)
@@ -161,11 +214,25 @@ def main():
                 only_orc += os_[j1:j2]
         report.append(f"## {unit}: src/SPLASH.cpp:{l0}-{l1} vs {fn}")
         report.append(f"arithmetic statements: reference {len(rs)}, oracle {len(os_)}, identical in order {same}")
-        report.append("only in the reference:")
-        report += ["    " + s for s in only_ref]
-        report.append("only in the oracle:")
-        report += ["    " + s for s in only_orc]
+        for title, items, table in (("only in the reference", only_ref, DEAD), ("only in the oracle", only_orc, ORACLE_ONLY)):
+            report.append(title + ":")
+            for st in items:
+                why = explained(st, table)
+                if why is None:
+                    failures += 1
+                report.append(f"    {st}\n        -> {why or 'UNEXPLAINED'}")
+        if rc or oc:
+            # the oracle reads the previous day's state into wn, snow, ... through the index p
+            same_calls = [x == y for x, y in zip(rc, oc)]
+            report.append(f"daily-step calls: reference {len(rc)}, oracle {len(oc)}, identical argument lists "
+                          f"{sum(same_calls)}")
+            for x, y in zip(rc, oc):
+                if x != y:
+                    failures += 1
+                    report.append(f"    reference ({x})\n    oracle    ({y})")
+            failures += abs(len(rc) - len(oc))
         report.append("")
+    report.append(f"unexplained differences: {failures}")
     txt = "\n".join(report)
     print(txt)
     if a.report:
