@@ -379,12 +379,11 @@ extern "C" int splash_dev_snow_threshold(size_t ncell, int nt, const double* tc,
 }
 
 // workspace of splash_dev_spin_up: two worklists, job records, aridity index, phase counters, and
-// the last phase's cache of state-independent day terms (room for 1/128 of the cells, at least
-// 4096: the cells that need more than a few dozen passes are a few per thousand)
+// the cache of state-independent day terms: 365 x 19 doubles per slot, 2^19 slots at most (29 GB).
+// Phase 0 walks the cells in blocks of that many; the later phases' worklists are far shorter.
 static size_t spin_cache_cap(size_t ncell)
 {
-    size_t cap = std::max<size_t>(4096, ncell / 128);
-    cap = std::min(cap, ncell);
+    size_t cap = std::min<size_t>(ncell, (size_t)1 << 19);
     return (cap + 63) & ~(size_t)63;
 }
 
@@ -453,6 +452,9 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
     // to count its passes), otherwise it is a single pass: see k_spin_phase.
     static const int budget_full[] = {8, 16, 64, 2100}, budget_fast[] = {4, 4, 16, 1100};
     const int* budget = passes ? budget_full : budget_fast;
+    a.cache = (double*)(w + o_cache);
+    a.cache_cap = spin_cache_cap(ncell);
+    a.ntotal = ncell;
     for (int ph = 0; ph < 4; ph++) {
         a.fresh = (ph == 0);
         a.budget = budget[ph];
@@ -460,9 +462,17 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
         a.n_in = ph == 0 ? nullptr : cnt + (ph - 1);
         a.wl_out = wl[ph & 1];
         a.n_out = cnt + ph;
-        a.cache = (ph == 3) ? (double*)(w + o_cache) : nullptr;
-        a.cache_cap = spin_cache_cap(ncell);
-        HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+        if (ph == 0) { // every cell, in blocks the size of the cache
+            for (size_t c0 = 0; c0 < ncell; c0 += a.cache_cap) {
+                a.cell0 = c0;
+                a.ncell = std::min(a.cache_cap, ncell - c0);
+                HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+            }
+            a.cell0 = 0;
+            a.ncell = ncell;
+        } else {
+            HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+        }
     }
     return SPLASH_OK;
 }
@@ -774,9 +784,22 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
     HIP_TRY(hipMemGetInfo(&free_b, &total_b), err, errlen);
     const size_t per_cell = (size_t)nt * 3 * 8 + (f32 ? (size_t)nt * 4 : 0) +
                             (size_t)nt_out * n_out * 8 +
-                            (SPLASH_NPAR + SPLASH_NSTATE + 6 + 5 + 3 + 1 + 4 + 4 + 1) * 8 + 64 +
-                            spin_cache_bytes_per_slot() / 128 + 8;
-    size_t nb_max = (size_t)((double)free_b * 0.85 / (double)std::max(share, 1)) / per_cell;
+                            (SPLASH_NPAR + SPLASH_NSTATE + 6 + 5 + 3 + 1 + 4 + 4 + 1) * 8 + 64;
+    // the spin-up's cache of day terms: 55 KB per slot, min(cells, 2^19) slots
+    const double budget = (double)free_b * 0.85 / (double)std::max(share, 1);
+    const size_t want = v1 - v0;
+    size_t nb_max = want;
+    auto need = [&](size_t nb) {
+        return (double)nb * (double)per_cell + (double)splash_dev_spin_up_work_size(nb);
+    };
+    if (need(nb_max) > budget) { // largest block that fits (bisection on a monotone function)
+        size_t lo = 0, hi = nb_max;
+        while (hi - lo > 256) {
+            const size_t mid = lo + (hi - lo) / 2;
+            if (need(mid) > budget) hi = mid; else lo = mid;
+        }
+        nb_max = lo;
+    }
     if (P.max_cells) nb_max = std::min(nb_max, P.max_cells);
     if (nb_max == 0) return fail(SPLASH_ENOMEM, err, errlen, "grid_run: not enough device memory");
     nb_max = std::min(nb_max, v1 - v0);

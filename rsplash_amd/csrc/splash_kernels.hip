@@ -227,10 +227,15 @@ __device__ __forceinline__ DayRecord rec_load(const double* __restrict__ base, s
     return r;
 }
 
-// CACHED (the last phase: the jobs that run hundreds of passes): the first pass of the launch
-// stores every day's record, the later ones read them back and only evaluate the state-dependent
-// update -- the same bits (terms_fence), less than half the instructions, and no forcing reads.
-// Jobs beyond the cache's capacity run the plain way.
+// CACHED: the first pass of the launch stores every day's record, the later ones read them back and
+// only evaluate the state-dependent update -- the same bits (terms_fence), about two thirds of the
+// instructions, and no forcing reads.  Used by phase 0 (every cell, in blocks the size of the cache:
+// the pass of spin-up #1 fills it, the passes of spin-up #2 read it) and by the later phases; jobs
+// beyond the cache's capacity run the plain way.
+// (A single day loop 0, 1, ..., 364, 0, ... with the pass-end decision after every day 0 -- one
+// inlined copy of the day step instead of four -- was tried: the turn a lane needs when it starts
+// spin-up #2 in the middle of that loop cost more than the smaller code saved: 2.2-4.4 s vs 1.35 s
+// for 2.1 M cells.)
 template <bool CACHED>
 __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPhaseArgs a)
 {
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     const size_t slot = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool valid = slot < nin;
     const size_t sl = valid ? slot : nin - 1;
-    const size_t ci = a.wl_in ? (size_t)a.wl_in[sl] : sl;
+    const size_t ci = a.wl_in ? (size_t)a.wl_in[sl] : a.cell0 + sl;
     const bool cached = CACHED && a.cache != nullptr && sl < a.cache_cap;
 
     Forcing f{a.sw, a.tc, a.pn, nullptr, a.ldf, a.Tt[ci],
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 a.state[2 * a.lds + ci] = cur.qin;
                 a.state[3 * a.lds + ci] = cur.td;
                 a.state[4 * a.lds + ci] = cur.nd;
-                if (a.passes) a.passes[a.ncell + ci] = count;
+                if (a.passes) a.passes[a.ntotal + ci] = count;
                 done = true;
             }
         } else {

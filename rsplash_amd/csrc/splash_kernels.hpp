@@ -69,8 +69,10 @@ struct SpinPhaseArgs {
     int budget;             // passes per job in this phase
     int fresh;              // phase 0
     ViscTables vt;
-    double* cache;          // last phase: [365][19][cache_cap] records of the day terms, or NULL
-    size_t cache_cap;       // jobs (worklist positions) the cache has room for
+    double* cache;          // [365][19][cache_cap] records of the day terms, or NULL
+    size_t cache_cap;       // jobs (launch positions) the cache has room for
+    size_t cell0;           // phase 0 runs in blocks of cache_cap cells: first cell of this launch
+    size_t ntotal;          // cells of the whole call (row stride of `passes`)
 };
 size_t spin_cache_bytes_per_slot();
 
