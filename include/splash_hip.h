@@ -119,6 +119,29 @@ int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, const double* s
                        double* cellpar, size_t ldp, double* state /*[5][lds]*/, size_t lds,
                        int* passes, void* work, void* stream);
 
+/* The spin-up in two parts, for callers that overlap its tail with other work.  A few cells per
+ * thousand never meet the 1 mm stopping rule and run 1000 passes (src/SPLASH.cpp:1697): a chain of
+ * 365 000 sequential day steps that keeps a handful of wavefronts busy for over a second while the
+ * rest of the GPU idles.  _begin runs the phases that finish all other cells (their state is final
+ * when it completes on its stream); _finish runs the rest, typically on a second stream, while the
+ * caller already runs run_all for the finished cells (splash_dev_out.skip) and copies their
+ * results; the late cells follow in list mode (splash_dev_out.cells).  Same workspace and same
+ * arguments for both; splash_dev_spin_up == _begin + _finish on one stream. */
+int splash_dev_spin_up_begin(const splash_calendar* cal, size_t ncell, const double* sw_in,
+                             const double* tc, const double* pn, size_t ldf, const double* Tt,
+                             double* cellpar, size_t ldp, double* state, size_t lds, int* passes,
+                             void* work, void* stream);
+int splash_dev_spin_up_finish(const splash_calendar* cal, size_t ncell, const double* sw_in,
+                              const double* tc, const double* pn, size_t ldf, const double* Tt,
+                              double* cellpar, size_t ldp, double* state, size_t lds, int* passes,
+                              void* work, void* stream);
+/* device pointers into `work`, valid once _begin has completed: the byte mask [ncell] of the cells
+ * left for _finish, their list (uint32 cell ids) and the list's length (one uint32) */
+int splash_dev_spin_up_pending(void* work, size_t ncell, const unsigned char** mask,
+                               const uint32_t** cells, const uint32_t** n_cells);
+/* the list's length on the host (waits for `stream`, the one _begin ran on) */
+int splash_dev_spin_up_pending_count(void* work, size_t ncell, void* stream, uint32_t* n_pending);
+
 typedef struct {
     double* out[SPLASH_NOUT]; /* each [nt_out][ldo] or NULL to skip that series */
     size_t ldo;
@@ -135,6 +158,15 @@ typedef struct {
     int64_t* diag_acc;
     const int32_t* basin;
     int n_basin;
+    /* Overlapping the spin-up's long tail with the transient run (splash_dev_spin_up_begin/_finish):
+     * skip [ncell] bytes (splash_dev_spin_up_pending): cells flagged there are still spinning up --
+     * this call computes them from whatever state they have, but they take no part in the totals,
+     * their state is left alone, and their outputs are to be rewritten by a later call in list mode;
+     * cells [ncell] uint32: list mode -- lane j works on cell cells[j] (forcing, parameters, state
+     * and basin of THAT cell; the array arguments of run_all then address cell 0) and writes its
+     * outputs to column j of compact [nt_out][ldo] arrays. */
+    const unsigned char* skip;
+    const uint32_t* cells;
 } splash_dev_out;
 
 size_t splash_dev_diag_acc_size(int n_basin, int nmonth); /* bytes */

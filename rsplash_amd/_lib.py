@@ -37,7 +37,8 @@ class GridOut(C.Structure):
 
 class DevOut(C.Structure):
     _fields_ = [("out", _vp * NOUT), ("ldo", C.c_size_t), ("monthly", C.c_int),
-                ("extra", _vp * NEXTRA), ("diag_acc", _vp), ("basin", _vp), ("n_basin", C.c_int)]
+                ("extra", _vp * NEXTRA), ("diag_acc", _vp), ("basin", _vp), ("n_basin", C.c_int),
+                ("skip", _vp), ("cells", _vp)]
 
 
 def _load():
@@ -65,6 +66,10 @@ def _load():
     L.splash_dev_spin_up_work_size.argtypes = [C.c_size_t]
     L.splash_dev_spin_up.argtypes = [_vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t, _vp, _vp,
                                      C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp]
+    for fn in ("splash_dev_spin_up_begin", "splash_dev_spin_up_finish"):
+        getattr(L, fn).argtypes = L.splash_dev_spin_up.argtypes
+    L.splash_dev_spin_up_pending.argtypes = [_vp, C.c_size_t, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]
+    L.splash_dev_spin_up_pending_count.argtypes = [_vp, C.c_size_t, _vp, C.POINTER(C.c_uint32)]
     L.splash_dev_diag_acc_size.restype = C.c_size_t
     L.splash_dev_diag_acc_size.argtypes = [C.c_int, C.c_int]
     L.splash_dev_diag_finalize.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp]
@@ -112,6 +117,8 @@ SYMBOLS = (
     "splash_calendar_create", "splash_calendar_destroy", "splash_calendar_nt",
     "splash_calendar_nmonth", "splash_calendar_orbit", "splash_orbit_day", "splash_dev_soil_hydro",
     "splash_dev_snow_threshold", "splash_dev_spin_up_work_size", "splash_dev_spin_up",
+    "splash_dev_spin_up_begin", "splash_dev_spin_up_finish", "splash_dev_spin_up_pending",
+    "splash_dev_spin_up_pending_count",
     "splash_dev_diag_acc_size", "splash_dev_diag_finalize", "splash_diag_finalize_host",
     "splash_dev_infiltration_probe", "splash_dev_terrain", "splash_dev_ncellflow",
     "splash_dev_run_all", "splash_dev_synth_statics", "splash_dev_synth_forcing",

@@ -409,6 +409,38 @@ def dev_spin_up(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, wo
                                  stream), "splash_dev_spin_up")
 
 
+def dev_spin_up_begin(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, work, passes=None,
+                      stream=None):
+    """all phases of the spin-up but the long tail (see include/splash_hip.h)"""
+    check(lib.splash_dev_spin_up_begin(cal.h, ncell, _ptr(sw_in), _ptr(tc), _ptr(pn), ldf, _ptr(Tt),
+                                       _ptr(cellpar), ldp, _ptr(state), lds, _ptr(passes), _ptr(work),
+                                       stream), "splash_dev_spin_up_begin")
+
+
+def dev_spin_up_finish(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, work, passes=None,
+                       stream=None):
+    """the tail: the cells _begin left unfinished"""
+    check(lib.splash_dev_spin_up_finish(cal.h, ncell, _ptr(sw_in), _ptr(tc), _ptr(pn), ldf, _ptr(Tt),
+                                        _ptr(cellpar), ldp, _ptr(state), lds, _ptr(passes), _ptr(work),
+                                        stream), "splash_dev_spin_up_finish")
+
+
+def dev_spin_up_pending(work, ncell):
+    """device pointers (ints) into the workspace: byte mask [ncell], uint32 cell list, uint32 count"""
+    m, c, n = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    check(lib.splash_dev_spin_up_pending(_ptr(work), ncell, C.byref(m), C.byref(c), C.byref(n)),
+          "splash_dev_spin_up_pending")
+    return m.value, c.value, n.value
+
+
+def dev_spin_up_pending_count(work, ncell, stream=None):
+    """number of cells _begin left for _finish (waits for `stream`)"""
+    v = C.c_uint32(0)
+    check(lib.splash_dev_spin_up_pending_count(_ptr(work), ncell, stream, C.byref(v)),
+          "splash_dev_spin_up_pending_count")
+    return v.value
+
+
 def diag_acc_size(n_basin, nmonth):
     """bytes of the exact water-balance accumulators: int64 [n_basin][nmonth][NDIAG+1][2]"""
     return lib.splash_dev_diag_acc_size(int(n_basin), int(nmonth))
@@ -444,7 +476,8 @@ def infiltration_probe(cellpar, wn, ksat_visc, P):
 
 
 def dev_run_all(cal, t0, nt, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, out_ptrs,
-                ldo, monthly=False, diag_acc=None, basin=None, n_basin=0, stream=None):
+                ldo, monthly=False, diag_acc=None, basin=None, n_basin=0, stream=None, skip=None,
+                cells=None):
     """out_ptrs: dict name -> tensor/pointer for the series to store (others are skipped); the
     names of OUT_NAMES plus, daily mode only, qin_prev / tdrain / snwage.
     diag_acc: int64 tensor [n_basin, cal.nmonth, NDIAG+1, 2] the water-balance totals are ADDED to."""
@@ -458,6 +491,8 @@ def dev_run_all(cal, t0, nt, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state,
     o.diag_acc = _ptr(diag_acc)
     o.basin = _ptr(basin)
     o.n_basin = int(n_basin)
+    o.skip = _ptr(skip)
+    o.cells = _ptr(cells)
     check(lib.splash_dev_run_all(cal.h, t0, nt, ncell, _ptr(sw_in), _ptr(tc), _ptr(pn), ldf,
                                  _ptr(Tt), _ptr(cellpar), ldp, _ptr(state), lds, C.byref(o),
                                  stream), "splash_dev_run_all")

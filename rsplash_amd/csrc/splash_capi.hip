@@ -388,7 +388,7 @@ static size_t spin_cache_cap(size_t ncell)
 }
 
 static size_t spin_work_layout(size_t ncell, size_t* o_wl_b, size_t* o_meta, size_t* o_ai,
-                               size_t* o_cnt, size_t* o_cache = nullptr)
+                               size_t* o_cnt, size_t* o_cache = nullptr, size_t* o_pend = nullptr)
 {
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -398,7 +398,9 @@ static size_t spin_work_layout(size_t ncell, size_t* o_wl_b, size_t* o_meta, siz
     };
     take(ncell * 4); // wl_a at 0
     size_t wl_b = take(ncell * 4), meta = take(ncell * 4), ai = take(ncell * 8), cnt = take(64);
+    size_t pend = take(ncell);
     size_t cache = take(spin_cache_cap(ncell) * spin_cache_bytes_per_slot());
+    if (o_pend) *o_pend = pend;
     if (o_wl_b) *o_wl_b = wl_b;
     if (o_meta) *o_meta = meta;
     if (o_ai) *o_ai = ai;
@@ -412,10 +414,12 @@ extern "C" size_t splash_dev_spin_up_work_size(size_t ncell)
     return spin_work_layout(ncell, nullptr, nullptr, nullptr, nullptr);
 }
 
-extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, const double* sw_in,
-                                  const double* tc, const double* pn, size_t ldf, const double* Tt,
-                                  double* cellpar, size_t ldp, double* state, size_t lds,
-                                  int* passes, void* work, void* stream)
+// phases [ph0, ph1) of the spin-up (see k_spin_phase): 0..2 finish all but a few cells per
+// thousand, 3 is the long tail
+static int spin_phases(const splash_calendar* cal, size_t ncell, const double* sw_in,
+                       const double* tc, const double* pn, size_t ldf, const double* Tt,
+                       double* cellpar, size_t ldp, double* state, size_t lds, int* passes,
+                       void* work, void* stream, int ph0, int ph1)
 {
     REQ(cal && sw_in && tc && pn && Tt && cellpar && state && work, "spin_up: NULL argument");
     REQ(cal->nt >= 365, "spin_up: needs at least 365 days (R/splash.point.R:141-144)");
@@ -424,12 +428,15 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
     if (int rc = need_device(nullptr, 0)) return rc;
     if (ncell == 0) return SPLASH_OK;
     hipStream_t s = (hipStream_t)stream;
-    size_t o_wl_b, o_meta, o_ai, o_cnt, o_cache;
-    spin_work_layout(ncell, &o_wl_b, &o_meta, &o_ai, &o_cnt, &o_cache);
+    size_t o_wl_b, o_meta, o_ai, o_cnt, o_cache, o_pend;
+    spin_work_layout(ncell, &o_wl_b, &o_meta, &o_ai, &o_cnt, &o_cache, &o_pend);
     char* w = (char*)work;
     uint32_t* wl[2] = {(uint32_t*)w, (uint32_t*)(w + o_wl_b)};
     uint32_t* cnt = (uint32_t*)(w + o_cnt);
-    HIP_TRY(hipMemsetAsync(cnt, 0, 64, s), nullptr, 0);
+    if (ph0 == 0) {
+        HIP_TRY(hipMemsetAsync(cnt, 0, 64, s), nullptr, 0);
+        HIP_TRY(hipMemsetAsync(w + o_pend, 0, ncell, s), nullptr, 0);
+    }
     SpinPhaseArgs a{};
     a.days = cal->spin_dev; // doy 1..365 of the first year, real months (see splash_calendar)
     a.n = 365;
@@ -455,13 +462,14 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
     a.cache = (double*)(w + o_cache);
     a.cache_cap = spin_cache_cap(ncell);
     a.ntotal = ncell;
-    for (int ph = 0; ph < 4; ph++) {
+    for (int ph = ph0; ph < ph1; ph++) {
         a.fresh = (ph == 0);
         a.budget = budget[ph];
         a.wl_in = ph == 0 ? nullptr : wl[(ph - 1) & 1];
         a.n_in = ph == 0 ? nullptr : cnt + (ph - 1);
         a.wl_out = wl[ph & 1];
         a.n_out = cnt + ph;
+        a.pending = (ph == 2) ? (unsigned char*)(w + o_pend) : nullptr;
         if (ph == 0) { // every cell, in blocks the size of the cache
             for (size_t c0 = 0; c0 < ncell; c0 += a.cache_cap) {
                 a.cell0 = c0;
@@ -474,6 +482,59 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
             HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
         }
     }
+    return SPLASH_OK;
+}
+
+extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, const double* sw_in,
+                                  const double* tc, const double* pn, size_t ldf, const double* Tt,
+                                  double* cellpar, size_t ldp, double* state, size_t lds,
+                                  int* passes, void* work, void* stream)
+{
+    return spin_phases(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, passes, work,
+                       stream, 0, 4);
+}
+
+extern "C" int splash_dev_spin_up_begin(const splash_calendar* cal, size_t ncell,
+                                        const double* sw_in, const double* tc, const double* pn,
+                                        size_t ldf, const double* Tt, double* cellpar, size_t ldp,
+                                        double* state, size_t lds, int* passes, void* work,
+                                        void* stream)
+{
+    return spin_phases(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, passes, work,
+                       stream, 0, 3);
+}
+
+extern "C" int splash_dev_spin_up_finish(const splash_calendar* cal, size_t ncell,
+                                         const double* sw_in, const double* tc, const double* pn,
+                                         size_t ldf, const double* Tt, double* cellpar, size_t ldp,
+                                         double* state, size_t lds, int* passes, void* work,
+                                         void* stream)
+{
+    return spin_phases(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, passes, work,
+                       stream, 3, 4);
+}
+
+extern "C" int splash_dev_spin_up_pending(void* work, size_t ncell, const unsigned char** mask,
+                                          const uint32_t** cells, const uint32_t** n_cells)
+{
+    REQ(work, "spin_up_pending: NULL workspace");
+    size_t o_wl_b, o_meta, o_ai, o_cnt, o_cache, o_pend;
+    spin_work_layout(ncell, &o_wl_b, &o_meta, &o_ai, &o_cnt, &o_cache, &o_pend);
+    char* w = (char*)work;
+    if (mask) *mask = (const unsigned char*)(w + o_pend);
+    if (cells) *cells = (const uint32_t*)w; // phase 2 writes worklist 0
+    if (n_cells) *n_cells = (const uint32_t*)(w + o_cnt) + 2;
+    return SPLASH_OK;
+}
+
+extern "C" int splash_dev_spin_up_pending_count(void* work, size_t ncell, void* stream,
+                                                uint32_t* n_pending)
+{
+    REQ(work && n_pending, "spin_up_pending_count: NULL argument");
+    const uint32_t* d_n = nullptr;
+    (void)splash_dev_spin_up_pending(work, ncell, nullptr, nullptr, &d_n);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream), nullptr, 0);
+    HIP_TRY(hipMemcpy(n_pending, d_n, sizeof(uint32_t), hipMemcpyDeviceToHost), nullptr, 0);
     return SPLASH_OK;
 }
 
@@ -553,6 +614,8 @@ extern "C" int splash_dev_run_all(const splash_calendar* cal, int t0, int nt, si
     a.basin = out->basin;
     a.n_basin = out->basin ? out->n_basin : 1;
     a.nmonth_cal = cal->nmonth;
+    a.cells = out->cells;
+    a.skip = out->skip;
     if (int rc = visc_tables(a.vt)) return rc;
     HIP_TRY(launch_run_all(a, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
@@ -836,7 +899,30 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
     if (getenv("SPLASH_TRACE"))
         fprintf(stderr, "[splash] device %d: calendar + allocations %.3f s\n", device,
                 std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_w0);
-    hipStream_t s = nullptr;
+    // two non-blocking streams: s1 the main sequence, s2 the spin-up's tail and the late cells
+    struct Streams {
+        hipStream_t a = nullptr, b = nullptr;
+        ~Streams()
+        {
+            if (a) (void)hipStreamDestroy(a);
+            if (b) (void)hipStreamDestroy(b);
+        }
+    } st_;
+    struct Event {
+        hipEvent_t e = nullptr;
+        ~Event()
+        {
+            if (e) (void)hipEventDestroy(e);
+        }
+    } ev;
+    HIP_TRY(hipStreamCreateWithFlags(&st_.a, hipStreamNonBlocking), err, errlen);
+    HIP_TRY(hipStreamCreateWithFlags(&st_.b, hipStreamNonBlocking), err, errlen);
+    HIP_TRY(hipEventCreateWithFlags(&ev.e, hipEventDisableTiming), err, errlen);
+    hipStream_t s1 = st_.a, s2 = st_.b;
+    const size_t late_cap = std::min(nb_max, std::max<size_t>(4096, nb_max / 64));
+    DevBuf d_late;
+    HIP_TRY(d_late.alloc((size_t)nt_out * std::max(n_out, 1) * late_cap * 8), err, errlen);
+    hipStream_t s = s1;
     bool prefaulted = false;
     // SPLASH_TRACE=1: wall-clock of the stages of every block on stderr (host-path tuning aid)
     const bool trace = getenv("SPLASH_TRACE") != nullptr;
@@ -905,13 +991,21 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
         double* Tt = d_tt.as<double>();
         int rc;
         rc = splash_dev_soil_hydro(nb, S, S + nb, S + 2 * nb, S + 3 * nb, S + 4 * nb, S + 5 * nb,
-                                   in->au ? S + 11 * nb : nullptr, par, s);
+                                   in->au ? S + 11 * nb : nullptr, par, s1);
         if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
-        rc = splash_dev_snow_threshold(nb, nt, dtc, nb, par, nb, Tt, s);
+        rc = splash_dev_snow_threshold(nb, nt, dtc, nb, par, nb, Tt, s1);
         if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
-        rc = splash_dev_spin_up(cal, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb,
-                                out->aux ? d_pass.as<int>() : nullptr, d_swork.p, s);
+        // The spin-up's tail (a few cells per thousand, over a second of sequential day steps) runs
+        // on a second stream while the first one already computes the transient run of all other
+        // cells and their results travel to the host; the late cells follow in list mode.
+        int* dpass = out->aux ? d_pass.as<int>() : nullptr;
+        rc = splash_dev_spin_up_begin(cal, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, dpass,
+                                      d_swork.p, s1);
         if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
+        HIP_TRY(hipEventRecord(ev.e, s1), err, errlen);
+        const unsigned char* d_mask = nullptr;
+        const uint32_t *d_cells = nullptr, *d_ncells = nullptr;
+        (void)splash_dev_spin_up_pending(d_swork.p, nb, &d_mask, &d_cells, &d_ncells);
         splash_dev_out dout{};
         int q = 0;
         for (int k = 0; k < SPLASH_NOUT; k++)
@@ -923,7 +1017,12 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
             dout.basin = in->basin ? d_basin.as<int32_t>() : nullptr;
             dout.n_basin = P.n_basin;
         }
-        rc = splash_dev_run_all(cal, 0, nt, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, &dout, s);
+        dout.skip = d_mask;
+        rc = splash_dev_run_all(cal, 0, nt, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, &dout, s1);
+        if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
+        HIP_TRY(hipStreamWaitEvent(s2, ev.e, 0), err, errlen);
+        rc = splash_dev_spin_up_finish(cal, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, dpass,
+                                       d_swork.p, s2);
         if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
         // The kernels of this block are queued; while they run, map the caller's (typically
         // freshly allocated) output arrays: the first touch of tens of GB is otherwise paid page
@@ -933,7 +1032,7 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
             prefaulted = true;
         }
         double t_c = now();
-        HIP_TRY(hipStreamSynchronize(s), err, errlen);
+        HIP_TRY(hipStreamSynchronize(s1), err, errlen);
         double t_d = now();
 
         for (int k = 0; k < SPLASH_NOUT; k++) {
@@ -947,6 +1046,38 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
                 for (int t = 0; t < nt_out; t++)
                     for (size_t j = 0; j < nb; j++)
                         out->out[k][(size_t)t * N + idx[j]] = stage[(size_t)t * nb + j];
+            }
+        }
+        double t_e = now();
+        // the late cells: transient run in list mode into compact arrays, patched into the results
+        HIP_TRY(hipStreamSynchronize(s2), err, errlen);
+        double t_f = now();
+        uint32_t n_late = 0;
+        HIP_TRY(hipMemcpy(&n_late, d_ncells, sizeof n_late, hipMemcpyDeviceToHost), err, errlen);
+        if (n_late) {
+            std::vector<uint32_t> late(n_late);
+            HIP_TRY(hipMemcpy(late.data(), d_cells, (size_t)n_late * 4, hipMemcpyDeviceToHost), err, errlen);
+            std::vector<double> patch((size_t)nt_out * late_cap);
+            for (size_t k0 = 0; k0 < n_late; k0 += late_cap) {
+                const size_t nl = std::min(late_cap, (size_t)n_late - k0);
+                splash_dev_out dl = dout;
+                int ql = 0;
+                for (int k = 0; k < SPLASH_NOUT; k++)
+                    dl.out[k] = out->out[k] ? d_late.as<double>() + (size_t)(ql++) * nt_out * late_cap : nullptr;
+                dl.ldo = late_cap;
+                dl.skip = nullptr;
+                dl.cells = d_cells + k0;
+                rc = splash_dev_run_all(cal, 0, nt, nl, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, &dl, s2);
+                if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
+                HIP_TRY(hipStreamSynchronize(s2), err, errlen);
+                for (int k = 0; k < SPLASH_NOUT; k++) {
+                    if (!out->out[k]) continue;
+                    HIP_TRY(hipMemcpy2D(patch.data(), nl * 8, dl.out[k], late_cap * 8, nl * 8,
+                                        (size_t)nt_out, hipMemcpyDeviceToHost), err, errlen);
+                    for (int t = 0; t < nt_out; t++)
+                        for (size_t j = 0; j < nl; j++)
+                            out->out[k][(size_t)t * N + idx[late[k0 + j]]] = patch[(size_t)t * nl + j];
+                }
             }
         }
         if (out->state_end) {
@@ -970,8 +1101,9 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
         }
         if (trace)
             fprintf(stderr, "[splash] device %d block %zu cells: host->device %.3f s, queue+prefault %.3f s, "
-                            "kernels (rest) %.3f s, device->host %.3f s\n",
-                    device, nb, t_b - t_a, t_c - t_b, t_d - t_c, now() - t_d);
+                            "main kernels (rest) %.3f s, device->host %.3f s, tail (rest) %.3f s, %u late cells + "
+                            "small copies %.3f s\n",
+                    device, nb, t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e, n_late, now() - t_f);
     }
     if (P.want_diag)
         HIP_TRY(hipMemcpy(acc, d_acc.p, acc_bytes, hipMemcpyDeviceToHost), err, errlen);

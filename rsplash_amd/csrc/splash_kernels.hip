@@ -430,6 +430,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         a.state[3 * a.lds + ci] = s_e[3][threadIdx.x];
         a.state[4 * a.lds + ci] = s_e[4][threadIdx.x];
         a.meta[ci] = (stage << 16) | count;
+        if (a.pending) a.pending[ci] = 1;
         const uint32_t k = atomicAdd(a.n_out, 1u);
         a.wl_out[k] = (uint32_t)ci;
     }
@@ -612,11 +613,17 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
     __syncthreads();
 #endif
     size_t cell = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = cell < a.ncell;
-    const size_t ci = valid ? cell : a.ncell - 1;
+    const bool in_range = cell < a.ncell;
+    const size_t sl = in_range ? cell : a.ncell - 1;        // position in this launch
+    const size_t ci = a.cells ? (size_t)a.cells[sl] : sl;   // the cell it works on
+    const size_t co = a.cells ? sl : ci;                    // the output column it writes
+    // valid: the lane's results count (state, totals, monthly stores); a cell that is still
+    // spinning up is computed like any other (from whatever state it has) but counts for nothing
+    const bool valid = in_range && !(a.skip && a.skip[ci]);
     Forcing f{a.sw, a.tc, a.pn, a.snowfall, a.ldf, a.Tt ? a.Tt[ci] : 0.0,
               a.par[P_ELV * a.ldp + ci] * 0.0004596581, fabs(a.par[P_LAT * a.ldp + ci]) * 0.0110592101,
               (unsigned)(ci * sizeof(double))};
+    const unsigned ooff = (unsigned)(co * sizeof(double));
     const DayTable days = day_table(a.days);
     CellConst c;
     cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci], a.vt);
@@ -691,14 +698,14 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
             for (int q = 0; q < 9; q++)
                 if (omask & (1u << q))
                     __builtin_nontemporal_store(
-                        v[q], reinterpret_cast<double*>(reinterpret_cast<char*>(a.out[q] + row) + f.off));
+                        v[q], reinterpret_cast<double*>(reinterpret_cast<char*>(a.out[q] + row) + ooff));
             if (OUTMASK == 0) { // general variant only: the state series run_all also returns
                 const double x[3] = {st.qin, st.td, st.nd}; // qin_prev, tdrain, snwage (:1913-1915)
 #pragma unroll
                 for (int q = 0; q < 3; q++)
                     if (a.extra[q])
                         __builtin_nontemporal_store(
-                            x[q], reinterpret_cast<double*>(reinterpret_cast<char*>(a.extra[q] + row) + f.off));
+                            x[q], reinterpret_cast<double*>(reinterpret_cast<char*>(a.extra[q] + row) + ooff));
             }
         } else {
 #pragma unroll
@@ -723,10 +730,10 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
                 // a month split over two calls is completed by adding to the stored partial
                 const bool partial_head = (m == 0) && a.head_partial;
                 const double inv_n = 1.0 / (double)d.mdays;
-                size_t k = (size_t)m * a.ldo + ci;
+                size_t k = (size_t)m * a.ldo + co;
 #pragma unroll
                 for (int q = 0; q < 9; q++) {
-                    if ((omask & (1u << q)) && valid) {
+                    if ((omask & (1u << q)) && in_range) {
                         double x = (q == 0 || q == 4 || q == 8) ? acc[q] * inv_n : acc[q];
                         if (partial_head) x += a.out[q][k];
                         a.out[q][k] = x;

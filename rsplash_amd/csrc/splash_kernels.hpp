@@ -68,6 +68,7 @@ struct SpinPhaseArgs {
     double* ai;             // [ncell] aridity index
     int budget;             // passes per job in this phase
     int fresh;              // phase 0
+    unsigned char* pending; // [ncell] or NULL: set to 1 for every job parked by this launch
     ViscTables vt;
     double* cache;          // [365][19][cache_cap] records of the day terms, or NULL
     size_t cache_cap;       // jobs (launch positions) the cache has room for
@@ -101,6 +102,12 @@ struct RunArgs {
     int n_basin;
     int nmonth_cal;   // months in the whole calendar (row stride of diag_acc)
     ViscTables vt;
+    // list mode (the cells whose spin-up finished late, splash_capi.hip): lane j works on cell
+    // cells[j] and writes its outputs to COLUMN j of compact [nt_out][ldo] arrays
+    const uint32_t* cells;
+    // main pass of an overlapped call: cells flagged here are still spinning up -- their outputs are
+    // rewritten later in list mode; they take no part in the totals and their state is left alone
+    const unsigned char* skip;
 };
 
 hipError_t launch_soil_hydro(size_t ncell, const double* lat, const double* elev,
