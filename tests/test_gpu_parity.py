@@ -1078,3 +1078,77 @@ def test_terrain_and_ncellflow_vs_oracle(api, oracle):
             assert np.allclose(g[k][m], o[k][m], rtol=1e-12, atol=1e-10), k
     assert (g["aspect"][185:195, 305:325] == 90.0).all() and (g["slope"][185:195, 305:325] == 0).all()
     assert np.isnan(g["slope"][0]).all() and 0 < np.nanmax(g["slope"]) < 60
+
+
+def test_overlapped_spin_up_gives_the_same_bits(api, oracle):
+    """splash_dev_spin_up_begin / _finish with the transient run of the finished cells in between
+    (skip mask) and the late cells in list mode afterwards == the plain sequence, bit for bit, water-
+    balance totals included (what splash_grid_run does to hide the spin-up's tail)."""
+    import torch
+    dev = torch.device("cuda:0")
+    seed, H, W, nt = 777000, 64, 128, 400
+    n = H * W
+    dates = np.datetime64("2001-01-01") + np.arange(nt)
+    cal = api.Calendar.from_dates(dates)
+    f64 = dict(dtype=torch.float64, device=dev)
+    lat, elev, slop, asp, res = (torch.empty(n, **f64) for _ in range(5))
+    soil, au = torch.empty(6, n, **f64), torch.empty(3, n, **f64)
+    api.dev_synth_statics(seed, H, W, 0, n, 1, lat, elev, slop, asp, res, soil, au)
+    sw, tc, pn = (torch.empty(nt, n, **f64) for _ in range(3))
+    api.dev_synth_forcing(seed, cal, 0, nt, 0, n, lat, elev, sw, tc, pn, n)
+    par0 = torch.empty(api.NPAR, n, **f64)
+    Tt = torch.empty(n, **f64)
+    api.dev_soil_hydro(n, lat, elev, slop, asp, res, soil, au, par0)
+    api.dev_snow_threshold(n, nt, tc, n, par0, n, Tt)
+    names = ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "sm_lim")
+    nm = cal.nmonth
+
+    def plain():
+        par, state = par0.clone(), torch.empty(api.NSTATE, n, **f64)
+        work = torch.empty(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
+        api.dev_spin_up(cal, n, sw, tc, pn, n, Tt, par, n, state, n, work)
+        out = {k: torch.empty(nt, n, **f64) for k in names}
+        acc = torch.zeros(1, nm, api.DIAG_REC, dtype=torch.int64, device=dev)
+        api.dev_run_all(cal, 0, nt, n, sw, tc, pn, n, Tt, par, n, state, n, out, n, diag_acc=acc)
+        torch.cuda.synchronize()
+        return out, state, acc, par
+
+    def overlapped():
+        par, state = par0.clone(), torch.empty(api.NSTATE, n, **f64)
+        work = torch.empty(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
+        s1, s2 = torch.cuda.current_stream(), torch.cuda.Stream(device=dev)
+        api.dev_spin_up_begin(cal, n, sw, tc, pn, n, Tt, par, n, state, n, work, stream=s1.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(s1)
+        mask_p, cells_p, _ = api.dev_spin_up_pending(work, n)
+        out = {k: torch.empty(nt, n, **f64) for k in names}
+        acc = torch.zeros(1, nm, api.DIAG_REC, dtype=torch.int64, device=dev)
+        api.dev_run_all(cal, 0, nt, n, sw, tc, pn, n, Tt, par, n, state, n, out, n, diag_acc=acc,
+                        skip=mask_p, stream=s1.cuda_stream)
+        s2.wait_event(ev)
+        api.dev_spin_up_finish(cal, n, sw, tc, pn, n, Tt, par, n, state, n, work, stream=s2.cuda_stream)
+        torch.cuda.synchronize()
+        n_late = api.dev_spin_up_pending_count(work, n, s1.cuda_stream)
+        assert 0 < n_late < n // 20
+        cells = torch.empty(n_late, dtype=torch.int32, device=dev)
+        import ctypes
+        # the list lives in the workspace: view it through a tensor of the workspace's bytes
+        off = cells_p - work.data_ptr()
+        cells = work[off:off + 4 * n_late].view(torch.int32).clone()
+        late = {k: torch.empty(nt, n_late, **f64) for k in names}
+        api.dev_run_all(cal, 0, nt, n_late, sw, tc, pn, n, Tt, par, n, state, n, late, n_late,
+                        diag_acc=acc, cells=cells_p)
+        torch.cuda.synchronize()
+        idx = cells.long()
+        for k in names:
+            out[k][:, idx] = late[k]
+        return out, state, acc, par, n_late
+
+    a_out, a_state, a_acc, a_par = plain()
+    b_out, b_state, b_acc, b_par, n_late = overlapped()
+    print("late cells:", n_late)
+    for k in names:
+        assert torch.equal(a_out[k].view(torch.int64), b_out[k].view(torch.int64)), k
+    assert torch.equal(a_state.view(torch.int64), b_state.view(torch.int64))
+    assert torch.equal(a_acc, b_acc) and torch.equal(a_par.view(torch.int64), b_par.view(torch.int64))
+    cal.close()
