@@ -425,7 +425,9 @@ __device__ __forceinline__ void visc_tbar_part_fast(float tbar, float& mu0_out, 
 // (vector-memory loads return in order).
 struct DayPre {
     double pw;          // density_h2o(tc, patm), src/EVAP.cpp:113
-    float c[6];         // coef2[0..5] of the viscosity (table)
+    uint32_t cw[6];     // coef2[0..5] of the viscosity (table), as the raw words the gather returns:
+                        // nothing may touch them before day_viscosity(), or the compiler waits for
+                        // the gather where it was issued instead of where its result is needed
     float mu0, ctbar;
     float rbar;
     int mode;           // 0: tc < 0 (viscosity at tw = 0 is a cell constant)  1: tables  2: direct
@@ -444,8 +446,9 @@ __device__ __forceinline__ DayPre day_prefetch(const CellConst& c, double tc)
     q.mode = 0;
     q.rbar = q.mu0 = q.ctbar = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 6; k++) q.c[k] = 0.0f;
+    for (int k = 0; k < 6; k++) q.cw[k] = 0u;
 #if !(defined(SPL_ABLATE) && SPL_ABLATE == 1)
+    uint32_t ir = 0;
     if (!(tc < 0.0)) { // tw = tc (src/EVAP.cpp:100-105)
         const float tcf = (float)tc;
         // forcing that is not float-representable, or no tables: the routine is evaluated directly
@@ -456,16 +459,19 @@ __device__ __forceinline__ DayPre day_prefetch(const CellConst& c, double tc)
         const float rho = to_float_checked(num * frcp(num - pbar) * dq.po1000, risky);
         const float rbar = to_float_checked((double)rho * (1.0 / 322.0), risky);          // :420
         const float tbar = to_float_checked(((double)tcf + 273.15) * (1.0 / 647.09600830078125), risky); // :416
-        const uint32_t ir = __float_as_uint(rbar) - kViscR0;
+        ir = __float_as_uint(rbar) - kViscR0;
         risky |= (ir >= kViscNR);
         visc_tbar_part_fast(tbar, q.mu0, q.ctbar, risky);
         q.mode = risky ? 2 : 1;
         q.rbar = rbar;
-        if (!risky) {
-            const float4 a = *reinterpret_cast<const float4*>(c.vt.rtab + (size_t)ir * 8);
-            const float2 b = *reinterpret_cast<const float2*>(c.vt.rtab + (size_t)ir * 8 + 4);
-            q.c[0] = a.x; q.c[1] = a.y; q.c[2] = a.z; q.c[3] = a.w; q.c[4] = b.x; q.c[5] = b.y;
-        }
+        ir = risky ? 0u : ir;
+    }
+    // The gather is issued by EVERY lane (entry 0 where the table is not used): a load under a
+    // lane predicate ends in a join at which the compiler settles all outstanding loads.
+    if (c.vt.rtab != nullptr) { // uniform
+        const uint4 a = *reinterpret_cast<const uint4*>(c.vt.rtab + (size_t)ir * 8);
+        const uint2 b = *reinterpret_cast<const uint2*>(c.vt.rtab + (size_t)ir * 8 + 4);
+        q.cw[0] = a.x; q.cw[1] = a.y; q.cw[2] = a.z; q.cw[3] = a.w; q.cw[4] = b.x; q.cw[5] = b.y;
     }
 #endif
     return q;
@@ -477,7 +483,14 @@ __device__ __forceinline__ double day_viscosity(const CellConst& c, const DayPre
     double visc = c.visc0;
     if (q.mode == 1) {
         SPL_SITE();
-        visc = (double)visc_combine(q.rbar, q.mu0, q.ctbar, q.c);
+        float cf[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            uint32_t w = q.cw[k];
+            asm volatile("" : "+v"(w)); // first touch of the gathered words: HERE, not at the load
+            cf[k] = __uint_as_float(w);
+        }
+        visc = (double)visc_combine(q.rbar, q.mu0, q.ctbar, cf);
     } else if (q.mode == 2) {
         SPL_SITE();
         visc = (double)viscosity_h2o((float)tc, c.patm_f);
@@ -1192,13 +1205,16 @@ __device__ __forceinline__ double snowfall_prob(double tc, double e1, double e2)
     return 1 / (1 + fexp(snow_logit(tc, e1, e2)));
 }
 
-__device__ __forceinline__ void rain_snow_split(const DayConst& d, double tc, double pn, double Tt,
-                                                double e1, double e2, double& rain,
-                                                double& snowfall)
+// Tt is handed over as a callable and fetched only on possible-snow days (k_run_all keeps it in LDS).
+template <class TtSource>
+__device__ __forceinline__ void rain_snow_split(const DayConst& d, double tc, double pn,
+                                                const TtSource& Tt_of_cell, double e1, double e2,
+                                                double& rain, double& snowfall)
 {
     const double x = snow_logit(tc, e1, e2);
     double f_rain = 1.0;
     if (x <= kSnowLogitMax) {
+        const double Tt = Tt_of_cell();
         double Ttm = Tt + (Tt * d.ttm_s);
         double q = ((tc - Ttm) * d.inv_trm14); // the divisor is a per-day constant: reciprocal from the host table
         double q2 = q * q, q3 = q2 * q;

@@ -121,6 +121,12 @@ __global__ __launch_bounds__(kBlock) void k_snow_threshold(size_t ncell, int nt,
 // One lane's view of the forcing rasters.  The row base (array + t*ld) is uniform and stays in
 // scalar registers; the lane adds a 32-bit byte offset, so a load is one global_load with an SGPR
 // base and no 64-bit vector address arithmetic (callers keep ncell*8 below 4 GiB per launch).
+// The snowfall threshold of a lane's cell, for kernels that keep it in LDS rather than in a register
+// (k_run_all: it is needed on possible-snow days only, the day loop is short of registers, and a
+// register the compiler spills comes back through scratch memory, i.e. through the vector-memory
+// counter: the reload would wait for every outstanding load, the prefetched forcing included).
+__shared__ double s_cell_Tt[kBlock];
+
 struct Forcing {
     const double *sw, *tc, *pn, *snowfall; // snowfall != NULL => explicit rain/snow series
     size_t ld;
@@ -137,16 +143,39 @@ struct Forcing {
         b = at(tc + r, off);
         c_ = at(pn + r, off);
     }
-    __device__ __forceinline__ void split(const DayRec& d, int t, double tcv, double pnv,
+    // the day's record of the explicit snowfall series (0 when the split is computed): requested
+    // together with the forcing, a day ahead, so that no load is issued -- and none has to be
+    // waited for -- in the first half of a day
+    __device__ __forceinline__ double raw_snowfall(int t) const
+    {
+        return snowfall ? at(snowfall + (size_t)t * ld, off) : 0.0;
+    }
+    template <bool TT_IN_LDS = false>
+    __device__ __forceinline__ void split(const DayRec& d, double tcv, double pnv, double snfv,
                                           double& rain, double& snowf) const
     {
         if (snowfall) {
             rain = pnv;
-            snowf = at(snowfall + (size_t)t * ld, off);
+            snowf = snfv;
         } else {
             DayConst dc{d.dr, d.sd, d.cd, d.ttm_s, d.inv_trm14};
-            rain_snow_split(dc, tcv, pnv, Tt, e1, e2, rain, snowf);
+            if (TT_IN_LDS)
+                rain_snow_split(dc, tcv, pnv, [] {
+                    // the index passes through an asm statement, which stays inside the snow branch:
+                    // the read cannot be hoisted into a register (a volatile read would be a flat load)
+                    unsigned i = threadIdx.x;
+                    asm volatile("" : "+v"(i));
+                    return s_cell_Tt[i];
+                }, e1, e2, rain, snowf);
+            else
+                rain_snow_split(dc, tcv, pnv, [this] { return Tt; }, e1, e2, rain, snowf);
         }
+    }
+    // the same with the snowfall record read on the spot (spin-up, module mirrors)
+    __device__ __forceinline__ void split(const DayRec& d, int t, double tcv, double pnv,
+                                          double& rain, double& snowf) const
+    {
+        split(d, tcv, pnv, raw_snowfall(t), rain, snowf);
     }
 };
 
@@ -248,7 +277,8 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     const size_t ci = a.wl_in ? (size_t)a.wl_in[sl] : a.cell0 + sl;
     const bool cached = CACHED && a.cache != nullptr && sl < a.cache_cap;
 
-    Forcing f{a.sw, a.tc, a.pn, nullptr, a.ldf, a.Tt[ci],
+    s_cell_Tt[threadIdx.x] = a.Tt[ci]; // own slot: no barrier needed
+    Forcing f{a.sw, a.tc, a.pn, nullptr, a.ldf, 0.0,
               a.par[P_ELV * a.ldp + ci] * 0.0004596581, fabs(a.par[P_LAT * a.ldp + ci]) * 0.0110592101,
               (unsigned)(ci * sizeof(double))};
     const DayTable days = day_table(a.days);
@@ -284,7 +314,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         } else {
             double sw0, tc0, pn0;
             f.raw(0, sw0, tc0, pn0);
-            f.split(d0, 0, tc0, pn0, r.rain, r.snf);
+            f.split<true>(d0, tc0, pn0, 0.0, r.rain, r.snf);
             day_terms(c, day_const(d0), day_prefetch(c, tc0), sw0, tc0, r.T);
             terms_fence(r.T);
             if (CACHED && cached) rec_store(a.cache, a.cache_cap, 0, sl, r);
@@ -341,17 +371,23 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 r = rn;
             }
         } else {
+            // order of the day's vector-memory traffic as in k_run_all: gathers at the top; once
+            // the terms are finished, tomorrow's forcing (and the record's stores); everything is
+            // waited for at the end of the day, half a day old
             double swv, tcv, pnv;
             f.raw(1, swv, tcv, pnv);
+            asm volatile("" : "+v"(swv), "+v"(tcv), "+v"(pnv) : : "memory");
             for (int i = 1; i < a.n; i++) {
                 const DayPre pre = day_prefetch(c, tcv);
-                double swn = swv, tcn = tcv, pnn = pnv;
-                if (i + 1 < a.n) f.raw(i + 1, swn, tcn, pnn);
                 const DayRec d = day_rec(days, i);
                 DayRecord r;
-                f.split(d, i, tcv, pnv, r.rain, r.snf);
+                f.split<true>(d, tcv, pnv, 0.0, r.rain, r.snf);
                 day_terms(c, day_const(d), pre, swv, tcv, r.T);
                 terms_fence(r.T);
+                asm volatile("" : : : "memory");
+                const int in_ = i + 1 < a.n ? i + 1 : i; // the last day reads its own row again
+                double swn, tcn, pnn;
+                f.raw(in_, swn, tcn, pnn);
                 if (CACHED && cached) rec_store(a.cache, a.cache_cap, i, sl, r);
                 day_update(c, r.T, r.rain, r.snf, cur, o);
                 if (acc) { // pet_vec is only filled in the first pass (:1667), Pinit = rain + snow
@@ -359,6 +395,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                     pet_sum += (o.pet == o.pet) ? o.pet : 0.0; // na.rm = T
                     p_sum += (pday == pday) ? pday : 0.0;
                 }
+                asm volatile("" : "+v"(swn), "+v"(tcn), "+v"(pnn) : : "memory");
                 swv = swn;
                 tcv = tcn;
                 pnv = pnn;
@@ -620,7 +657,8 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
     // valid: the lane's results count (state, totals, monthly stores); a cell that is still
     // spinning up is computed like any other (from whatever state it has) but counts for nothing
     const bool valid = in_range && !(a.skip && a.skip[ci]);
-    Forcing f{a.sw, a.tc, a.pn, a.snowfall, a.ldf, a.Tt ? a.Tt[ci] : 0.0,
+    s_cell_Tt[threadIdx.x] = a.Tt ? a.Tt[ci] : 0.0; // own slot: no barrier needed
+    Forcing f{a.sw, a.tc, a.pn, a.snowfall, a.ldf, 0.0,
               a.par[P_ELV * a.ldp + ci] * 0.0004596581, fabs(a.par[P_LAT * a.ldp + ci]) * 0.0110592101,
               (unsigned)(ci * sizeof(double))};
     const unsigned ooff = (unsigned)(co * sizeof(double));
@@ -669,17 +707,33 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
         if (s_wgb[0] == s_wgb[1] && (unsigned)s_wgb[0] < (unsigned)a.n_basin) wg_basin = s_wgb[0];
     }
 
-    double swv, tcv, pnv;
+    double swv, tcv, pnv, sfv;
     f.raw(0, swv, tcv, pnv);
+    sfv = f.raw_snowfall(0);
+    asm volatile("" : "+v"(swv), "+v"(tcv), "+v"(pnv), "+v"(sfv) : : "memory"); // landed before the loop
     for (int t = 0; t < a.nt; t++) {
+        // Vector-memory traffic of a day, in issue order (loads and stores share ONE counter on
+        // gfx950 and may complete out of order with respect to each other, so a wait for a load
+        // while stores are outstanding is a wait for everything):
+        //   top      gathers of today's viscosity (Infinity Cache / L2, ~1 us)
+        //   mid-day  wait for the gathers (nothing else is outstanding but yesterday's stores,
+        //            half a day old), THEN request tomorrow's forcing (HBM)
+        //   end      wait for the forcing (half a day old), THEN today's stores
+        // so that every wait finds its data long since arrived and the next day starts without one.
         const DayRec d = day_rec(days, t);
-        const DayPre pre = day_prefetch(c, tcv);       // table gathers of today's viscosity first,
-        double swn = swv, tcn = tcv, pnn = pnv;
-        if (t + 1 < a.nt) f.raw(t + 1, swn, tcn, pnn); // then next day's forcing in flight
+        const DayPre pre = day_prefetch(c, tcv);
         double rain, snf;
-        f.split(d, t, tcv, pnv, rain, snf);
+        f.split<true>(d, tcv, pnv, sfv, rain, snf);
         DayOut o;
-        day_step(c, day_const(d), pre, swv, tcv, rain, snf, st, o);
+        DayTerms T;
+        day_terms(c, day_const(d), pre, swv, tcv, T);
+        asm volatile("" : "+v"(T.kv) : : "memory"); // the viscosity (gathers) is finished here
+        const int tn = t + 1 < a.nt ? t + 1 : t;    // the last day reads its own row again
+        double swn, tcn, pnn;
+        f.raw(tn, swn, tcn, pnn);
+        double sfn = f.raw_snowfall(tn);
+        day_update(c, T, rain, snf, st, o);
+        asm volatile("" : "+v"(swn), "+v"(tcn), "+v"(pnn), "+v"(sfn) : : "memory"); // forcing has landed
 
         double lim = 0.0;
         if (omask & (1u << 8)) { // R/splash.point.R:197-200 (only when sm_lim is requested)
@@ -757,6 +811,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
         swv = swn;
         tcv = tcn;
         pnv = pnn;
+        sfv = sfn;
     }
     if (valid) {
         a.state[ci] = st.wn;

@@ -135,17 +135,14 @@ SPL_HD double fsqrt(double x)
 #include "splash_log_table.hpp"
 #if defined(__HIPCC__)
 __device__ const double kLogTabDev[256] = {SPL_LOG_TABLE_VALUES};
-__shared__ double s_log_tab[256];
+__shared__ __attribute__((aligned(16))) double s_log_tab[256];
 __device__ __forceinline__ void math_tables_init()
 {
     for (unsigned i = threadIdx.x; i < 256; i += blockDim.x) s_log_tab[i] = kLogTabDev[i];
 }
 #endif
-#if defined(__HIP_DEVICE_COMPILE__)
-#define SPL_LOG_TAB(i) s_log_tab[i]
-#else
+#if !defined(__HIP_DEVICE_COMPILE__)
 static const double kLogTabHost[256] = {SPL_LOG_TABLE_VALUES};
-#define SPL_LOG_TAB(i) kLogTabHost[i]
 #endif
 
 SPL_HD double flog(double x)
@@ -160,7 +157,15 @@ SPL_HD double flog(double x)
     const int kk = tmp >> 20; // -1 for m < 0.6875 (then z = 2m), else 0
     const unsigned zhi = hi - ((unsigned)tmp & 0xFFF00000u);
     const double z = __builtin_bit_cast(double, ((unsigned long long)zhi << 32) | (bm & 0xFFFFFFFFull));
-    const double invc = SPL_LOG_TAB(2 * i), logc = SPL_LOG_TAB(2 * i + 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one 16-byte LDS read for the pair: logc is not needed until the end, but a second read would
+    // cost a second round trip to LDS (the wait is for ALL outstanding LDS reads)
+    typedef double vec2d __attribute__((ext_vector_type(2)));
+    const vec2d ent = reinterpret_cast<const vec2d*>(s_log_tab)[i];
+    const double invc = ent.x, logc = ent.y;
+#else
+    const double invc = kLogTabHost[2 * i], logc = kLogTabHost[2 * i + 1];
+#endif
     const double r = fma(z, invc, -1.0);
     const double kd = (double)(e + kk);
     const double r2 = r * r;
