@@ -645,9 +645,12 @@ struct Etr { // src/etr.h:44-56 (fields the water balance needs)
 __device__ __forceinline__ void hour_angle(double cosv, bool at_one_is_zero, double& h,
                                            double& sinh_)
 {
+    // saturation by max/min: one instruction each instead of compare + two selects.  A NaN cosine
+    // comes out as -1 (h = pi) rather than NaN; every caller multiplies the angle with the NaN's
+    // own source (rw, rnl, econ: evap_update; a NaN ru/rv is a NaN cell), so the day's results are
+    // NaN all the same (test_gaps_in_the_forcing_propagate_like_NA_in_R).
     double x = at_one_is_zero ? cosv : -cosv;
-    x = (x >= 1.0) ? 1.0 : x;
-    x = (x <= -1.0) ? -1.0 : x;
+    x = fmin(fmax(x, -1.0), 1.0);
 #if defined(SPL_ABLATE) && SPL_ABLATE == 2
     h = 1.0 - x;
     sinh_ = x;
@@ -707,7 +710,7 @@ __device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d,
     const double sinfirst = num * frcp(b2c2);
     const double ru = -1 * a + cc * sinfirst;
     const double rv = b;
-    const double ruv = ru / rv;
+    const double ruv = ru * frcp(rv); // rv = cos(delta)*kb: an ordinary number for any real cell
 
     double hs, sin_hs; // :149-159: ruv >= 1 polar day (hs = 180), ruv <= -1 polar night (hs = 0)
     hour_angle(ruv, false, hs, sin_hs);
@@ -719,7 +722,7 @@ __device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d,
     if (isnan(ra_d) || r_in == 0 || ra_d < r_in) {
         tau = c.tau_o;
     } else {
-        tau = r_in / ra_d;
+        tau = r_in * frcp(ra_d); // here ra_d >= r_in > 0
     }
 #if defined(SPL_ABLATE) && SPL_ABLATE == 4
     double sf = (tau - c.tau_a) * c.tau_binv;
@@ -736,7 +739,7 @@ __device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d,
     if ((sw_in == 0.0) || (hs == 0.0)) {
         T.xrw = tau * d.dr * kGsc;
     } else {
-        T.xrw = (r_in) / ((86400.0 / kPI) * geo);
+        T.xrw = r_in * frcp((86400.0 / kPI) * geo);
     }
     T.ru = ru;
     T.rv = rv;
@@ -792,7 +795,7 @@ __device__ __forceinline__ void evap_update(const CellConst& c, const DayTerms& 
     }
     const double rw = (1.0 - alb) * T.xrw; // :220-224
 
-    const double inv_rwrv = 1.0 / (rw * rv);
+    const double inv_rwrv = frcp(rw * rv);
     const double xn = (rnl - rw * ru) * inv_rwrv; // :231
     double hn, sin_hn; // xn >= 1: net radiation negative all day (hn = 0)
     hour_angle(xn, true, hn, sin_hn);
@@ -1086,7 +1089,11 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
         if (theta_i >= c.theta_s) {
             theta_i = c.theta_s - 0.001;
         } else if (theta_i <= c.theta_r) {
-            theta_i = c.theta_r + 0.001;
+            // (formed here: hoisted out of the day loop the sum would be one more live register,
+            // i.e. a spill to scratch memory, whose reload waits on the vector-memory counter)
+            double tr = c.theta_r;
+            asm volatile("" : "+v"(tr));
+            theta_i = tr + 0.001;
         }
         const double theta_m = SPL_MAX(c.wm_th, theta_i);
         const double Kunsat = Ksat_visc * fpow(div_cr(theta_m, c.theta_s, c.inv_theta_s), c.kun_exp); // :1275
