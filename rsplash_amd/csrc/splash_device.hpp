@@ -106,6 +106,7 @@ struct CellConst {
     double bub, bpr, inv_bpr; // bubbling pressure [mm], [cm], 1 / bpr
     double Wmax, wm_th, inv_wr; // src/SPLASH.cpp:1029, Wmax/(depth*1000), 1/(Wmax-RES)
     double int_perm;        // Ksat/fluidity
+    double inv_kv24c;       // 1 / (24 * 3.6 * g * int_perm): 1/(24*Ksat_visc) = (visc/pw) * inv_kv24c
     double tan2_slop, inv_cos2; // tan^2(slop), 1/cos^2(slop)
     double h_f;             // Green-Ampt wetting-front suction (src/SPLASH.cpp:1987)
     double kun_exp;         // 3 + 2/lambda
@@ -234,10 +235,10 @@ __device__ __forceinline__ float expf_glibc(float x)
     double xd = (double)x;
     // |x| >= 88: overflow/underflow paths of the original are unreachable for viscosity
     // arguments (0 <= x < 8); handled generically for completeness.
-    if (!(fabsf(x) < 88.0f)) {
-        if (x != x) return x;
-        if (x > 0.0f) return x > 88.72283f ? __builtin_inff() : (float)exp(xd);
-        return x < -103.97208f ? 0.0f : (float)exp(xd);
+    if (!(fabsf(x) < 88.0f)) { // (the short exp of splash_math.hpp: four inlined copies of the
+        if (x != x) return x;  //  library routine cost the day loop registers for nothing)
+        if (x > 0.0f) return x > 88.72283f ? __builtin_inff() : (float)fexp(xd);
+        return x < -103.97208f ? 0.0f : (float)fexp(xd);
     }
     double z = InvLn2N * xd;
     double kd = z + Shift;
@@ -401,15 +402,14 @@ __device__ __forceinline__ float to_float_checked(double v, bool& risky)
 // visc_tbar_part() with reciprocal-based quotients and a fast square root, every rounding to float
 // checked (to_float_checked): ~60 instructions instead of three IEEE divisions, a correctly
 // rounded square root and two more divisions -- or instead of a 23 MB table whose gathers miss L2.
-__device__ __forceinline__ void visc_tbar_part_fast(float tbar, float& mu0_out, float& ctbar_out,
+__device__ __forceinline__ void visc_tbar_part_fast(float tbar, double t1, double t2, double t3,
+                                                    double r, float& mu0_out, float& ctbar_out,
                                                     bool& risky)
 {
 #pragma clang fp contract(off)
-    const float tbar2 = tbar * tbar;                                   // :418
-    const float tbar3 = tbar * tbar * tbar;                            // :419
-    const double t1 = (double)tbar, t2 = (double)tbar2, t3 = (double)tbar3;
-    // 1/t1, 1/t2, 1/t3 from one reciprocal of the product (all three ~0.1 .. 0.5)
-    const double r = frcp(t1 * t2 * t3);
+    // t1 = tbar, t2 = (float)(tbar*tbar), t3 = (float)(tbar*tbar*tbar) (:418-419) and
+    // r = 1/(t1*t2*t3) come from the caller, which takes r out of a reciprocal it needs anyway:
+    // 1/t1, 1/t2, 1/t3 from the one reciprocal of the product (all three ~0.1 .. 0.5)
     const double i1 = r * (t2 * t3), i2 = r * (t1 * t3), i3 = r * (t1 * t2);
     const float den = to_float_checked(1.67752 + 2.20462 * i1 + 0.6366564 * i2 - 0.241605 * i3, risky);
     const float tbarx = to_float_checked(fsqrt(t1), risky);            // :417
@@ -456,12 +456,20 @@ __device__ __forceinline__ DayPre day_prefetch(const CellConst& c, double tc)
         // density at the float-rounded pressure (:413): same temperature polynomials
         const double pbar = (1.0e-5) * (double)c.patm_f;
         const double num = (dq.ko + dq.ca * pbar + dq.cb * (pbar * pbar));
-        const float rho = to_float_checked(num * frcp(num - pbar) * dq.po1000, risky);
-        const float rbar = to_float_checked((double)rho * (1.0 / 322.0), risky);          // :420
         const float tbar = to_float_checked(((double)tcf + 273.15) * (1.0 / 647.09600830078125), risky); // :416
+        // the density quotient and the three quotients of the tbar part share ONE reciprocal,
+        // 1/((num - pbar) * t1*t2*t3): a reciprocal is a quarter-rate seed and two Newton steps
+        // (~9 issue slots), splitting it afterwards two multiplies
+        const float tbar2 = tbar * tbar;                                   // :418
+        const float tbar3 = tbar * tbar * tbar;                            // :419
+        const double t1 = (double)tbar, t2 = (double)tbar2, t3 = (double)tbar3;
+        const double den_rho = num - pbar, ttt = t1 * t2 * t3;
+        const double rr = frcp(den_rho * ttt);
+        const float rho = to_float_checked(num * (rr * ttt) * dq.po1000, risky);
+        const float rbar = to_float_checked((double)rho * (1.0 / 322.0), risky);          // :420
         ir = __float_as_uint(rbar) - kViscR0;
         risky |= (ir >= kViscNR);
-        visc_tbar_part_fast(tbar, q.mu0, q.ctbar, risky);
+        visc_tbar_part_fast(tbar, t1, t2, t3, rr * den_rho, q.mu0, q.ctbar, risky);
         q.mode = risky ? 2 : 1;
         q.rbar = rbar;
         ir = risky ? 0u : ir;
@@ -588,6 +596,7 @@ __device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, 
     c.inv_wr = 1.0 / (c.Wmax - RES);
 
     c.int_perm = Ksat / kFluidity; // :1260
+    c.inv_kv24c = 1.0 / (24.0 * 3.6 * kG * c.int_perm);
     const double tan_slop = tan(slop * kPir); // :1278
     c.tan2_slop = tan_slop * tan_slop;
     c.inv_cos2 = 1.0 / (cs * cs);  // :2011
@@ -707,10 +716,13 @@ __device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d,
     const double dd = b2c2 - a * a;
     const double acc = a * cc;
     const double num = (dd < 0) ? acc : (acc + b * fsqrt(dd < 0 ? 0.0 : dd)); // :133-137
-    const double sinfirst = num * frcp(b2c2);
+    // 1/b2c2 and 1/rv (rv = b = cos(delta)*kb, an ordinary number for any real cell) from one
+    // reciprocal of their product
+    const double r_sol = frcp(b2c2 * b);
+    const double sinfirst = num * (r_sol * b);
     const double ru = -1 * a + cc * sinfirst;
     const double rv = b;
-    const double ruv = ru * frcp(rv); // rv = cos(delta)*kb: an ordinary number for any real cell
+    const double ruv = ru * (r_sol * b2c2);
 
     double hs, sin_hs; // :149-159: ruv >= 1 polar day (hs = 180), ruv <= -1 polar night (hs = 0)
     hour_angle(ruv, false, hs, sin_hs);
@@ -718,11 +730,14 @@ __device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d,
     const double ra_d = (86400.0 / kPI) * d.dr * kGsc * geo; // :164-165
 
     const double r_in = 86400 * sw_in;
+    // r_in/ra_d serves twice: as the transmittivity (:177) and, times dr*Gsc, as the
+    // r_in/((86400/pi)*geo) of :223 (ra_d = (86400/pi)*dr*Gsc*geo)
+    const double tau_raw = r_in * frcp(ra_d);
     double tau; // :174-178
     if (isnan(ra_d) || r_in == 0 || ra_d < r_in) {
         tau = c.tau_o;
     } else {
-        tau = r_in * frcp(ra_d); // here ra_d >= r_in > 0
+        tau = tau_raw; // here ra_d >= r_in > 0
     }
 #if defined(SPL_ABLATE) && SPL_ABLATE == 4
     double sf = (tau - c.tau_a) * c.tau_binv;
@@ -736,11 +751,7 @@ __device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d,
     }
     T.rnl = (0.0883289 + (1.0 - kB) * sf) * (kA + 1.95974 * tc); // :203
     // rw = (1 - alb) * xrw, :220-224
-    if ((sw_in == 0.0) || (hs == 0.0)) {
-        T.xrw = tau * d.dr * kGsc;
-    } else {
-        T.xrw = r_in * frcp((86400.0 / kPI) * geo);
-    }
+    T.xrw = (((sw_in == 0.0) || (hs == 0.0)) ? tau : tau_raw) * d.dr * kGsc;
     T.ru = ru;
     T.rv = rv;
     T.ruv = ruv;
@@ -748,36 +759,40 @@ __device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d,
     T.sin_hs = sin_hs;
 
     // ----- EVAP
-    double s; // sat_slope :299-301 (tc + 237.3 > 0 for any air temperature above -237 C)
-    {
-        const double inv_q = frcp(tc + 237.3);
-        s = fexp((tc * 17.269) * inv_q) * (inv_q * inv_q) * ((17.269) * (237.3) * (610.78));
-    }
-    double lv; // enthalpy_vap :313-315
-    {
-        const double u = tc + 273.15;
-        const double q = u * frcp(u - 33.91);
-        lv = q * q * 1.91846e6;
-    }
+    // Reciprocals are the dearest ordinary operation of the day step (a quarter-rate seed and two
+    // Newton steps, ~9 issue slots), so denominators that are known together share one: the
+    // reciprocal of their product, split by multiplications (each quotient 2-3 ulp).
+    // tc + 237.3 (sat_slope :299-301), tc + 239.24 and tc + 273.15 (enthalpy_vap :313-315 and its
+    // reciprocal in the psychrometric constant :486) are all > 0 for any air temperature
+    const double qa = tc + 237.3, u = tc + 273.15, qb = u - 33.91;
+    const double r_t = frcp(qa * qb * u);
+    const double inv_q = r_t * (qb * u);
+    const double s = fexp((tc * 17.269) * inv_q) * (inv_q * inv_q) * ((17.269) * (237.3) * (610.78));
+    const double qlv = u * (r_t * (qa * u));     // u/(u - 33.91)
+    const double lv = qlv * qlv * 1.91846e6;
+    const double qil = qb * (r_t * (qa * qb));   // (u - 33.91)/u
     const double pw = pre.pw;                                         // :113
-    const double g = (kMa * specific_heat(tc) * c.patm) * frcp(kMv * lv); // psychro :486
+    const double g = (kMa * specific_heat(tc) * c.patm) * ((qil * qil) * (1.0 / (kMv * 1.91846e6))); // psychro :486
     const double lvpw = lv * pw;
-    // econ = s/(lv*pw*(s+g)) (:117) and s/(lv*pw*(s+0.24g)) (:129) from one reciprocal
+    // econ = s/(lv*pw*(s+g)) (:117), its reciprocal and s/(lv*pw*(s+0.24g)) (:129)
     const double sg1 = s + g, sg2 = s + 0.24 * g;
-    const double inv_e = frcp(lvpw * sg1 * sg2);
+    const double d1 = lvpw * sg1, d2 = d1 * sg2;
+    const double r_e = frcp(d2 * s);
+    const double inv_e = r_e * s;
     T.econ = s * sg2 * inv_e;
-    T.inv_econ = frcp(T.econ);
+    T.inv_econ = d1 * (r_e * d2);                                     // lv*pw*(s+g)/s
     T.eetc = (1.0e3) * (s * sg1 * inv_e);                             // :129
     T.s = s;
     T.g = g;
     T.pw = pw;
-    T.ipk = 0.0;                                                      // :233-236
-    if (tc >= 3.0) {
-        T.ipk = frcp(pw * kKfus);
-    }
+    // 1/visc (Ksat_visc, src/SPLASH.cpp:1260-1261), 1/(24*Ksat_visc) (:1281) and 1/(pw*kfus)
+    // (:233-236) from the reciprocal of visc*pw
     const double visc = day_viscosity(c, pre, tc);                    // :100-105, :120
-    T.kv = c.int_perm * ((pw * kG) * frcp(visc)) * 3.6;               // src/SPLASH.cpp:1260-1261
-    T.ikv24 = frcp(T.kv * 24);
+    const double r_v = frcp(visc * pw);
+    const double inv_pw = r_v * visc;
+    T.ipk = (tc >= 3.0) ? inv_pw * (1.0 / kKfus) : 0.0;
+    T.kv = c.int_perm * ((pw * kG) * (r_v * pw)) * 3.6;
+    T.ikv24 = (visc * inv_pw) * c.inv_kv24c;
     T.tc = tc;
 }
 
@@ -795,6 +810,9 @@ __device__ __forceinline__ void evap_update(const CellConst& c, const DayTerms& 
     }
     const double rw = (1.0 - alb) * T.xrw; // :220-224
 
+    // (1/(rw*rv) keeps its own reciprocal: the cross-over angles hn and hi below are arc cosines of
+    // differences formed with it, near 1 for a low sun, where an ulp of the cosine is 1e4 ulp of
+    // the angle)
     const double inv_rwrv = frcp(rw * rv);
     const double xn = (rnl - rw * ru) * inv_rwrv; // :231
     double hn, sin_hn; // xn >= 1: net radiation negative all day (hn = 0)

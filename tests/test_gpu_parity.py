@@ -50,6 +50,13 @@ def test_evap_vs_reference_kat(api, kat):
     for j, name in enumerate(("cond", "eet", "pet", "aet", "snowmelt", "sublimation", "econ", "pw",
                               "rn_d", "visc", "pet_max")):
         scale = np.maximum(np.abs(ref[:, j]), 1e-6 * np.abs(ref[:, j]).max())
+        if name == "aet":
+            # aet is a difference of pet-sized terms in the cross-over angles hn and hi
+            # (src/EVAP.cpp:254-263), and for a low sun those are arc cosines near 1: the
+            # reference's own doubles are 1.6e-12 mm (3e-12 of pet) away from a long-double
+            # evaluation of the same statements on the supply-limited winter row that decides
+            # this bound (tools/debug_kat.py prints it).  1e-9 relative + 1e-11 of pet.
+            scale = scale + 1e-2 * np.abs(ref[:, 2])
         err = np.max(np.abs(out[:, j] - ref[:, j]) / scale)
         assert err < 1e-9, f"{name}: {err:.3e}"
 
