@@ -412,7 +412,7 @@ __device__ __forceinline__ void visc_tbar_part_fast(float tbar, double t1, doubl
     // 1/t1, 1/t2, 1/t3 from the one reciprocal of the product (all three ~0.1 .. 0.5)
     const double i1 = r * (t2 * t3), i2 = r * (t1 * t3), i3 = r * (t1 * t2);
     const float den = to_float_checked(1.67752 + 2.20462 * i1 + 0.6366564 * i2 - 0.241605 * i3, risky);
-    const float tbarx = to_float_checked(fsqrt(t1), risky);            // :417
+    const float tbarx = to_float_checked(fsqrt_nn(t1), risky);            // :417
     mu0_out = to_float_checked(1e2 * (double)tbarx * frcp((double)den), risky); // :424
     // :439: 1/tbar - 1 is ~1.0..1.4; the subtraction is exact enough (error of i1 is 2e-16 * 2.4)
     ctbar_out = to_float_checked(i1 - 1.0, risky);
@@ -665,7 +665,21 @@ __device__ __forceinline__ void hour_angle(double cosv, bool at_one_is_zero, dou
     sinh_ = x;
 #else
     h = facos(x);
-    sinh_ = fsqrt((1.0 - x) * (1.0 + x));
+    sinh_ = fsqrt_nn((1.0 - x) * (1.0 + x));
+#endif
+}
+
+// two hour angles whose cosines saturate at >= 1 -> 0 (hn and hi of evap_update), see hour_angle()
+__device__ __forceinline__ void hour_angle2(double cos1, double cos2, double& h1, double& sinh1,
+                                            double& h2, double& sinh2)
+{
+    const double x1 = fmin(fmax(cos1, -1.0), 1.0), x2 = fmin(fmax(cos2, -1.0), 1.0);
+#if defined(SPL_ABLATE) && SPL_ABLATE == 2
+    h1 = 1.0 - x1; sinh1 = x1; h2 = 1.0 - x2; sinh2 = x2;
+#else
+    facos2(x1, x2, h1, h2);
+    sinh1 = fsqrt_nn((1.0 - x1) * (1.0 + x1));
+    sinh2 = fsqrt_nn((1.0 - x2) * (1.0 + x2));
 #endif
 }
 
@@ -715,7 +729,7 @@ __device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d,
     const double b2c2 = b * b + cc * cc;
     const double dd = b2c2 - a * a;
     const double acc = a * cc;
-    const double num = (dd < 0) ? acc : (acc + b * fsqrt(dd < 0 ? 0.0 : dd)); // :133-137
+    const double num = (dd < 0) ? acc : (acc + b * fsqrt_nn(dd < 0 ? 0.0 : dd)); // :133-137
     // 1/b2c2 and 1/rv (rv = b = cos(delta)*kb, an ordinary number for any real cell) from one
     // reciprocal of their product
     const double r_sol = frcp(b2c2 * b);
@@ -815,16 +829,6 @@ __device__ __forceinline__ void evap_update(const CellConst& c, const DayTerms& 
     // the angle)
     const double inv_rwrv = frcp(rw * rv);
     const double xn = (rnl - rw * ru) * inv_rwrv; // :231
-    double hn, sin_hn; // xn >= 1: net radiation negative all day (hn = 0)
-    hour_angle(xn, true, hn, sin_hn);
-    const double rn_d = (hn * (rw * ru - rnl) + rw * rv * sin_hn) * (86400.0 / kPI); // :245-246
-    double rnn_d = rw * rv * (T.sin_hs - sin_hn);                                     // :252-255
-    rnn_d += rw * ru * (T.hs - hn);
-    rnn_d -= rnl * (kPI - hn);
-    rnn_d *= (86400.0 / kPI);
-
-    const double cn = (1.0e3) * econ * fabs(rnn_d) * 0.1;             // :124
-    const double eet_d = T.eetc * rn_d;                               // :129
     const double rx = (3.6e6) * econ;                                 // :145
     const double pet_max = rx * ((rw * (ru + rv)) - rnl);             // :148
 
@@ -835,8 +839,17 @@ __device__ __forceinline__ void evap_update(const CellConst& c, const DayTerms& 
         sup = 0.0;
     }
     const double cos_hi = (sup * (T.inv_econ * (1.0 / 3.6e6)) + rnl) * inv_rwrv - T.ruv; // :208
-    double hi, sin_hi; // cos_hi >= 1: supply exceeds demand (hi = 0)
-    hour_angle(cos_hi, true, hi, sin_hi);
+    // xn >= 1: net radiation negative all day (hn = 0); cos_hi >= 1: supply exceeds demand (hi = 0)
+    double hn, sin_hn, hi, sin_hi;
+    hour_angle2(xn, cos_hi, hn, sin_hn, hi, sin_hi);
+    const double rn_d = (hn * (rw * ru - rnl) + rw * rv * sin_hn) * (86400.0 / kPI); // :245-246
+    double rnn_d = rw * rv * (T.sin_hs - sin_hn);                                     // :252-255
+    rnn_d += rw * ru * (T.hs - hn);
+    rnn_d -= rnl * (kPI - hn);
+    rnn_d *= (86400.0 / kPI);
+
+    const double cn = (1.0e3) * econ * fabs(rnn_d) * 0.1;             // :124
+    const double eet_d = T.eetc * rn_d;                               // :129
 
     double snowmelt = 0.0, sublimation = 0.0, melt_enrg = 0.0; // :233-249
     if (T.tc >= 3.0) {
@@ -1063,7 +1076,7 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
 
     // :1275-1284
     const double hyd_grad_z = (infi * K.ikv24) - 1.0;
-    const double hyd_grad_out = fsqrt(hyd_grad_z * hyd_grad_z + c.tan2_slop);
+    const double hyd_grad_out = fsqrt_nn(hyd_grad_z * hyd_grad_z + c.tan2_slop);
 
     // :1291-1326 (cell-static part folded into kb_coef); Kb and log(Kb) keep the reference's
     // exp-then-log rounding.  Kb is only consumed under the two conditions below.

@@ -120,6 +120,23 @@ SPL_HD double fsqrt(double x)
 #endif
 }
 
+// The same for an argument that is known to be >= 0 (or NaN): the seed is taken of max(x, 1e-300),
+// so x = 0 gives y = 0 * 1e150 = 0 and stays 0 through the Heron steps -- one instruction instead
+// of the compare and two selects that patch rsq(0) = inf above.  NaN stays NaN (y = x * r).
+SPL_HD double fsqrt_nn(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = __builtin_amdgcn_rsq(fmax(x, 1.0e-300));
+    double y = x * r;
+    const double h = 0.5 * r;
+    y = fma(fma(-y, y, x), h, y);
+    y = fma(fma(-y, y, x), h, y);
+    return y;
+#else
+    return sqrt(x);
+#endif
+}
+
 // natural logarithm, table driven (Tang / glibc scheme), <~ 2 ulp; log(0) = -inf, log(x<0) = NaN.
 //   x = 2^k * z, z in [0.6875, 1.375);  log x = k*ln2 + log c_i + log1p(z/c_i - 1)
 // with (1/c_i, log c_i) from a 128-entry table indexed by the top 7 mantissa bits (offset so that
@@ -198,7 +215,15 @@ SPL_HD double fexp(double x)
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     const double y = ldexp(p, (int)k);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // NaN in, NaN out (the clamp above turned it into -746): patched in the high word alone --
+    // a compare and ONE select instead of two
+    const unsigned long long yb = __builtin_bit_cast(unsigned long long, y);
+    const unsigned hi = (x != x) ? 0x7FF80000u : (unsigned)(yb >> 32);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (yb & 0xFFFFFFFFull));
+#else
     return (x != x) ? x : y;
+#endif
 }
 
 // x^y for the bases the water balance uses (x >= 0 or NaN-producing x < 0), via exp(y*log x);
@@ -232,10 +257,41 @@ SPL_HD double facos(double x)
     // |x| <= 0.5: pi/2 - (x + x*r)
     const double a_small = pio2_hi - (x - (pio2_lo - x * r));
     // |x| > 0.5: 2*asin(sqrt(z)), reflected for x < 0
-    const double s = fsqrt(small ? 0.25 : z);
+    const double s = fsqrt_nn(small ? 0.25 : z);
     const double v = 2.0 * (s + r * s);
     const double a_large = (x < 0.0) ? pi - (v - 2.0 * pio2_lo) : v;
     return small ? a_small : a_large;
+}
+
+// Two arc cosines at once: the same evaluation as facos() for each, with the two rational
+// approximations sharing ONE reciprocal, 1/(q1*q2) (q in [0.3, 1]) -- the net-radiation and the
+// supply/demand cross-over angles of a day are needed together.
+SPL_HD void facos2(double x1, double x2, double& a1, double& a2)
+{
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
+    const double pi = 3.14159265358979311600e+00;
+    const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
+                 pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
+                 pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05;
+    const double qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00,
+                 qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
+    const double ax1 = fabs(x1), ax2 = fabs(x2);
+    const bool small1 = ax1 <= 0.5, small2 = ax2 <= 0.5;
+    const double z1 = small1 ? x1 * x1 : (1.0 - ax1) * 0.5;
+    const double z2 = small2 ? x2 * x2 : (1.0 - ax2) * 0.5;
+    const double p1 = z1 * horner5(pS5, z1, pS4, pS3, pS2, pS1, pS0);
+    const double p2 = z2 * horner5(pS5, z2, pS4, pS3, pS2, pS1, pS0);
+    const double q1 = fma(z1, horner3(qS4, z1, qS3, qS2, qS1), 1.0);
+    const double q2 = fma(z2, horner3(qS4, z2, qS3, qS2, qS1), 1.0);
+    const double rq = frcp(q1 * q2);
+    const double r1 = p1 * (rq * q2), r2 = p2 * (rq * q1);
+    const double s1 = fsqrt_nn(small1 ? 0.25 : z1), s2 = fsqrt_nn(small2 ? 0.25 : z2);
+    const double as1 = pio2_hi - (x1 - (pio2_lo - x1 * r1)), as2 = pio2_hi - (x2 - (pio2_lo - x2 * r2));
+    const double v1 = 2.0 * (s1 + r1 * s1), v2 = 2.0 * (s2 + r2 * s2);
+    const double al1 = (x1 < 0.0) ? pi - (v1 - 2.0 * pio2_lo) : v1;
+    const double al2 = (x2 < 0.0) ? pi - (v2 - 2.0 * pio2_lo) : v2;
+    a1 = small1 ? as1 : al1;
+    a2 = small2 ? as2 : al2;
 }
 
 } // namespace splash
