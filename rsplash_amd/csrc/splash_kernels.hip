@@ -134,7 +134,12 @@ struct Forcing {
     unsigned off; // cell * sizeof(double)
     static __device__ __forceinline__ double at(const double* row, unsigned off_bytes)
     {
-        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(row) + off_bytes);
+        // non-temporal: the forcing streams through once per pass and must not push the viscosity
+        // table (7.5 MB, gathered by every lane every day) out of the 4 MB L2 of an XCD -- with
+        // default-policy loads the gathers added 0.76 GB of fabric reads per 512x4096x365 launch
+        // (FETCH_SIZE, tools/pmc_fetch.sh), with non-temporal ones 0.09 GB
+        return __builtin_nontemporal_load(
+            reinterpret_cast<const double*>(reinterpret_cast<const char*>(row) + off_bytes));
     }
     __device__ __forceinline__ void raw(int t, double& a, double& b, double& c_) const
     {
