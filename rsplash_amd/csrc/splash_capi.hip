@@ -414,8 +414,9 @@ extern "C" size_t splash_dev_spin_up_work_size(size_t ncell)
     return spin_work_layout(ncell, nullptr, nullptr, nullptr, nullptr);
 }
 
-// phases [ph0, ph1) of the spin-up (see k_spin_phase): 0..2 finish all but a few cells per
-// thousand, 3 is the long tail
+// phases [ph0, ph1) of the spin-up (see k_spin_phase): all but the last finish all but a few cells
+// per thousand, the last is the long tail
+constexpr int kSpinPhases = 6;
 static int spin_phases(const splash_calendar* cal, size_t ncell, const double* sw_in,
                        const double* tc, const double* pn, size_t ldf, const double* Tt,
                        double* cellpar, size_t ldp, double* state, size_t lds, int* passes,
@@ -457,9 +458,14 @@ static int spin_phases(const splash_calendar* cal, size_t ncell, const double* s
     // pass budgets per phase; the last one covers the 1000-pass worst case of a spin-up
     // (src/SPLASH.cpp:1697).  With `passes` the first spin-up is iterated to its end as well (only
     // to count its passes), otherwise it is a single pass: see k_spin_phase.
-    static const int budget_full[] = {8, 16, 64, 2100}, budget_fast[] = {4, 4, 16, 1100};
+    // A wavefront runs as many passes as its slowest lane, so the early phases are short and the
+    // worklist is compacted after each (synthetic grid: 20-50 % of the cells need 2 passes of
+    // spin-up #2, 35-60 % 3, 6-20 % 4, 2-8 % 5, 3-12 % more): phase 0 = the pass of spin-up #1 + 2
+    // passes of #2 for every cell, then 1, 2, 4 and 16 passes for those that are left.
+    static const int budget_full[kSpinPhases] = {8, 8, 16, 32, 64, 2100},
+                     budget_fast[kSpinPhases] = {3, 1, 2, 4, 16, 1100};
     const int* budget = passes ? budget_full : budget_fast;
-    a.cache = (double*)(w + o_cache);
+    double* const cache_all = (double*)(w + o_cache);
     a.cache_cap = spin_cache_cap(ncell);
     a.ntotal = ncell;
     for (int ph = ph0; ph < ph1; ph++) {
@@ -469,7 +475,9 @@ static int spin_phases(const splash_calendar* cal, size_t ncell, const double* s
         a.n_in = ph == 0 ? nullptr : cnt + (ph - 1);
         a.wl_out = wl[ph & 1];
         a.n_out = cnt + ph;
-        a.pending = (ph == 2) ? (unsigned char*)(w + o_pend) : nullptr;
+        a.pending = (ph == kSpinPhases - 2) ? (unsigned char*)(w + o_pend) : nullptr;
+        // the cache of day terms pays from the second pass of a launch on
+        a.cache = budget[ph] >= 2 ? cache_all : nullptr;
         if (ph == 0) { // every cell, in blocks the size of the cache
             for (size_t c0 = 0; c0 < ncell; c0 += a.cache_cap) {
                 a.cell0 = c0;
@@ -491,7 +499,7 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
                                   int* passes, void* work, void* stream)
 {
     return spin_phases(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, passes, work,
-                       stream, 0, 4);
+                       stream, 0, kSpinPhases);
 }
 
 extern "C" int splash_dev_spin_up_begin(const splash_calendar* cal, size_t ncell,
@@ -501,7 +509,7 @@ extern "C" int splash_dev_spin_up_begin(const splash_calendar* cal, size_t ncell
                                         void* stream)
 {
     return spin_phases(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, passes, work,
-                       stream, 0, 3);
+                       stream, 0, kSpinPhases - 1);
 }
 
 extern "C" int splash_dev_spin_up_finish(const splash_calendar* cal, size_t ncell,
@@ -511,7 +519,7 @@ extern "C" int splash_dev_spin_up_finish(const splash_calendar* cal, size_t ncel
                                          void* stream)
 {
     return spin_phases(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, passes, work,
-                       stream, 3, 4);
+                       stream, kSpinPhases - 1, kSpinPhases);
 }
 
 extern "C" int splash_dev_spin_up_pending(void* work, size_t ncell, const unsigned char** mask,
@@ -522,8 +530,9 @@ extern "C" int splash_dev_spin_up_pending(void* work, size_t ncell, const unsign
     spin_work_layout(ncell, &o_wl_b, &o_meta, &o_ai, &o_cnt, &o_cache, &o_pend);
     char* w = (char*)work;
     if (mask) *mask = (const unsigned char*)(w + o_pend);
-    if (cells) *cells = (const uint32_t*)w; // phase 2 writes worklist 0
-    if (n_cells) *n_cells = (const uint32_t*)(w + o_cnt) + 2;
+    static_assert(((kSpinPhases - 2) & 1) == 0, "the phase before the tail writes worklist 0");
+    if (cells) *cells = (const uint32_t*)w;
+    if (n_cells) *n_cells = (const uint32_t*)(w + o_cnt) + (kSpinPhases - 2);
     return SPLASH_OK;
 }
 

@@ -320,6 +320,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             double sw0, tc0, pn0;
             f.raw(0, sw0, tc0, pn0);
             f.split<true>(d0, tc0, pn0, 0.0, r.rain, r.snf);
+            asm volatile("" : "+v"(r.rain), "+v"(r.snf)); // finished doubles, like the terms below
             day_terms(c, day_const(d0), day_prefetch(c, tc0), sw0, tc0, r.T);
             terms_fence(r.T);
             if (CACHED && cached) rec_store(a.cache, a.cache_cap, 0, sl, r);
@@ -387,6 +388,10 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 const DayRec d = day_rec(days, i);
                 DayRecord r;
                 f.split<true>(d, tcv, pnv, 0.0, r.rain, r.snf);
+                // rain and snowfall are finished doubles before the update uses them, as when they
+                // are read back from the cache: the same bits from either kernel variant and from
+                // any split of the passes over launches
+                asm volatile("" : "+v"(r.rain), "+v"(r.snf));
                 day_terms(c, day_const(d), pre, swv, tcv, r.T);
                 terms_fence(r.T);
                 asm volatile("" : : : "memory");
