@@ -651,7 +651,11 @@ __global__ __launch_bounds__(kBlock) void k_diag_finalize(const long long* __res
 // outputs in order: wn, ro, pet, aet, snow, cond, bflow, netr, sm_lim
 constexpr unsigned kOutMaskFive = 0x1Fu;
 
-template <bool MONTHLY, bool DIAG, unsigned OUTMASK>
+// SUBSET: the launch works on a list of cells (a.cells) and/or leaves out masked ones (a.skip) -- the
+// two ways splash_grid_run hides the spin-up's tail behind the transient run.  A variant of its own
+// (general output set), so that the plain launches carry no test for either and profiles list the
+// two kinds of launch under different names.
+template <bool MONTHLY, bool DIAG, unsigned OUTMASK, bool SUBSET = false>
 __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a)
 {
     lds_tables_init();
@@ -662,11 +666,11 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
     size_t cell = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool in_range = cell < a.ncell;
     const size_t sl = in_range ? cell : a.ncell - 1;        // position in this launch
-    const size_t ci = a.cells ? (size_t)a.cells[sl] : sl;   // the cell it works on
-    const size_t co = a.cells ? sl : ci;                    // the output column it writes
+    const size_t ci = (SUBSET && a.cells) ? (size_t)a.cells[sl] : sl; // the cell it works on
+    const size_t co = sl;                                             // the output column it writes
     // valid: the lane's results count (state, totals, monthly stores); a cell that is still
     // spinning up is computed like any other (from whatever state it has) but counts for nothing
-    const bool valid = in_range && !(a.skip && a.skip[ci]);
+    const bool valid = in_range && !(SUBSET && a.skip && a.skip[ci]);
     s_cell_Tt[threadIdx.x] = a.Tt ? a.Tt[ci] : 0.0; // own slot: no barrier needed
     Forcing f{a.sw, a.tc, a.pn, a.snowfall, a.ldf, 0.0,
               a.par[P_ELV * a.ldp + ci] * 0.0004596581, fabs(a.par[P_LAT * a.ldp + ci]) * 0.0110592101,
@@ -1266,7 +1270,19 @@ hipError_t launch_run_all(const RunArgs& a, hipStream_t s)
     unsigned mask = 0;
     for (int q = 0; q < 9; q++) mask |= (a.out[q] != nullptr ? 1u : 0u) << q;
     if (a.extra[0] || a.extra[1] || a.extra[2]) mask = 0x200u; // only the general variant stores them
-    if (a.monthly) {
+    if (a.cells || a.skip) {
+        if (a.monthly) {
+            if (diag)
+                hipLaunchKernelGGL((k_run_all<true, true, 0, true>), g, b, 0, s, a);
+            else
+                hipLaunchKernelGGL((k_run_all<true, false, 0, true>), g, b, 0, s, a);
+        } else {
+            if (diag)
+                hipLaunchKernelGGL((k_run_all<false, true, 0, true>), g, b, 0, s, a);
+            else
+                hipLaunchKernelGGL((k_run_all<false, false, 0, true>), g, b, 0, s, a);
+        }
+    } else if (a.monthly) {
         if (diag)
             hipLaunchKernelGGL((k_run_all<true, true, 0>), g, b, 0, s, a);
         else
