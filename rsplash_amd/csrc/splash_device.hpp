@@ -995,7 +995,7 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
     return Ksat_visc * 1e-3 * sm;
 #endif
     const double Theta = rel_saturation(c, sm);
-    const double L = flog(Theta);
+    const double L = flog<kLogFinite>(Theta); // sm <= SAT: Theta <= 1
     const double P = fexp(-L * c.inv_lambda); // Theta^(-1/lambda) in [1, +inf]
     const double psi_m = c.bub * P;           // bub / Theta^(1/lambda)
     double wtd = ((c.bub - psi_m) * 1.0e-3);
@@ -1025,7 +1025,8 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
         const double xs = psi_m + w1000;
         const double u = (xs - psi_m) * frcp(psi_m); // in (-1, 0] for a dry column (NaN if psi_m = -inf:
                                                       // T_uns then falls to the guard below, = 0)
-        const double l1p = (fabs(u) < 1.0e-5) ? u * (1.0 - u * (0.5 - u * (1.0 / 3.0))) : flog(1.0 + u);
+        const double l1p = (fabs(u) < 1.0e-5) ? u * (1.0 - u * (0.5 - u * (1.0 / 3.0)))
+                                              : flog<kLogPositive>(1.0 + u); // 1 + u in (0, 2] or NaN
         const double z = -c.e3l1 * l1p;
         const double em1 = (fabs(z) < 1.0e-5) ? z * (1.0 + z * (0.5 + z * (1.0 / 6.0))) : fexp(z) - 1.0;
         diff = -A * em1;
@@ -1155,7 +1156,9 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
         }
         const double Q = (T * c.Ai) * 1.0e-3; // :1456
         const double Qt = (Ksat_visc * c.qt_coef) * hyd_grad_out; // :1360
-        t_drain = -1.0 * flog(1.0 - (lkb * (c.Au * R / Q))) / lkb;
+        // (R/Q stays an IEEE division: Q = 0 -- a transmittance of exactly zero -- must give the
+        // reference's +inf; 1/lkb is NaN for lkb = 0 either way: the sticky NaN of flat terrain)
+        t_drain = (-1.0 * flog(1.0 - (lkb * (c.Au * R / Q)))) * frcp(lkb);
         q_in_f = (Qt - c.Au * R * lkb) * c.inv_Ai;
     }
     if (q_in_f < 0.0 || isnan(q_in_f)) {

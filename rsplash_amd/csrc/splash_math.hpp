@@ -162,6 +162,12 @@ __device__ __forceinline__ void math_tables_init()
 static const double kLogTabHost[256] = {SPL_LOG_TABLE_VALUES};
 #endif
 
+// kLogFull: every special value patched (log(+inf) = +inf, log(0) = -inf, log(x<0) = log(NaN) = NaN).
+// kLogFinite: the caller's argument is never +inf (a relative saturation, <= 1): that patch is left out.
+// kLogPositive: the argument is a positive finite number or NaN (1 + u of the transmittance): only
+//   NaN is patched, in the high word.
+enum LogDomain { kLogFull = 0, kLogFinite = 1, kLogPositive = 2 };
+template <int DOMAIN = kLogFull>
 SPL_HD double flog(double x)
 {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
@@ -191,7 +197,12 @@ SPL_HD double flog(double x)
     const double hi_ = fma(kd, ln2_hi, logc);
     const double lo_ = fma(kd, ln2_lo, r2 * p);
     double res = (hi_ + r) + lo_;
-    res = (x < HUGE_VAL) ? res : x;                 // +inf (NaN falls through to the next line)
+    if (DOMAIN == kLogPositive) {
+        const unsigned long long rb = __builtin_bit_cast(unsigned long long, res);
+        const unsigned rh = (x != x) ? 0x7FF80000u : (unsigned)(rb >> 32);
+        return __builtin_bit_cast(double, ((unsigned long long)rh << 32) | (rb & 0xFFFFFFFFull));
+    }
+    if (DOMAIN == kLogFull) res = (x < HUGE_VAL) ? res : x; // +inf (NaN falls through to the next line)
     res = (x > 0.0) ? res : ((x == 0.0) ? -HUGE_VAL : __builtin_nan("")); // 0 -> -inf, <0/NaN -> NaN
     return res;
 }
@@ -229,7 +240,7 @@ SPL_HD double fexp(double x)
 // x^y for the bases the water balance uses (x >= 0 or NaN-producing x < 0), via exp(y*log x);
 // relative error ~ (1 + |y*log x|) ulp.  pow(0, y>0) = 0, pow(x<0, y) = NaN as in libm for
 // non-integer y (the reference relies on that NaN, src/SPLASH.cpp:1951-1955).
-SPL_HD double fpow(double x, double y) { return fexp(y * flog(x)); }
+SPL_HD double fpow(double x, double y) { return fexp(y * flog<>(x)); }
 
 // arc cosine in radians, |x| <= 1 (callers guard the range), < 2.5 ulp.
 // fdlibm e_acos.c scheme (rational approximation R(z) of (asin(t)-t)/t^3 on t^2 = z <= 0.25,
