@@ -1435,35 +1435,84 @@ hipError_t launch_synth_forcing(uint64_t seed, const DayRec* days, int t0, int n
 // by three consecutive workgroup rows: L2 hits), 8 B in + up to 40 B out per cell: HBM bound.
 // The arithmetic of raster::terrain / raster::area lives in a package that is not vendored in the
 // reference: this restates the published algorithm, parity unpinned.
+// Everything that depends on the row alone -- latitude, metric cell size, the three D8 distances
+// and their reciprocals: a cosine, two square roots and five divisions -- is computed once per ROW
+// by k_terrain_rows and read by k_terrain with scalar loads (the row is uniform in a workgroup).
+constexpr int kRowTerms = 10;
+__global__ __launch_bounds__(kBlock) void k_terrain_rows(int H, double ymax, double yres, double xres,
+                                                        double* __restrict__ rows)
+{
+    const int r = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (r >= H) return;
+    const double Rearth = 6378137.0;
+    const double lat = ymax - ((double)r + 0.5) * yres;
+    const double dy = Rearth * (yres * kPir);
+    const double dx = Rearth * cos(lat * kPir) * (xres * kPir);
+    const double dd = sqrt(dx * dx + dy * dy);
+    double* o = rows + (size_t)r * kRowTerms;
+    o[0] = lat;
+    o[1] = dx;
+    o[2] = dy;
+    o[3] = dd;
+    o[4] = sqrt(dx * dy);
+    o[5] = 1.0 / dx;
+    o[6] = 1.0 / dy;
+    o[7] = 1.0 / dd;
+    o[8] = 1.0 / (8.0 * dx);
+    o[9] = 1.0 / (8.0 * dy);
+}
+
+// One lane walks a strip of kStripRows rows of its column with the 3x3 window in registers: three
+// new elevations per cell instead of nine (the window rows slide down), and kStripRows cells per
+// lane to amortise the launch of a wavefront.  Grid: x = column blocks of kBlock, y = row strips.
+// Quotients by the row's distances are formed with div_cr() (the correctly rounded a/b from
+// y = RN(1/b): bit-identical to the division they replace, so the D8 code -- an argmax over
+// quotients -- cannot change).
+constexpr int kStripRows = 16;
+__device__ __forceinline__ void window_row(const double* __restrict__ p, int H, int W, int r, int c,
+                                           double& l, double& m, double& rt)
+{
+    // the three values of row r at columns c-1, c, c+1; NA outside the grid.  The reads come from
+    // clamped positions, so none of them depends on a branch (all in flight together).
+    const int rc = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
+    const double* q = p + (size_t)rc * W;
+    const double a = q[c > 0 ? c - 1 : 0], b = q[c], d = q[c < W - 1 ? c + 1 : W - 1];
+    const bool rin = r >= 0 && r < H;
+    const double na = __builtin_nan("");
+    l = (rin && c > 0) ? a : na;
+    m = rin ? b : na;
+    rt = (rin && c < W - 1) ? d : na;
+}
+
 __global__ __launch_bounds__(kBlock) void k_terrain(int H, int W, const double* __restrict__ elev,
-                                                   double ymax, double yres, double xres,
-                                                   int na_to_zero, double* __restrict__ slope,
+                                                   const double* __restrict__ rows, int na_to_zero,
+                                                   double* __restrict__ slope,
                                                    double* __restrict__ aspect,
                                                    double* __restrict__ lat_o,
                                                    double* __restrict__ res_o,
                                                    double* __restrict__ flowdir)
 {
-    const size_t n = (size_t)H * W;
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const int r = (int)(i / W), cidx = (int)(i % W);
-    const double Rearth = 6378137.0;
-    const double lat = ymax - ((double)r + 0.5) * yres;
-    const double dy = Rearth * (yres * kPir);
-    const double dx = Rearth * cos(lat * kPir) * (xres * kPir);
-    const double z = elev[i];
-    if (lat_o) lat_o[i] = (z == z) ? lat : __builtin_nan("");
-    if (res_o) res_o[i] = (z == z) ? sqrt(dx * dy) : __builtin_nan("");
+    const int cidx = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (cidx >= W) return;
+    for (int r0 = (int)blockIdx.y * kStripRows; r0 < H; r0 += (int)gridDim.y * kStripRows) {
+    double a, b, c, d, z, f, g, h, k; // a b c / d z f / g h k  (north row first)
+    window_row(elev, H, W, r0 - 1, cidx, a, b, c);
+    window_row(elev, H, W, r0, cidx, d, z, f);
+    const int r1 = r0 + kStripRows < H ? r0 + kStripRows : H;
+    for (int r = r0; r < r1; r++) {
+    window_row(elev, H, W, r + 1, cidx, g, h, k);
+    const double* s_row = rows + (size_t)r * kRowTerms;
+    const size_t i = (size_t)r * W + cidx;
+    const double lat = s_row[0], dx = s_row[1], dy = s_row[2], dd = s_row[3];
+    if (lat_o) __builtin_nontemporal_store((z == z) ? lat : __builtin_nan(""), lat_o + i);
+    if (res_o) __builtin_nontemporal_store((z == z) ? s_row[4] : __builtin_nan(""), res_o + i);
     const bool inner = r > 0 && r < H - 1 && cidx > 0 && cidx < W - 1;
     double sl = __builtin_nan(""), as = __builtin_nan(""), fd = __builtin_nan("");
     if (inner && z == z) {
-        const double a = elev[i - W - 1], b = elev[i - W], c = elev[i - W + 1];
-        const double d = elev[i - 1], f = elev[i + 1];
-        const double g = elev[i + W - 1], h = elev[i + W], k = elev[i + W + 1];
         const double sum8 = a + b + c + d + f + g + h + k; // NaN if any neighbour is NA
         if (sum8 == sum8) {
-            const double zx = ((c + 2.0 * f + k) - (a + 2.0 * d + g)) / (8.0 * dx); // eastward
-            const double zy = ((a + 2.0 * b + c) - (g + 2.0 * h + k)) / (8.0 * dy); // northward
+            const double zx = div_cr((c + 2.0 * f + k) - (a + 2.0 * d + g), 8.0 * dx, s_row[8]); // eastward
+            const double zy = div_cr((a + 2.0 * b + c) - (g + 2.0 * h + k), 8.0 * dy, s_row[9]); // northward
             sl = atan(sqrt(zx * zx + zy * zy)) / kPir;
             if (zx == 0.0 && zy == 0.0) {
                 as = 90.0;
@@ -1473,16 +1522,16 @@ __global__ __launch_bounds__(kBlock) void k_terrain(int H, int W, const double* 
             }
         }
         // D8: largest drop per unit distance (diagonals are sqrt(dx^2+dy^2) away)
-        const double dd = sqrt(dx * dx + dy * dy);
         const double nb[8] = {f, k, h, g, d, a, b, c};             // E SE S SW W NW N NE
         const double dist[8] = {dx, dd, dy, dd, dx, dd, dy, dd};
+        const double idist[8] = {s_row[5], s_row[7], s_row[6], s_row[7], s_row[5], s_row[7], s_row[6], s_row[7]};
         double best = -__builtin_inf();
         int code = 0;
         bool any = false;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             if (nb[q] == nb[q]) {
-                const double drop = (z - nb[q]) / dist[q];
+                const double drop = div_cr(z - nb[q], dist[q], idist[q]);
                 if (drop > best) {
                     best = drop;
                     code = 1 << q;
@@ -1496,44 +1545,46 @@ __global__ __launch_bounds__(kBlock) void k_terrain(int H, int W, const double* 
         if (sl != sl) sl = 0.0;
         if (as != as) as = 0.0;
     }
-    if (slope) slope[i] = sl;
-    if (aspect) aspect[i] = as;
-    if (flowdir) flowdir[i] = fd;
+    if (slope) __builtin_nontemporal_store(sl, slope + i);
+    if (aspect) __builtin_nontemporal_store(as, aspect + i);
+    if (flowdir) flowdir[i] = fd; // read again by k_ncellflow: default cache policy
+    a = d; b = z; c = f; // the window slides down one row
+    d = g; z = h; f = k;
+    }
+    }
 }
-
-// ncellflow (R/upslope_area.R:140-165): how many of a cell's 3x3 neighbourhood carry the flow code
-// given for their window position (codes[9], window in row order: the matrix(c(2,1,128,4,0,64,8,16,
-// 32), nrow=3) of 'in'/'top', its reverse for 'out').  NA when the whole window is NA; positions
-// that are NA do not count; a count of 0 becomes 1 (:157).  Edge cells see NA outside the grid
-// (pad = 1, focal(pad=TRUE)) or are NA themselves (pad = 0: raster::focal's default).
 __global__ __launch_bounds__(kBlock) void k_ncellflow(int H, int W, const double* __restrict__ fd,
                                                      const double* __restrict__ codes, int pad,
                                                      double* __restrict__ out)
 {
-    const size_t n = (size_t)H * W;
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const int r = (int)(i / W), c = (int)(i % W);
-    const bool edge = r == 0 || r == H - 1 || c == 0 || c == W - 1;
-    if (edge && !pad) {
-        out[i] = __builtin_nan("");
-        return;
-    }
-    int nna = 0, nmatch = 0;
+    // strips of kStripRows rows per lane, 3x3 window of flow codes in registers (see k_terrain)
+    const int c = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (c >= W) return;
+    double code[9];
 #pragma unroll
-    for (int q = 0; q < 9; q++) {
-        const int rr = r + q / 3 - 1, cc = c + q % 3 - 1;
-        double v = __builtin_nan("");
-        if (rr >= 0 && rr < H && cc >= 0 && cc < W) v = fd[(size_t)rr * W + cc];
-        if (v != v) {
-            nna++;
-        } else if (v == codes[q]) {
-            nmatch++;
+    for (int q = 0; q < 9; q++) code[q] = codes[q];
+    for (int r0 = (int)blockIdx.y * kStripRows; r0 < H; r0 += (int)gridDim.y * kStripRows) {
+        double v[9];
+        window_row(fd, H, W, r0 - 1, c, v[0], v[1], v[2]);
+        window_row(fd, H, W, r0, c, v[3], v[4], v[5]);
+        const int r1 = r0 + kStripRows < H ? r0 + kStripRows : H;
+        for (int r = r0; r < r1; r++) {
+            window_row(fd, H, W, r + 1, c, v[6], v[7], v[8]);
+            const size_t i = (size_t)r * W + c;
+            const bool edge = r == 0 || r == H - 1 || c == 0 || c == W - 1;
+            int nna = 0, nmatch = 0;
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                nna += (v[q] != v[q]) ? 1 : 0;
+                nmatch += (v[q] == code[q]) ? 1 : 0;
+            }
+            double res = (double)(nmatch == 0 ? 1 : nmatch);
+            if (nna == 9 || (edge && !pad)) res = __builtin_nan("");
+            __builtin_nontemporal_store(res, out + i);
+#pragma unroll
+            for (int q = 0; q < 6; q++) v[q] = v[q + 3];
         }
     }
-    double res = (double)(nmatch == 0 ? 1 : nmatch);
-    if (nna == 9) res = __builtin_nan("");
-    out[i] = res;
 }
 
 hipError_t launch_terrain(int H, int W, const double* elev, double ymax, double yres, double xres,
@@ -1542,9 +1593,18 @@ hipError_t launch_terrain(int H, int W, const double* elev, double ymax, double 
 {
     const size_t n = (size_t)H * W;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_terrain, dim3(nblk(n, kBlock)), dim3(kBlock), 0, s, H, W, elev, ymax, yres,
-                       xres, na_to_zero, slope, aspect, lat, res, flowdir);
-    return hipGetLastError();
+    double* rows = nullptr; // stream-ordered scratch: 80 bytes per row
+    hipError_t e = hipMallocAsync((void**)&rows, (size_t)H * kRowTerms * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_terrain_rows, dim3(nblk((size_t)H, kBlock)), dim3(kBlock), 0, s, H, ymax, yres, xres,
+                       rows);
+    const unsigned strips = nblk((size_t)H, kStripRows);
+    hipLaunchKernelGGL(k_terrain, dim3(nblk((size_t)W, kBlock), strips < 65535 ? strips : 65535),
+                       dim3(kBlock), 0, s, H, W, elev, rows, na_to_zero, slope, aspect, lat, res, flowdir);
+    e = hipGetLastError();
+    (void)hipFreeAsync(rows, s);
+    return e;
+    
 }
 
 hipError_t launch_ncellflow(int H, int W, const double* fd, const double* codes, int pad,
@@ -1552,7 +1612,9 @@ hipError_t launch_ncellflow(int H, int W, const double* fd, const double* codes,
 {
     const size_t n = (size_t)H * W;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_ncellflow, dim3(nblk(n, kBlock)), dim3(kBlock), 0, s, H, W, fd, codes, pad, out);
+    const unsigned strips = nblk((size_t)H, kStripRows);
+    hipLaunchKernelGGL(k_ncellflow, dim3(nblk((size_t)W, kBlock), strips < 65535 ? strips : 65535), dim3(kBlock),
+                       0, s, H, W, fd, codes, pad, out);
     return hipGetLastError();
 }
 
