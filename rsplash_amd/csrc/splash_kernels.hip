@@ -932,24 +932,31 @@ __global__ __launch_bounds__(kBlock) void k_unswc(size_t ncell, int nt,
     const double u1000 = uns_depth * 1000;
     const double inv_lm1 = 1 / (lambda - 1);
     const double inv_d1000 = 1 / d1000, inv_dth = 1 / dth, inv_u1000 = 1 / u1000;
+    // the next step's column water is requested a step ahead and waited for before this step's
+    // stores are issued (loads and stores share one counter: see k_run_all)
+    double w_next = nt > 0 ? __builtin_nontemporal_load(&wn[i]) : 0.0;
+    asm volatile("" : "+v"(w_next) : : "memory");
     for (int t = 0; t < nt; t++) {
-        const double w = __builtin_nontemporal_load(&wn[(size_t)t * ldw + i]) * gfac; // :56
+        const double w = w_next * gfac; // :56
+        w_next = __builtin_nontemporal_load(&wn[(size_t)(t + 1 < nt ? t + 1 : t) * ldw + i]);
         double theta_i = w * inv_d1000;                                               // :64-66
         if (theta_i >= theta_s) theta_i = theta_s - 0.0001;
         if (theta_i <= theta_r) theta_i = theta_r + 0.0001;
-        const double L = flog((theta_i - theta_r) * inv_dth);
+        const double Theta = (theta_i - theta_r) * inv_dth; // in (0, 1) after the two clamps (or NaN)
+        const double L = flog<kLogPositive>(Theta);
         const double psi_m = bub * fexp(-L * inv_lambda); // bub / Theta^(1/lambda), :67
         const double wtdini = (bub - psi_m) * 1.0e-3;     // UnsWater, :36-37
         const double wtd = (wtdini > depth) ? depth : ((wtdini < 0) ? 0 : wtdini);
         const double z_uns = (wtd <= uns_depth) ? wtd * 1000 : u1000; // :39
-        // :41-43  (bub/(psi_m+z))^lambda = exp(lambda*log(..)); at z = 0 the base is Theta^(1/lambda)
-        const double pz = fexp(lambda * flog(bub * frcp(psi_m + z_uns))); // psi_m + z <= bub < 0
-        const double p0 = fexp(L); // (bub/psi_m)^lambda = Theta
+        // :41-43  (bub/(psi_m+z))^lambda = exp(lambda*log(..)); psi_m + z <= bub < 0: the base is in (0, 1]
+        const double pz = fexp(lambda * flog<kLogPositive>(bub * frcp(psi_m + z_uns)));
+        const double p0 = Theta; // (bub/psi_m)^lambda at z = 0 is Theta itself
         const double w_uns_z = theta_r * z_uns + (((psi_m + z_uns) * (theta_r - theta_s) * pz) * inv_lm1);
         const double w_uns_0 = ((psi_m * (theta_r - theta_s) * p0) * inv_lm1);
         const double sat_swc = (wtd <= uns_depth) ? theta_s * (uns_depth - wtd) * 1000 : 0; // :46
         double swc_tot = (w_uns_z - w_uns_0) + sat_swc;
         if (swc_tot <= 0) swc_tot = theta_r * u1000; // :74
+        asm volatile("" : "+v"(w_next) : : "memory"); // the next step's load has landed
         const size_t k = (size_t)t * ldo + i;
         if (theta_o) __builtin_nontemporal_store(swc_tot * inv_u1000, &theta_o[k]); // :80
         if (wn_z) __builtin_nontemporal_store(swc_tot * gout, &wn_z[k]);       // :82
