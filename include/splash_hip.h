@@ -225,6 +225,24 @@ int splash_dev_terrain(int H, int W, const double* elev, double ymax, double yre
  * pad = 0: outer ring NA (raster::focal's default); pad = 1: NA outside the grid. */
 int splash_dev_ncellflow(int H, int W, const double* flowdir, const double* codes9, int pad,
                          double* ncell, void* stream);
+/* Sink filling (R/upslope_area.R:15-16 `topmodel::sinkfill(as.matrix(dem), resolution, 1)`; :68 TauDEM
+ * pitremove): the surface is raised until every cell has a path to an outlet (grid edge or NA
+ * neighbour) that descends by at least tan(degree) * resolution_m per cell (sqrt 2 times that
+ * along diagonals); degree = 0 fills to level.  NA stays NA.  filled: [H*W], not elev itself.
+ * sweeps (optional, host): relaxation sweeps run.  The third-party codes are not in the reference
+ * tree: this is Planchon & Darboux (2002) (parity unpinned).  Synchronises the stream. */
+int splash_dev_sinkfill(int H, int W, const double* elev, double resolution_m, double degree,
+                        double* filled, int* sweeps, void* stream);
+/* Contributing area by D8 accumulation (R/upslope_area.R:21 `topidx()$area`; :74 TauDEM aread8 and
+ * :85-96): ups_ncell = number of cells draining through a cell, itself included (>= 1 wherever
+ * there is a cell: the reference's fix_coast); ups_area = ups_ncell * resolution_m^2 (the reference's
+ * ups_ncell * cell area).  flowdir: raster's codes (splash_dev_terrain) or, tau_codes = 1, TauDEM's
+ * 1..8.  elev (optional) says where cells are (NaN = none); without it, where flowdir is not NaN.
+ * Cells on a closed loop of codes (pits left unfilled) keep what drains into them and pass nothing
+ * on.  levels (optional, host): host-synchronised levels of the order.  Synchronises the stream. */
+int splash_dev_flow_accumulation(int H, int W, const double* flowdir, const double* elev,
+                                 int tau_codes, const double* resolution_m, double* ups_ncell,
+                                 double* ups_area, int* levels, void* stream);
 
 /* ---------------------------------------------------------------- unSWC epilogue */
 /* R/unsSWC.R:14-88 / R/unsSWC.grid.R: from the column water content wn [mm] (output of the path

@@ -126,6 +126,8 @@ class Oracle:
             [_dp, C.POINTER(_dp), C.c_void_p, C.c_double, C.c_void_p, C.c_int]
         L.orc_terrain.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_double, C.c_double, C.c_int] + [_dp] * 5
         L.orc_ncellflow.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
+        L.orc_sinkfill.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_double, _dp]
+        L.orc_flow_accumulation.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]
         L.orc_synth_statics.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int] + \
             [_dp] * 7
         L.orc_synth_forcing.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
@@ -351,6 +353,29 @@ class Oracle:
             o[name] = np.empty((H, W))
             self.lib.orc_ncellflow(H, W, o["flowdir"].ctypes.data_as(_dp), c9p, 0, o[name].ctypes.data_as(_dp))
         return o
+
+    def sinkfill(self, elev, resolution_m, degree=1.0):
+        """Planchon & Darboux relaxation (serial restatement of the published algorithm)"""
+        e, ep = _d(elev)
+        H, W = e.shape
+        out = np.empty((H, W))
+        self.lib.orc_sinkfill(H, W, ep, C.c_double(resolution_m), C.c_double(degree), out.ctypes.data_as(_dp))
+        return out
+
+    def flow_accumulation(self, flowdir, elev=None, resolution=None, tau=False):
+        f, fp = _d(flowdir)
+        H, W = f.shape
+        ep = rp = None
+        if elev is not None:
+            e_, ep = _d(elev)
+        cnt, area = np.empty((H, W)), None
+        ap = None
+        if resolution is not None:
+            r_, rp = _d(resolution)
+            area = np.empty((H, W))
+            ap = area.ctypes.data_as(_dp)
+        self.lib.orc_flow_accumulation(H, W, fp, ep, int(bool(tau)), rp, cnt.ctypes.data_as(_dp), ap)
+        return cnt, area
 
     def synth_statics(self, seed, H, W, cell0, ncell, terrain):
         lat, elev, slop, asp, res = (np.empty(ncell) for _ in range(5))

@@ -1726,6 +1726,102 @@ void orc_ncellflow(int H, int W, const double* fd, const double* codes9, int pad
     }
 }
 
+/* Sink filling and D8 contributing area: the remaining steps of R/upslope_area.R (:15-16
+ * topmodel::sinkfill, :21 topidx()$area; :68-74 TauDEM pitremove/aread8; :85-96 fix_coast and
+ * ups_ncell * cell area).  The third-party codes are not in the reference tree (parity unpinned):
+ * these are plain serial statements of the published algorithms the product implements --
+ * Planchon & Darboux (2002) relaxation, Kahn-ordered D8 accumulation -- written independently of
+ * the kernels (raster-order sweeps; an explicit FIFO). */
+void orc_sinkfill(int H, int W, const double* z, double resolution_m, double degree, double* w)
+{
+    const double eps = tan(degree * G_pir) * resolution_m, eps_d = eps * sqrt(2.0);
+    for (int r = 0; r < H; r++)
+        for (int c = 0; c < W; c++) {
+            size_t i = (size_t)r * W + c;
+            int outlet = (r == 0 || r == H - 1 || c == 0 || c == W - 1);
+            if (!outlet)
+                for (int q = 0; q < 9; q++)
+                    if (isnan(z[(size_t)(r + q / 3 - 1) * W + (c + q % 3 - 1)])) outlet = 1;
+            w[i] = isnan(z[i]) ? z[i] : (outlet ? z[i] : INFINITY);
+        }
+    int changed = 1;
+    while (changed) {
+        changed = 0;
+        for (int pass = 0; pass < 2; pass++) /* down-right, then up-left */
+            for (int rr = 1; rr < H - 1; rr++)
+                for (int cc = 1; cc < W - 1; cc++) {
+                    int r = pass ? H - 1 - rr : rr, c = pass ? W - 1 - cc : cc;
+                    size_t i = (size_t)r * W + c;
+                    if (!(w[i] > z[i])) continue;
+                    double m = INFINITY;
+                    for (int q = 0; q < 9; q++) {
+                        if (q == 4) continue;
+                        double cand = w[(size_t)(r + q / 3 - 1) * W + (c + q % 3 - 1)] + ((q & 1) ? eps : eps_d);
+                        if (cand < m) m = cand;
+                    }
+                    double nw = (m > z[i]) ? m : z[i];
+                    if (nw < w[i]) {
+                        w[i] = nw;
+                        changed = 1;
+                    }
+                }
+    }
+}
+
+static long long orc_d8_target(double code, int tau, int r, int c, int H, int W)
+{
+    static const int DR[8] = {0, 1, 1, 1, 0, -1, -1, -1}, DC[8] = {1, 1, 0, -1, -1, -1, 0, 1}; /* E SE S SW W NW N NE */
+    if (!(code >= 1.0) || code != floor(code)) return -1;
+    int k = (int)code, q = -1;
+    if (tau) {
+        static const int TAU[9] = {-1, 0, 7, 6, 5, 4, 3, 2, 1}; /* 1 E, 2 NE, 3 N, 4 NW, 5 W, 6 SW, 7 S, 8 SE */
+        if (k > 8) return -1;
+        q = TAU[k];
+    } else {
+        for (int b = 0; b < 8; b++)
+            if (k == (1 << b)) q = b;
+        if (q < 0) return -1;
+    }
+    int rr = r + DR[q], cc = c + DC[q];
+    if (rr < 0 || rr >= H || cc < 0 || cc >= W) return -1;
+    return (long long)rr * W + cc;
+}
+
+void orc_flow_accumulation(int H, int W, const double* fd, const double* elev, int tau,
+                           const double* resolution, double* ups_ncell, double* ups_area)
+{
+    size_t n = (size_t)H * W;
+    long long* tgt = (long long*)malloc(n * sizeof(long long));
+    int* indeg = (int*)calloc(n, sizeof(int));
+    double* cnt = (double*)malloc(n * sizeof(double));
+    size_t* fifo = (size_t*)malloc(n * sizeof(size_t));
+    for (size_t i = 0; i < n; i++) {
+        int cell = elev ? !isnan(elev[i]) : !isnan(fd[i]);
+        cnt[i] = cell ? 1.0 : NAN;
+        tgt[i] = cell ? orc_d8_target(fd[i], tau, (int)(i / W), (int)(i % W), H, W) : -1;
+    }
+    for (size_t i = 0; i < n; i++)
+        if (tgt[i] >= 0 && !isnan(cnt[tgt[i]])) indeg[tgt[i]]++;
+    size_t head = 0, tail = 0;
+    for (size_t i = 0; i < n; i++)
+        if (!isnan(cnt[i]) && indeg[i] == 0) fifo[tail++] = i;
+    while (head < tail) {
+        size_t i = fifo[head++];
+        long long t = tgt[i];
+        if (t < 0 || isnan(cnt[t])) continue;
+        cnt[t] += cnt[i];
+        if (--indeg[t] == 0) fifo[tail++] = (size_t)t;
+    }
+    for (size_t i = 0; i < n; i++) {
+        if (ups_ncell) ups_ncell[i] = cnt[i];
+        if (ups_area) ups_area[i] = cnt[i] * (resolution[i] * resolution[i]); /* x*y*1e6 with y in km2 */
+    }
+    free(tgt);
+    free(indeg);
+    free(cnt);
+    free(fifo);
+}
+
 /* ------------------------------------------------------------------ synthetic inputs */
 
 static inline uint64_t mix64(uint64_t z)

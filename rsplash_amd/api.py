@@ -531,10 +531,52 @@ def dev_ncellflow(H, W, flowdir, codes9, out, pad=False, stream=None):
                                    _ptr(out), stream), "splash_dev_ncellflow")
 
 
+def dev_sinkfill(H, W, elev, resolution_m, filled, degree=1.0, stream=None):
+    """R/upslope_area.R:15-16 (sinkfill(as.matrix(dem), resolution, 1)) on a device raster; returns the
+    number of relaxation sweeps (see include/splash_hip.h: splash_dev_sinkfill)"""
+    n = C.c_int(0)
+    check(lib.splash_dev_sinkfill(int(H), int(W), _ptr(elev), float(resolution_m), float(degree),
+                                  _ptr(filled), C.byref(n), stream), "splash_dev_sinkfill")
+    return n.value
+
+
+def dev_flow_accumulation(H, W, flowdir, ups_ncell=None, ups_area=None, elev=None, resolution=None,
+                          tau_codes=False, stream=None):
+    """R/upslope_area.R:21 / :74, 85-96: cells draining through each cell and the contributing area
+    in m2; returns the number of host-synchronised levels"""
+    n = C.c_int(0)
+    check(lib.splash_dev_flow_accumulation(int(H), int(W), _ptr(flowdir), _ptr(elev), int(bool(tau_codes)),
+                                           _ptr(resolution), _ptr(ups_ncell), _ptr(ups_area),
+                                           C.byref(n), stream), "splash_dev_flow_accumulation")
+    return n.value
+
+
+def upslope_area(dem, ymax, yres, xres, degree=1.0):
+    """upslope_area(dem, resolution) of R/upslope_area.R:12-58 for a host lon/lat elevation array
+    [H, W]: sink fill with the mean resolution (:14-16), contributing area (:21), flow direction of
+    the FILLED surface and the cells draining in and out (:31-33).  Returns dict(areacatch, ncellin,
+    ncellout) like the reference's stack, plus ups_ncell, flowdir and the filled surface."""
+    import torch
+    e = torch.as_tensor(np.ascontiguousarray(dem, dtype=np.float64), device="cuda")
+    H, W = e.shape
+    t = lambda: torch.empty(H * W, dtype=torch.float64, device="cuda")
+    res, filled, fd, nin, nout, cnt, area = (t() for _ in range(7))
+    dev_terrain(H, W, e, ymax, yres, xres, resolution=res)
+    mean_res = float(res[~torch.isnan(res)].mean().item())  # cellStats(resolution, 'mean', na.rm=TRUE)
+    dev_sinkfill(H, W, e, mean_res, filled, degree)
+    dev_terrain(H, W, filled, ymax, yres, xres, flowdir=fd)
+    dev_flow_accumulation(H, W, fd, cnt, area, elev=filled, resolution=res)
+    for out, codes in ((nin, FLOW_IN_TOP), (nout, FLOW_OUT_TOP)):
+        dev_ncellflow(H, W, fd, torch.tensor(codes, dtype=torch.float64, device="cuda"), out)
+    torch.cuda.synchronize()
+    g = lambda x: x.cpu().numpy().reshape(H, W)
+    return dict(areacatch=g(area), ncellin=g(nin), ncellout=g(nout), ups_ncell=g(cnt), flowdir=g(fd),
+                filled=g(filled))
+
+
 def terrain(elev, ymax, yres, xres, na_to_zero=True):
     """host arrays: elev [H, W] -> dict(slope, aspect, lat, resolution, flowdir, ncellin, ncellout),
-    the static rasters splash.grid prepares before its loop (upslope AREA excepted: sink filling and
-    flow accumulation are topmodel/TauDEM code outside the reference tree)"""
+    the static rasters splash.grid prepares before its loop (the upslope area: upslope_area())"""
     import torch
     e = torch.as_tensor(np.ascontiguousarray(elev, dtype=np.float64), device="cuda")
     H, W = e.shape

@@ -680,6 +680,33 @@ extern "C" int splash_dev_ncellflow(int H, int W, const double* flowdir, const d
     return SPLASH_OK;
 }
 
+// sink fill and contributing area (the rest of R/upslope_area.R: SURVEY 8f-1)
+extern "C" int splash_dev_sinkfill(int H, int W, const double* elev, double resolution_m,
+                                   double degree, double* filled, int* sweeps, void* stream)
+{
+    REQ(elev && filled && H > 0 && W > 0, "sinkfill: NULL argument or empty grid");
+    REQ(elev != filled, "sinkfill: the filled surface needs its own raster");
+    REQ(resolution_m > 0 && degree >= 0 && degree < 90, "sinkfill: resolution must be positive, 0 <= degree < 90");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    HIP_TRY(launch_sinkfill(H, W, elev, resolution_m, degree, filled, sweeps, (hipStream_t)stream), nullptr, 0);
+    return SPLASH_OK;
+}
+
+extern "C" int splash_dev_flow_accumulation(int H, int W, const double* flowdir, const double* elev,
+                                            int tau_codes, const double* resolution_m,
+                                            double* ups_ncell, double* ups_area, int* levels,
+                                            void* stream)
+{
+    REQ(flowdir && H > 0 && W > 0, "flow_accumulation: NULL flow direction or empty grid");
+    REQ(ups_ncell || ups_area, "flow_accumulation: no output requested");
+    REQ(!ups_area || resolution_m, "flow_accumulation: the area needs the resolution raster");
+    REQ((size_t)H * W < ((size_t)1 << 32), "flow_accumulation: more than 2^32-1 cells");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    HIP_TRY(launch_flow_accumulation(H, W, flowdir, elev, tau_codes, resolution_m, ups_ncell, ups_area, levels,
+                                     (hipStream_t)stream), nullptr, 0);
+    return SPLASH_OK;
+}
+
 // unSWC epilogue on device-resident rasters (R/unsSWC.R:14-88, R/unsSWC.grid.R)
 extern "C" int splash_dev_unswc(size_t ncell, int nt, const double* wn, size_t ldw,
                                 const double* soil, double uns_depth, double* wn_z, double* wtd,

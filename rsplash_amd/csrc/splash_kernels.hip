@@ -14,6 +14,7 @@
 namespace splash {
 
 static constexpr int kBlock = 256;
+static constexpr int kStripRows = 16; // rows a lane walks in the static-raster stencil kernels
 
 // minimum waves per SIMD requested from the register allocator for the two day-loop kernels
 #ifndef SPLASH_RUNALL_WPE
@@ -1212,6 +1213,207 @@ __global__ __launch_bounds__(kBlock) void k_synth_forcing(uint64_t seed,
     }
 }
 
+// ================================================================ sink fill + D8 accumulation ===
+// The rest of R/upslope_area.R: sink filling (:15-16 `topmodel::sinkfill(dem, res, 1)`,
+// :68 TauDEM pitremove) and the contributing area (:21 `topidx()$area`, :74 TauDEM aread8).  Both
+// are third-party codes outside the reference tree; what stands here are the published algorithms
+// (parity unpinned): Planchon & Darboux (2002) for the fill, plain D8 accumulation for the area.
+//
+// Sink fill: W = z on outlets (grid edge, next to NA), +inf elsewhere; relax
+//   W(c) <- max(z(c), min over the 8 neighbours n of W(n) + eps(n)),  eps = tan(degree)*res (*sqrt 2
+// on diagonals), until nothing changes.  The relaxation is monotone (every W only ever decreases,
+// and rounding keeps a <= b => a + eps <= b + eps), so the fixed point -- for every cell the
+// smallest over all paths to an outlet of the sum formed outlet-inwards -- does not depend on the
+// order of the updates: sweeps are done in place, any number of them per launch, and the result is
+// bit-identical to a serial evaluation in any sweep order.
+__global__ __launch_bounds__(kBlock) void k_sinkfill_init(int H, int W, const double* __restrict__ z,
+                                                         double* __restrict__ w)
+{
+    const int c = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (c >= W) return;
+    for (int r = (int)blockIdx.y; r < H; r += (int)gridDim.y) {
+        const size_t i = (size_t)r * W + c;
+        const double zc = z[i];
+        bool outlet = r == 0 || r == H - 1 || c == 0 || c == W - 1;
+        if (!outlet) {
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                const double v = z[(size_t)(r + q / 3 - 1) * W + (c + q % 3 - 1)];
+                outlet |= (v != v);
+            }
+        }
+        w[i] = (zc != zc) ? zc : (outlet ? zc : __builtin_inf());
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sinkfill_sweep(int H, int W, const double* __restrict__ z,
+                                                          double* w, double eps, double eps_d,
+                                                          int* __restrict__ changed)
+{
+    const int c = (int)(blockIdx.x * kBlock + threadIdx.x);
+    bool any = false;
+    if (c > 0 && c < W - 1) {
+        for (int r = (int)blockIdx.y * kStripRows; r < H; r += (int)gridDim.y * kStripRows) {
+            const int r1 = r + kStripRows < H ? r + kStripRows : H;
+            for (int rr = r < 1 ? 1 : r; rr < r1 && rr < H - 1; rr++) {
+                const size_t i = (size_t)rr * W + c;
+                const double zc = z[i];
+                // relaxed agent-scope accesses: other workgroups update w while this one reads it
+                const double wc = __hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(wc > zc)) continue; // NA, outlet, or already down at the terrain
+                double m = __builtin_inf();
+#pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    if (q == 4) continue;
+                    const double v = __hip_atomic_load(w + (size_t)(rr + q / 3 - 1) * W + (c + q % 3 - 1),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double cand = v + ((q & 1) ? eps : eps_d); // q odd: N, W, E, S
+                    m = (cand < m) ? cand : m;                       // NaN neighbours never win
+                }
+                const double nw = (m > zc) ? m : zc;
+                if (nw < wc) {
+                    __hip_atomic_store(w + i, nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    any = true;
+                }
+            }
+        }
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) *changed = 1;
+}
+
+// D8 accumulation: every cell sends the number of cells draining through it (itself included) to
+// the one neighbour its flow code names.  Kahn's order: a cell is ready when all cells that drain
+// into it have delivered.  Counts are integers, so the sums do not depend on the order of the
+// atomic adds.  Cells on a closed loop of codes (a pit the fill left: raster's flowdir names the
+// smallest rise when there is no drop) are never ready: they keep what their tributaries delivered
+// and pass nothing on.  codes: raster (1 E, 2 SE, 4 S, 8 SW, 16 W, 32 NW, 64 N, 128 NE) or TauDEM
+// (1 E, 2 NE, 3 N, 4 NW, 5 W, 6 SW, 7 S, 8 SE).
+__device__ __forceinline__ long long d8_target(double code, int tau, int r, int c, int H, int W)
+{
+    if (!(code >= 1.0)) return -1; // NA, 0 (no direction)
+    int q;                         // 0 E, 1 SE, 2 S, 3 SW, 4 W, 5 NW, 6 N, 7 NE
+    const int k = (int)code;
+    if ((double)k != code) return -1;
+    if (tau) {
+        if (k > 8) return -1;
+        q = (9 - k) & 7; // 1 E -> 0, 2 NE -> 7, 3 N -> 6, ..., 8 SE -> 1
+    } else {
+        if (k > 128 || (k & (k - 1)) != 0) return -1;
+        q = __ffs(k) - 1;
+    }
+    const int dr = (q >= 1 && q <= 3) ? 1 : ((q >= 5) ? -1 : 0);
+    const int dc = (q == 0 || q == 1 || q == 7) ? 1 : ((q >= 3 && q <= 5) ? -1 : 0);
+    const int rr = r + dr, cc = c + dc;
+    if (rr < 0 || rr >= H || cc < 0 || cc >= W) return -1;
+    return (long long)rr * W + cc;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fa_init(int H, int W, const double* __restrict__ fd,
+                                                   const double* __restrict__ elev, int tau,
+                                                   unsigned* __restrict__ count, int* __restrict__ indeg)
+{
+    const int c = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (c >= W) return;
+    for (int r = (int)blockIdx.y; r < H; r += (int)gridDim.y) {
+        const size_t i = (size_t)r * W + c;
+        const double code = fd[i];
+        const bool valid = elev ? (elev[i] == elev[i]) : (code == code);
+        int n = 0;
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            if (q == 4) continue;
+            const int rr = r + q / 3 - 1, cc = c + q % 3 - 1;
+            if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+            const size_t j = (size_t)rr * W + cc;
+            const bool jvalid = elev ? (elev[j] == elev[j]) : (fd[j] == fd[j]);
+            if (jvalid && d8_target(fd[j], tau, rr, cc, H, W) == (long long)i) n++;
+        }
+        count[i] = valid ? 1u : 0u;
+        indeg[i] = valid ? n : -1; // -1: not a cell
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_fa_seed(size_t n, const int* __restrict__ indeg,
+                                                   unsigned* __restrict__ queue, unsigned* __restrict__ qn)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n && indeg[i] == 0) queue[atomicAdd(qn, 1u)] = (unsigned)i;
+}
+
+__device__ __forceinline__ void fa_deliver(unsigned i, int H, int W, const double* __restrict__ fd,
+                                           const double* __restrict__ elev, int tau, unsigned* count,
+                                           int* indeg, unsigned* qout, unsigned* qout_n)
+{
+    const int r = (int)(i / (unsigned)W), c = (int)(i % (unsigned)W);
+    const long long t = d8_target(fd[i], tau, r, c, H, W);
+    if (t < 0) return;
+    if (__hip_atomic_load(indeg + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) return; // flows off the land
+    const unsigned mine = __hip_atomic_load(count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicAdd(count + t, mine);
+    if (atomicSub(indeg + t, 1) == 1) qout[atomicAdd(qout_n, 1u)] = (unsigned)t; // last delivery: ready
+}
+
+__global__ __launch_bounds__(kBlock) void k_fa_level(int H, int W, const double* __restrict__ fd,
+                                                    const double* __restrict__ elev, int tau,
+                                                    unsigned* count, int* indeg,
+                                                    const unsigned* __restrict__ qin, unsigned nin,
+                                                    unsigned* qout, unsigned* qout_n)
+{
+    const unsigned k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < nin) fa_deliver(qin[k], H, W, fd, elev, tau, count, indeg, qout, qout_n);
+}
+
+// The long thin end of the order (river trunks: a frontier never grows, every cell frees at most the
+// one cell it drains to): ONE workgroup walks the remaining levels without returning to the host.
+// Every pass empties the current queue; the loop ends when a pass frees nothing.
+constexpr int kFaTailBlock = 1024;
+__global__ __launch_bounds__(kFaTailBlock) void k_fa_tail(int H, int W, const double* __restrict__ fd,
+                                                         const double* __restrict__ elev, int tau,
+                                                         unsigned* count, int* indeg, unsigned* qa,
+                                                         unsigned na, unsigned* qb, unsigned* qn)
+{
+    __shared__ unsigned s_n;
+    unsigned* qin = qa;
+    unsigned* qout = qb;
+    unsigned nin = na;
+    while (nin > 0) { // uniform: nin is read from LDS by every thread after a barrier
+        if (threadIdx.x == 0) *qn = 0;
+        __syncthreads();
+        for (unsigned k = threadIdx.x; k < nin; k += kFaTailBlock)
+            fa_deliver(__hip_atomic_load(qin + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), H, W, fd, elev,
+                       tau, count, indeg, qout, qn);
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = __hip_atomic_load(qn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        nin = s_n;
+        unsigned* t = qin;
+        qin = qout;
+        qout = t;
+        __syncthreads();
+    }
+}
+
+// counts -> doubles (NA where there is no cell) and, optionally, the reference's contributing area
+// (R/upslope_area.R:85-96): fix_coast -- a cell with an elevation but no count gets 1 -- and
+// ups_ncell * cell area, here count * resolution^2 in m2.
+__global__ __launch_bounds__(kBlock) void k_fa_finish(size_t n, const unsigned* __restrict__ count,
+                                                     const int* __restrict__ indeg,
+                                                     const double* __restrict__ resolution,
+                                                     double* __restrict__ ups_ncell,
+                                                     double* __restrict__ ups_area)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const bool cell = indeg[i] != -1;
+    const double k = cell ? (double)count[i] : __builtin_nan("");
+    if (ups_ncell) ups_ncell[i] = k;
+    if (ups_area) {
+        const double res = resolution[i];
+        ups_area[i] = k * (res * res);
+    }
+}
+
 // ================================================================ launchers ===================
 static inline unsigned nblk(size_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
@@ -1311,6 +1513,83 @@ hipError_t launch_run_all(const RunArgs& a, hipStream_t s)
             hipLaunchKernelGGL((k_run_all<false, false, 0>), g, b, 0, s, a);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_sinkfill(int H, int W, const double* elev, double resolution_m, double degree,
+                           double* filled, int* sweeps_out, hipStream_t s)
+{
+    const size_t n = (size_t)H * W;
+    if (n == 0) return hipSuccess;
+    int* changed = nullptr;
+    hipError_t e = hipMallocAsync((void**)&changed, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    const dim3 g1(nblk((size_t)W, kBlock), (unsigned)(H < 65535 ? H : 65535));
+    const unsigned strips = nblk((size_t)H, kStripRows);
+    const dim3 g2(nblk((size_t)W, kBlock), strips < 65535 ? strips : 65535);
+    hipLaunchKernelGGL(k_sinkfill_init, g1, dim3(kBlock), 0, s, H, W, elev, filled);
+    const double eps = tan(degree * kPir) * resolution_m, eps_d = eps * sqrt(2.0);
+    int sweeps = 0, h_changed = 1;
+    const int batch = 16;
+    // a fill level travels at least one cell per sweep: (H + W) * 8 sweeps bound any DEM's longest
+    // fill path many times over; the loop normally ends much earlier, on a batch that changed nothing
+    const long max_sweeps = 8L * ((long)H + W) + 64;
+    while (h_changed && sweeps < max_sweeps) {
+        e = hipMemsetAsync(changed, 0, sizeof(int), s);
+        if (e != hipSuccess) break;
+        for (int k = 0; k < batch; k++)
+            hipLaunchKernelGGL(k_sinkfill_sweep, g2, dim3(kBlock), 0, s, H, W, elev, filled, eps, eps_d, changed);
+        sweeps += batch;
+        e = hipMemcpyAsync(&h_changed, changed, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) break;
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) break;
+    }
+    if (sweeps_out) *sweeps_out = sweeps;
+    (void)hipFreeAsync(changed, s);
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
+hipError_t launch_flow_accumulation(int H, int W, const double* fd, const double* elev, int tau,
+                                    const double* resolution, double* ups_ncell, double* ups_area,
+                                    int* levels_out, hipStream_t s)
+{
+    const size_t n = (size_t)H * W;
+    if (n == 0) return hipSuccess;
+    // stream-ordered scratch: count, in-degree, two queues (a cell enters a queue once), 2 counters
+    char* w = nullptr;
+    hipError_t e = hipMallocAsync((void**)&w, n * 16 + 64, s);
+    if (e != hipSuccess) return e;
+    unsigned* count = (unsigned*)w;
+    int* indeg = (int*)(w + n * 4);
+    unsigned* q[2] = {(unsigned*)(w + n * 8), (unsigned*)(w + n * 12)};
+    unsigned* qn = (unsigned*)(w + n * 16);
+    const dim3 g1(nblk((size_t)W, kBlock), (unsigned)(H < 65535 ? H : 65535));
+    hipLaunchKernelGGL(k_fa_init, g1, dim3(kBlock), 0, s, H, W, fd, elev, tau, count, indeg);
+    e = hipMemsetAsync(qn, 0, 64, s);
+    hipLaunchKernelGGL(k_fa_seed, dim3(nblk(n, kBlock)), dim3(kBlock), 0, s, n, indeg, q[0], qn);
+    int cur = 0, levels = 0;
+    while (e == hipSuccess) {
+        unsigned nin = 0;
+        e = hipMemcpyAsync(&nin, qn + cur, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess || nin == 0) break;
+        levels++;
+        if (nin <= 16384u) { // the frontier never grows: one workgroup finishes the order
+            hipLaunchKernelGGL(k_fa_tail, dim3(1), dim3(kFaTailBlock), 0, s, H, W, fd, elev, tau, count, indeg,
+                               q[cur], nin, q[cur ^ 1], qn + (cur ^ 1));
+            break;
+        }
+        e = hipMemsetAsync(qn + (cur ^ 1), 0, sizeof(unsigned), s);
+        hipLaunchKernelGGL(k_fa_level, dim3(nblk((size_t)nin, kBlock)), dim3(kBlock), 0, s, H, W, fd, elev, tau,
+                           count, indeg, q[cur], nin, q[cur ^ 1], qn + (cur ^ 1));
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_fa_finish, dim3(nblk(n, kBlock)), dim3(kBlock), 0, s, n, count, indeg, resolution,
+                       ups_ncell, ups_area);
+    if (levels_out) *levels_out = levels;
+    const hipError_t e2 = hipGetLastError();
+    (void)hipFreeAsync(w, s);
+    return e != hipSuccess ? e : e2;
 }
 
 hipError_t launch_run_all_mod(const RunArgs& a, hipStream_t s)
@@ -1475,7 +1754,6 @@ __global__ __launch_bounds__(kBlock) void k_terrain_rows(int H, double ymax, dou
 // Quotients by the row's distances are formed with div_cr() (the correctly rounded a/b from
 // y = RN(1/b): bit-identical to the division they replace, so the D8 code -- an argmax over
 // quotients -- cannot change).
-constexpr int kStripRows = 16;
 __device__ __forceinline__ void window_row(const double* __restrict__ p, int H, int W, int r, int c,
                                            double& l, double& m, double& rt)
 {

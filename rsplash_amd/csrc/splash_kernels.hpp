@@ -127,6 +127,11 @@ hipError_t launch_terrain(int H, int W, const double* elev, double ymax, double 
                           double* flowdir, hipStream_t s);
 hipError_t launch_ncellflow(int H, int W, const double* fd, const double* codes, int pad,
                             double* out, hipStream_t s);
+hipError_t launch_sinkfill(int H, int W, const double* elev, double resolution_m, double degree,
+                           double* filled, int* sweeps_out, hipStream_t s);
+hipError_t launch_flow_accumulation(int H, int W, const double* fd, const double* elev, int tau,
+                                    const double* resolution, double* ups_ncell, double* ups_area,
+                                    int* levels_out, hipStream_t s);
 hipError_t launch_widen_f32(const float* src, size_t n, double* dst, hipStream_t s);
 hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, const double* sw,
                              const double* dr, const double* sd, const double* cd,

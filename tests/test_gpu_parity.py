@@ -1087,6 +1087,65 @@ def test_terrain_and_ncellflow_vs_oracle(api, oracle):
     assert np.isnan(g["slope"][0]).all() and 0 < np.nanmax(g["slope"]) < 60
 
 
+def test_sinkfill_and_flow_accumulation_vs_oracle(api, oracle):
+    """SURVEY 8f-1, the graph part of R/upslope_area.R: sink fill (fixed point of a monotone
+    relaxation: bit-identical to the serial sweeps whatever the update order) and D8 accumulation
+    (integer counts: identical whatever the order of the atomic adds), on a rough DEM with NA
+    patches, pits and a long valley, both code conventions; then the whole upslope_area() chain."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(20221130)
+    H, W = 301, 517
+    rows, cols = np.mgrid[0:H, 0:W]
+    z = (400 + 3.0 * np.hypot(rows - 150, 0.6 * (cols - 250)) + 60 * np.sin(rows / 17.0) * np.cos(cols / 23.0)
+         + 25 * rng.random((H, W)))
+    z[100:110, 200:240] = np.nan                      # a lake / missing tile
+    z[40:43, 40:43] -= 200                            # a deep pit
+    z[250, :] = np.minimum(z[250, :], 300 - 0.05 * cols[250])  # a long valley draining east
+    zt = torch.as_tensor(z, device=dev)
+    for degree in (0.0, 1.0):
+        filled = torch.empty(H * W, dtype=torch.float64, device=dev)
+        sweeps = api.dev_sinkfill(H, W, zt, 250.0, filled, degree)
+        ref = oracle.sinkfill(z, 250.0, degree)
+        got = filled.cpu().numpy().reshape(H, W)
+        assert sweeps > 0
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)]), f"sink fill, degree {degree}"
+        assert (got[~np.isnan(z)] >= z[~np.isnan(z)]).all() and (got > z).sum() > 100
+    # flow direction of the filled surface, then the accumulation, against the oracle's
+    t = oracle.terrain(ref, 60.0, 0.0025, 0.0025, na_to_zero=False)
+    fd, res = t["flowdir"], t["resolution"]
+    cnt_o, area_o = oracle.flow_accumulation(fd, elev=ref, resolution=res)
+    cnt = torch.empty(H * W, dtype=torch.float64, device=dev)
+    area = torch.empty(H * W, dtype=torch.float64, device=dev)
+    levels = api.dev_flow_accumulation(H, W, torch.as_tensor(fd, device=dev), cnt, area,
+                                       elev=torch.as_tensor(ref, device=dev),
+                                       resolution=torch.as_tensor(res, device=dev))
+    g = cnt.cpu().numpy().reshape(H, W)
+    assert levels >= 1
+    assert np.array_equal(np.isnan(g), np.isnan(cnt_o)) and np.array_equal(g[~np.isnan(g)], cnt_o[~np.isnan(g)])
+    ga = area.cpu().numpy().reshape(H, W)
+    m = ~np.isnan(area_o)
+    assert np.array_equal(np.isnan(ga), ~m) and np.array_equal(ga[m], area_o[m])
+    assert np.nanmax(g) > 2000 and np.nanmin(g) == 1   # the valley collects a large catchment
+    # without the elevation mask cells are where the flow code is not NA; TauDEM codes agree
+    cnt2_o, _ = oracle.flow_accumulation(fd)
+    api.dev_flow_accumulation(H, W, torch.as_tensor(fd, device=dev), cnt)
+    g2 = cnt.cpu().numpy().reshape(H, W)
+    assert np.array_equal(np.isnan(g2), np.isnan(cnt2_o)) and np.array_equal(g2[~np.isnan(g2)], cnt2_o[~np.isnan(g2)])
+    q = np.log2(np.where(np.isnan(fd) | (fd < 1), 1.0, fd)).astype(int)   # 0 E, 1 SE, ... 7 NE
+    tau = np.where(np.isnan(fd) | (fd < 1), fd, ((9 - q) % 8 + (((9 - q) % 8) == 0) * 8).astype(float))
+    tau = np.where(np.isnan(fd) | (fd < 1), fd, np.array([1, 8, 7, 6, 5, 4, 3, 2], float)[q])
+    api.dev_flow_accumulation(H, W, torch.as_tensor(tau, device=dev), cnt, tau_codes=True)
+    g3 = cnt.cpu().numpy().reshape(H, W)
+    assert np.array_equal(g3[~np.isnan(g3)], cnt2_o[~np.isnan(g3)])
+    # the whole chain of upslope_area(dem, resolution)
+    u = api.upslope_area(z, 60.0, 0.0025, 0.0025)
+    assert np.array_equal(u["filled"][~np.isnan(z)], oracle.sinkfill(z, float(np.nanmean(res)), 1.0)[~np.isnan(z)])
+    assert np.nanmin(u["ups_ncell"]) == 1 and np.isnan(u["areacatch"][105, 220])
+    assert np.allclose(u["areacatch"][m], (u["ups_ncell"] * res ** 2)[m], rtol=1e-15)
+
+
 def test_overlapped_spin_up_gives_the_same_bits(api, oracle):
     """splash_dev_spin_up_begin / _finish with the transient run of the finished cells in between
     (skip mask) and the late cells in list mode afterwards == the plain sequence, bit for bit, water-

@@ -347,3 +347,63 @@ def test_restatement_matches_the_reference_statement_by_statement():
     assert r.returncode == 0, r.stdout[-3000:]
     assert "unexplained differences: 0" in r.stdout
     assert "identical in order 101" in r.stdout  # run_one_day's live arithmetic
+
+
+def test_sinkfill_and_flow_accumulation_hand_cases(oracle):
+    """the rest of R/upslope_area.R, hand-computable cases of the restated published
+    algorithms: a pit is raised to its spill level (+ the minimum slope), a filled surface has no
+    interior cell without a lower neighbour, every cell of a V-shaped valley drains down the axis."""
+    # a 2-cell-deep pit in a plane tilted to the east edge (outlet side), degree = 0: filled to level
+    H, W = 7, 9
+    rows, cols = np.mgrid[0:H, 0:W]
+    z = 1000.0 - 10.0 * cols.astype(float)  # descends eastwards, 10 m per 100 m cell (5.7 degrees)
+    z[3, 3] = 500.0                         # pit
+    f0 = oracle.sinkfill(z, 100.0, degree=0.0)
+    assert f0[3, 3] == 960.0                # spills over its lowest neighbour (3, 4)
+    assert np.array_equal(np.delete(f0.ravel(), 3 * W + 3), np.delete(z.ravel(), 3 * W + 3))
+    # with a minimum slope the pit sits eps above the neighbour it drains to (the plane itself is
+    # steeper than 1 degree and stays as it is)
+    f1 = oracle.sinkfill(z, 100.0, degree=1.0)
+    eps = np.tan(np.radians(1.0)) * 100.0
+    assert np.isclose(f1[3, 3], 960.0 + eps, rtol=0, atol=1e-12)
+    assert np.array_equal(np.delete(f1.ravel(), 3 * W + 3), np.delete(z.ravel(), 3 * W + 3))
+    # NA stays NA and makes its neighbours outlets
+    z2 = np.full((6, 6), 10.0)
+    z2[2, 2] = np.nan
+    z2[3, 3] = 1.0                          # next to the NA cell: an outlet, keeps its value
+    f2 = oracle.sinkfill(z2, 50.0, 0.0)
+    assert np.isnan(f2[2, 2]) and f2[3, 3] == 1.0
+    # random rough DEM: after the fill every interior cell (not an outlet) has a strictly lower
+    # neighbour when degree > 0, and nothing was lowered
+    rng = np.random.default_rng(7)
+    z3 = rng.random((40, 50)) * 100.0
+    f3 = oracle.sinkfill(z3, 30.0, 0.5)
+    assert (f3 >= z3).all()
+    inner = f3[1:-1, 1:-1]
+    nmin = np.min([f3[1 + dr:f3.shape[0] - 1 + dr, 1 + dc:f3.shape[1] - 1 + dc]
+                   for dr in (-1, 0, 1) for dc in (-1, 0, 1) if (dr, dc) != (0, 0)], axis=0)
+    assert (nmin < inner).all()
+    # V-shaped valley draining south: flow codes by hand (raster codes: 4 = S, 2 = SE, 8 = SW)
+    H, W = 6, 7
+    fd = np.full((H, W), 4.0)               # the axis (column 3) flows south
+    fd[:, :3] = 2.0                         # west flank flows south-east
+    fd[:, 4:] = 8.0                         # east flank flows south-west
+    cnt, area = oracle.flow_accumulation(fd, resolution=np.full((H, W), 10.0))
+    assert cnt[0].tolist() == [1] * W       # top row: nothing upstream
+    # the whole grid leaves through the bottom row: every cell is counted once there
+    assert cnt[-1].sum() == H * W and cnt.min() == 1
+    # axis cell of row 1: itself, the axis cell above and the two flank cells above
+    assert cnt[1, 3] == 4 and cnt[1, 2] == 2 and cnt[2, 2] == 3 and cnt[1, 0] == 1
+    assert np.array_equal(area, cnt * 100.0)
+    # TauDEM codes give the same counts (7 = S, 8 = SE, 6 = SW)
+    tau = np.where(fd == 4, 7.0, np.where(fd == 2, 8.0, 6.0))
+    cnt_t, _ = oracle.flow_accumulation(tau, tau=True)
+    assert np.array_equal(cnt_t, cnt)
+    # a closed loop (two cells naming each other) keeps its tributaries and passes nothing on
+    fd = np.array([[1.0, 16.0, 16.0]])      # (0,0) -> E, (0,1) -> W, (0,2) -> W
+    cnt, _ = oracle.flow_accumulation(fd)
+    assert cnt.tolist() == [[1.0, 2.0, 1.0]]
+    # NA cells: no count, flow into them leaves the land
+    fd = np.array([[1.0, np.nan, 16.0]])
+    cnt, _ = oracle.flow_accumulation(fd)
+    assert cnt[0, 0] == 1 and np.isnan(cnt[0, 1]) and cnt[0, 2] == 1
