@@ -244,6 +244,20 @@ int splash_dev_flow_accumulation(int H, int W, const double* flowdir, const doub
                                  int tau_codes, const double* resolution_m, double* ups_ncell,
                                  double* ups_area, int* levels, void* stream);
 
+/* The static rasters in ONE call on host buffers (what an R caller binds): everything
+ * R/splash.grid.R:96-110 and upslope_area() (R/upslope_area.R:12-58) derive from the elevation
+ * matrix.  elev [H*W] row-major (raster::as.matrix / getValues order), NaN = NA.  Outputs [H*W], any
+ * may be NULL: slope, aspect (degrees, of the RAW dem as splash.grid takes them), lat, resolution (m);
+ * filled (sink-filled surface: degree as in sinkfill(dem, mean resolution, degree)), flowdir (raster
+ * codes, of the FILLED surface), ups_ncell, ups_area (m2), ncellin, ncellout (met='top' windows). */
+typedef struct splash_static_out {
+    double *slope, *aspect, *lat, *resolution;
+    double *filled, *flowdir, *ups_ncell, *ups_area, *ncellin, *ncellout;
+} splash_static_out;
+int splash_static_rasters_run(int H, int W, const double* elev, double ymax, double yres, double xres,
+                              int na_to_zero, double degree, const splash_static_out* out,
+                              char* err, size_t errlen);
+
 /* ---------------------------------------------------------------- unSWC epilogue */
 /* R/unsSWC.R:14-88 / R/unsSWC.grid.R: from the column water content wn [mm] (output of the path
  * above), the water held between the surface and uns_depth [m] (wn_z, mm), the water-table depth

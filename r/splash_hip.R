@@ -135,6 +135,20 @@ splash.grid.statics <- function(elev, tmpdir = tempdir()) {
   list(lat = lat, terraines = terraines, resolution = resolution, Au = Au)
 }
 
+# The same rasters from the HIP library (Horn slope/aspect, latitude, resolution, sink fill, D8
+# contributing area, cells draining in/out: include/splash_hip.h, splash_static_rasters_run); a
+# lon/lat grid is assumed, as raster::area() and the rest of splash.grid do.
+splash.grid.statics.hip <- function(elev, degree = 1) {
+  z <- matrix(raster::getValues(elev), nrow = ncol(elev), ncol = nrow(elev))   # [ncol x nrow]: row-major cells
+  r <- .Call("C_splash_static_rasters", z, as.numeric(raster::ymax(elev)), as.numeric(raster::yres(elev)),
+             as.numeric(raster::xres(elev)), as.numeric(degree))
+  as_raster <- function(m) raster::setValues(raster::raster(elev), as.vector(m))
+  terraines <- raster::stack(as_raster(r$slope), as_raster(r$aspect))
+  names(terraines) <- c("slope", "aspect")
+  Au <- raster::stack(as_raster(r$areacatch), as_raster(r$ncellin), as_raster(r$ncellout))   # R/upslope_area.R:56
+  list(lat = as_raster(r$lat), terraines = terraines, resolution = as_raster(r$resolution), Au = Au)
+}
+
 # unSWC (R/unsSWC.R:14): same signature; the analytical integral runs in the HIP library.
 # One site = one "cell": wn is handed over as a [1 x nt] matrix, soil as [1 x 6].
 unSWC <- function(soil_data, uns_depth, wn) {

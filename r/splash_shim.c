@@ -159,10 +159,40 @@ SEXP C_splash_unswc_run(SEXP wn, SEXP soil, SEXP uns_depth)
     return res;
 }
 
+/* Static rasters of an elevation matrix (R/splash.grid.R:96-110, R/upslope_area.R:12-58).
+ * elev: numeric matrix [W x H], i.e. t(raster::as.matrix(dem)) or the vector raster::getValues(dem)
+ * with dim c(ncol, nrow) -- row-major cells, as the C ABI wants them; ymax/yres/xres: northern edge
+ * and cell size in degrees.  Returns a named list of [W x H] matrices in the same cell order. */
+SEXP C_splash_static_rasters(SEXP elev, SEXP ymax, SEXP yres, SEXP xres, SEXP degree)
+{
+    SEXP dim = getAttrib(elev, R_DimSymbol);
+    if (isNull(dim) || LENGTH(dim) != 2 || !isReal(elev)) error("elev must be a numeric [ncol x nrow] matrix");
+    const int W = INTEGER(dim)[0], H = INTEGER(dim)[1];
+    static const char* names[] = {"slope", "aspect", "lat", "resolution", "filled", "flowdir",
+                                  "ups_ncell", "areacatch", "ncellin", "ncellout", ""};
+    SEXP res = PROTECT(mkNamed(VECSXP, names));
+    double* p[10];
+    for (int k = 0; k < 10; k++) {
+        SEXP m = PROTECT(allocMatrix(REALSXP, W, H));
+        SET_VECTOR_ELT(res, k, m);
+        UNPROTECT(1);
+        p[k] = REAL(m);
+    }
+    splash_static_out out = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9]};
+    char msg[256] = "";
+    const int rc = splash_static_rasters_run(H, W, REAL(elev), asReal(ymax), asReal(yres), asReal(xres),
+                                             /* na_to_zero (R/splash.grid.R:107) */ 1, asReal(degree), &out,
+                                             msg, sizeof msg);
+    UNPROTECT(1);
+    if (rc != 0) error("splash_static_rasters_run: %s (code %d)", msg, rc);
+    return res;
+}
+
 static const R_CallMethodDef CallEntries[] = {
     {"C_splash_grid_run", (DL_FUNC)&C_splash_grid_run, 11},
     {"C_splash_point_run", (DL_FUNC)&C_splash_point_run, 14},
     {"C_splash_unswc_run", (DL_FUNC)&C_splash_unswc_run, 3},
+    {"C_splash_static_rasters", (DL_FUNC)&C_splash_static_rasters, 5},
     {NULL, NULL, 0}};
 
 /* add these two entries to the package's existing R_init_rsplash (src/RcppExports.cpp:21-24),

@@ -562,7 +562,10 @@ def upslope_area(dem, ymax, yres, xres, degree=1.0):
     t = lambda: torch.empty(H * W, dtype=torch.float64, device="cuda")
     res, filled, fd, nin, nout, cnt, area = (t() for _ in range(7))
     dev_terrain(H, W, e, ymax, yres, xres, resolution=res)
-    mean_res = float(res[~torch.isnan(res)].mean().item())  # cellStats(resolution, 'mean', na.rm=TRUE)
+    rv = res.cpu().numpy()
+    rv = rv[~np.isnan(rv)].astype(np.longdouble)  # cellStats(resolution, 'mean', na.rm=TRUE): R's mean is
+    m0 = rv.sum() / rv.size                        # a long-double sum and one refinement pass
+    mean_res = float(m0 + (rv - m0).sum() / rv.size)
     dev_sinkfill(H, W, e, mean_res, filled, degree)
     dev_terrain(H, W, filled, ymax, yres, xres, flowdir=fd)
     dev_flow_accumulation(H, W, fd, cnt, area, elev=filled, resolution=res)
@@ -572,6 +575,23 @@ def upslope_area(dem, ymax, yres, xres, degree=1.0):
     g = lambda x: x.cpu().numpy().reshape(H, W)
     return dict(areacatch=g(area), ncellin=g(nin), ncellout=g(nout), ups_ncell=g(cnt), flowdir=g(fd),
                 filled=g(filled))
+
+
+def static_rasters(elev, ymax, yres, xres, na_to_zero=True, degree=1.0, want=None):
+    """host arrays through the host-buffer entry point (splash_static_rasters_run, what the R shim
+    binds): elev [H, W] -> dict of [H, W] arrays named like _lib.STATIC_NAMES (want: subset)"""
+    from ._lib import STATIC_NAMES, StaticOut
+    e = np.ascontiguousarray(elev, dtype=np.float64)
+    H, W = e.shape
+    names = STATIC_NAMES if want is None else tuple(want)
+    o = {k: np.empty((H, W)) for k in names}
+    so = StaticOut(**{k: o[k].ctypes.data_as(_dp) for k in names})
+    buf = C.create_string_buffer(256)
+    rc = lib.splash_static_rasters_run(H, W, e.ctypes.data_as(_dp), float(ymax), float(yres), float(xres),
+                                       int(bool(na_to_zero)), float(degree), C.byref(so), buf, 256)
+    if rc:
+        raise SplashError(rc, "splash_static_rasters_run: " + buf.value.decode())
+    return o
 
 
 def terrain(elev, ymax, yres, xres, na_to_zero=True):

@@ -1346,6 +1346,87 @@ extern "C" int splash_unswc_run(size_t ncell, int nt, const double* wn, const do
     return SPLASH_OK;
 }
 
+// static rasters on host buffers: R/splash.grid.R:96-110 + upslope_area() (R/upslope_area.R:12-58)
+extern "C" int splash_static_rasters_run(int H, int W, const double* elev, double ymax, double yres,
+                                         double xres, int na_to_zero, double degree,
+                                         const splash_static_out* out, char* err, size_t errlen)
+{
+    if (!elev || !out || H <= 0 || W <= 0)
+        return fail(SPLASH_EINVAL, err, errlen, "static_rasters_run: NULL argument or empty grid");
+    if (int rc = need_device(err, errlen)) return rc;
+    const size_t n = (size_t)H * W, nb = n * sizeof(double);
+    const bool graph = out->filled || out->flowdir || out->ups_ncell || out->ups_area || out->ncellin ||
+                       out->ncellout;
+    DevBuf de, dsl, das, dla, dre, dfi, dfd, dcn, dar, dni, dno, dcodes;
+    HIP_TRY(de.alloc(nb), err, errlen);
+    HIP_TRY(hipMemcpy(de.p, elev, nb, hipMemcpyHostToDevice), err, errlen);
+    if (out->slope) HIP_TRY(dsl.alloc(nb), err, errlen);
+    if (out->aspect) HIP_TRY(das.alloc(nb), err, errlen);
+    if (out->lat) HIP_TRY(dla.alloc(nb), err, errlen);
+    HIP_TRY(dre.alloc(nb), err, errlen); // always: the fill uses its mean, the area its square
+    int rc = splash_dev_terrain(H, W, de.as<double>(), ymax, yres, xres, na_to_zero,
+                                out->slope ? dsl.as<double>() : nullptr, out->aspect ? das.as<double>() : nullptr,
+                                out->lat ? dla.as<double>() : nullptr, dre.as<double>(), nullptr, nullptr);
+    if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
+    HIP_TRY(hipDeviceSynchronize(), err, errlen);
+    std::vector<double> res(graph || out->resolution ? n : 0);
+    if (!res.empty()) HIP_TRY(hipMemcpy(res.data(), dre.p, nb, hipMemcpyDeviceToHost), err, errlen);
+    if (out->resolution) memcpy(out->resolution, res.data(), nb);
+    if (graph) {
+        // cellStats(resolution, stat = 'mean', na.rm = TRUE), R/upslope_area.R:14: R's mean is a
+        // long-double sum followed by one long-double refinement pass
+        long double sum = 0.0L;
+        size_t cnt = 0;
+        for (size_t i = 0; i < n; i++)
+            if (res[i] == res[i]) {
+                sum += res[i];
+                cnt++;
+            }
+        if (cnt == 0) return fail(SPLASH_EINVAL, err, errlen, "static_rasters_run: the elevation is all NA");
+        long double mean = sum / (long double)cnt, corr = 0.0L;
+        for (size_t i = 0; i < n; i++)
+            if (res[i] == res[i]) corr += (long double)res[i] - mean;
+        const double mean_res = (double)(mean + corr / (long double)cnt);
+        HIP_TRY(dfi.alloc(nb), err, errlen);
+        HIP_TRY(dfd.alloc(nb), err, errlen);
+        rc = splash_dev_sinkfill(H, W, de.as<double>(), mean_res, degree, dfi.as<double>(), nullptr, nullptr);
+        if (!rc) rc = splash_dev_terrain(H, W, dfi.as<double>(), ymax, yres, xres, 0, nullptr, nullptr, nullptr,
+                                         nullptr, dfd.as<double>(), nullptr);
+        if (!rc && (out->ups_ncell || out->ups_area)) {
+            HIP_TRY(dcn.alloc(nb), err, errlen);
+            HIP_TRY(dar.alloc(nb), err, errlen);
+            rc = splash_dev_flow_accumulation(H, W, dfd.as<double>(), dfi.as<double>(), 0, dre.as<double>(),
+                                              dcn.as<double>(), dar.as<double>(), nullptr, nullptr);
+        }
+        if (!rc && (out->ncellin || out->ncellout)) {
+            static const double in_top[9] = {2, 1, 128, 4, 0, 64, 8, 16, 32}; // R/upslope_area.R:142
+            double codes[18];
+            for (int q = 0; q < 9; q++) {
+                codes[q] = in_top[q];
+                codes[9 + q] = in_top[8 - q]; // :144: rev()
+            }
+            HIP_TRY(dcodes.alloc(sizeof(codes)), err, errlen);
+            HIP_TRY(hipMemcpy(dcodes.p, codes, sizeof(codes), hipMemcpyHostToDevice), err, errlen);
+            if (out->ncellin) {
+                HIP_TRY(dni.alloc(nb), err, errlen);
+                rc = splash_dev_ncellflow(H, W, dfd.as<double>(), dcodes.as<double>(), 0, dni.as<double>(), nullptr);
+            }
+            if (!rc && out->ncellout) {
+                HIP_TRY(dno.alloc(nb), err, errlen);
+                rc = splash_dev_ncellflow(H, W, dfd.as<double>(), dcodes.as<double>() + 9, 0, dno.as<double>(), nullptr);
+            }
+        }
+        if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
+    }
+    HIP_TRY(hipDeviceSynchronize(), err, errlen);
+    struct { double* h; DevBuf* d; } back[] = {{out->slope, &dsl}, {out->aspect, &das}, {out->lat, &dla},
+                                               {out->filled, &dfi}, {out->flowdir, &dfd}, {out->ups_ncell, &dcn},
+                                               {out->ups_area, &dar}, {out->ncellin, &dni}, {out->ncellout, &dno}};
+    for (auto& b : back)
+        if (b.h) HIP_TRY(hipMemcpy(b.h, b.d->p, nb, hipMemcpyDeviceToHost), err, errlen);
+    return SPLASH_OK;
+}
+
 // ------------------------------------------------------------------ Rcpp-module mirrors
 namespace {
 

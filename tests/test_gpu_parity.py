@@ -1141,9 +1141,22 @@ def test_sinkfill_and_flow_accumulation_vs_oracle(api, oracle):
     assert np.array_equal(g3[~np.isnan(g3)], cnt2_o[~np.isnan(g3)])
     # the whole chain of upslope_area(dem, resolution)
     u = api.upslope_area(z, 60.0, 0.0025, 0.0025)
-    assert np.array_equal(u["filled"][~np.isnan(z)], oracle.sinkfill(z, float(np.nanmean(res)), 1.0)[~np.isnan(z)])
+    rv = res[~np.isnan(res)].astype(np.longdouble)
+    mean_res = float(rv.sum() / rv.size + (rv - rv.sum() / rv.size).sum() / rv.size)   # R's mean()
+    assert np.array_equal(u["filled"][~np.isnan(z)], oracle.sinkfill(z, mean_res, 1.0)[~np.isnan(z)])
     assert np.nanmin(u["ups_ncell"]) == 1 and np.isnan(u["areacatch"][105, 220])
     assert np.allclose(u["areacatch"][m], (u["ups_ncell"] * res ** 2)[m], rtol=1e-15)
+    # the host-buffer entry point the R shim binds gives the same rasters in one call
+    sr = api.static_rasters(z, 60.0, 0.0025, 0.0025)
+    for k, ku in (("filled", "filled"), ("flowdir", "flowdir"), ("ups_ncell", "ups_ncell"),
+                  ("ups_area", "areacatch"), ("ncellin", "ncellin"), ("ncellout", "ncellout")):
+        a, b = sr[k], u[ku]
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(a)]), k
+    t0 = api.terrain(z, 60.0, 0.0025, 0.0025)
+    for k in ("slope", "aspect", "lat", "resolution"):
+        assert np.array_equal(np.isnan(sr[k]), np.isnan(t0[k])) and np.array_equal(sr[k][~np.isnan(sr[k])], t0[k][~np.isnan(sr[k])]), k
+    with pytest.raises(Exception):
+        api.static_rasters(np.full((4, 4), np.nan), 60.0, 0.0025, 0.0025)   # all NA: no mean resolution
 
 
 def test_overlapped_spin_up_gives_the_same_bits(api, oracle):
