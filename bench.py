@@ -427,7 +427,7 @@ def cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp):
     tcpu = cpu_run(ns2, cores)
     line["cpu_baseline"] = {
         "value": ns2 * nt / tcpu, "unit": "cell-days/s", "cores": cores, "kind": "port",
-        "single_thread_value": rate1, "threads_obtained": o.max_threads(), "cpu_model": cpu_model(),
+        "single_thread_value": rate1, "threads_obtained": o.threads_obtained(cores), "omp_max_threads": o.max_threads(), "cpu_model": cpu_model(),
         "sample": f"first {ns2} cells x {nt} days of the same grid (run_all + rain/snow split from the "
                   f"GPU's spun-up state), OpenMP over cells with {cores} threads, {tcpu:.1f} s; one thread: "
                   f"{ns1} cells in {t1:.1f} s",

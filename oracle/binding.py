@@ -395,6 +395,10 @@ class Oracle:
                                    *[x.ctypes.data_as(_dp) for x in (sw, tc, pn)])
         return sw, tc, pn
 
+    def threads_obtained(self, n):
+        """threads an OpenMP region asked for n really gets"""
+        return int(self.lib.orc_threads_obtained(int(n)))
+
     def max_threads(self):
         return self.lib.orc_max_threads()
 

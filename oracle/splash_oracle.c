@@ -1450,6 +1450,22 @@ void orc_point(int nt, const int* doy, const int* year, const int* month, const 
     free(rain);
 }
 
+/* threads a parallel region asked for n really gets (what the baseline's loops run on) */
+int orc_threads_obtained(int n)
+{
+    int got = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n > 0 ? n : omp_get_max_threads())
+    {
+#pragma omp single
+        got = omp_get_num_threads();
+    }
+#else
+    (void)n;
+#endif
+    return got;
+}
+
 int orc_max_threads(void)
 {
 #ifdef _OPENMP
