@@ -55,6 +55,14 @@ def _load():
         raise RuntimeError(
             f"{path} is missing: build it with rsplash_amd.build_library() "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64/libhsa-runtime64, this
+    # library links the system's.  Whichever is loaded FIRST serves both (same SONAME); loaded the
+    # other way round the process ends up with two HSA runtimes and the second sees no device.
+    # So when PyTorch is there (it is the device-memory plumbing of the Python mirror), it goes first.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(path)
     L.splash_hip_abi_version.restype = C.c_int
     L.splash_hip_device_count.restype = C.c_int
