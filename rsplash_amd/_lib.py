@@ -95,12 +95,15 @@ def _load():
     L.splash_dev_terrain.argtypes = [C.c_int, C.c_int, _vp, C.c_double, C.c_double, C.c_double, C.c_int,
                                      _vp, _vp, _vp, _vp, _vp, _vp]
     L.splash_dev_ncellflow.argtypes = [C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp]
-    L.splash_static_rasters_run.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_double, C.c_double,
-                                            C.c_int, C.c_double, C.POINTER(StaticOut), C.c_char_p, C.c_size_t]
-    L.splash_dev_sinkfill.argtypes = [C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp,
-                                      C.POINTER(C.c_int), _vp]
-    L.splash_dev_flow_accumulation.argtypes = [C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp,
-                                               C.POINTER(C.c_int), _vp]
+    if not (os.environ.get("SPLASH_HIP_LIBRARY") and not hasattr(L, "splash_dev_sinkfill")):
+        # (an A/B build of an earlier commit, selected by SPLASH_HIP_LIBRARY, may predate these three)
+        L.splash_static_rasters_run.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_double, C.c_double,
+                                                C.c_int, C.c_double, C.POINTER(StaticOut), C.c_char_p,
+                                                C.c_size_t]
+        L.splash_dev_sinkfill.argtypes = [C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp,
+                                          C.POINTER(C.c_int), _vp]
+        L.splash_dev_flow_accumulation.argtypes = [C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp,
+                                                   C.POINTER(C.c_int), _vp]
     L.splash_dev_run_all.argtypes = [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, C.c_size_t,
                                      _vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(DevOut), _vp]
     L.splash_dev_synth_statics.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_size_t,
