@@ -271,13 +271,19 @@ __device__ __forceinline__ DayRecord rec_load(const double* __restrict__ base, s
 // inlined copy of the day step instead of four -- was tried: the turn a lane needs when it starts
 // spin-up #2 in the middle of that loop cost more than the smaller code saved: 2.2-4.4 s vs 1.35 s
 // for 2.1 M cells.)
-template <bool CACHED>
+// READBACK: a kernel of its own for the long tail -- jobs whose 365 records are in the cache already
+// (a preceding one-pass launch of the general kernel stored them): no forcing, no day terms, no
+// viscosity tables, i.e. a fraction of the code and of the live values of the general kernel.  The
+// tail is ~1000 passes x 365 sequential day steps of lone wavefronts, every instruction of which is
+// latency; compiled together with the general loop its day step carried ~100 v_readlane (scalar
+// registers spilled to vector lanes) and ~300 s_mov per day that the smaller kernel does not need.
+template <bool CACHED, bool READBACK = false>
 __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPhaseArgs a)
 {
     const size_t nin = a.n_in ? (size_t)*a.n_in : a.ncell;
-    if ((size_t)blockIdx.x * kBlock >= nin) return; // whole workgroup past the list
+    if ((size_t)blockIdx.x * kBlock + a.slot0 >= nin) return; // whole workgroup past the list
     lds_tables_init();
-    const size_t slot = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t slot = (size_t)blockIdx.x * kBlock + threadIdx.x + a.slot0;
     const bool valid = slot < nin;
     const size_t sl = valid ? slot : nin - 1;
     const size_t ci = a.wl_in ? (size_t)a.wl_in[sl] : a.cell0 + sl;
@@ -294,12 +300,17 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     CellConst c;
     DayOut o;
     double pet_sum = 0.0, p_sum = 0.0;
-    if (a.fresh) {
+    bool finished_before = false; // a job of this list that an earlier launch of the phase completed
+    if (!READBACK && a.fresh) {
         stage = 1;
         count = 1;
         cell_setup(c, a.par, a.ldp, ci, a.par[P_CELLOUT * a.ldp + ci], a.vt);
     } else {
-        const int m = a.meta[ci];
+        int m = a.meta[ci];
+        if (m < 0) {
+            finished_before = true;
+            m = (2 << 16) | 1;
+        }
         stage = m >> 16;
         count = m & 0xFFFF;
         cell_setup(c, a.par, a.ldp, ci, stage == 1 ? a.par[P_CELLOUT * a.ldp + ci] : a.ai[ci], a.vt);
@@ -315,9 +326,9 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     // the next pass): from the cache when there is one, from the forcing otherwise
     auto day_one = [&](State& st_, DayOut& o_, double* p_day) {
         DayRecord r;
-        if (CACHED && cached && p_day == nullptr) {
+        if (READBACK || (CACHED && cached && p_day == nullptr)) {
             r = rec_load(a.cache, a.cache_cap, 0, sl);
-        } else {
+        } else if constexpr (!READBACK) {
             double sw0, tc0, pn0;
             f.raw(0, sw0, tc0, pn0);
             f.split<true>(d0, tc0, pn0, 0.0, r.rain, r.snf);
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     };
     State cur;
     double e_wn;
-    if (a.fresh) {
+    if (!READBACK && a.fresh) {
         cur = State{c.RES, 0.0, 0.0, 0.0, 0.0}; // wn_vec(n,RES), others 0, read at [n-1] (:1633-1648)
         double p0;
         day_one(cur, o, &p0);
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     } else {
         cur = State{a.state[ci], a.state[a.lds + ci], a.state[2 * a.lds + ci],
                     a.state[3 * a.lds + ci], a.state[4 * a.lds + ci]};
-        if (CACHED && cached) { // fill day 1's record (the closing steps of this launch read it)
+        if (!READBACK && CACHED && cached) { // fill day 1's record (the closing steps of this launch read it)
             State tmp = cur;
             double p0;
             day_one(tmp, o, &p0);
@@ -364,11 +375,11 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     // an exact 2- or 3-cycle after a few dozen passes.  The checkpoint lives in LDS (one compare
     // per pass); it restarts with every phase, moving to the current state whenever the number of
     // passes since the phase began is a power of two.
-    bool done = !valid;
+    bool done = !valid || finished_before || (READBACK && !cached);
     for (int it = 0; it < a.budget; it++) {
-        const bool acc = a.fresh && it == 0; // first pass of spin-up #1 (uniform)
+        const bool acc = !READBACK && a.fresh && it == 0; // first pass of spin-up #1 (uniform)
         // cur = state after day 1 of this pass (== the parked start-of-pass state)
-        if (CACHED && cached && it > 0) {
+        if (READBACK || (CACHED && cached && it > 0)) {
             // read-back pass: next day's record is requested a day ahead
             DayRecord r = rec_load(a.cache, a.cache_cap, 1, sl);
             for (int i = 1; i < a.n; i++) {
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 day_update(c, r.T, r.rain, r.snf, cur, o);
                 r = rn;
             }
-        } else {
+        } else if constexpr (!READBACK) {
             // order of the day's vector-memory traffic as in k_run_all: gathers at the top; once
             // the terms are finished, tomorrow's forcing (and the record's stores); everything is
             // waited for at the end of the day, half a day old
@@ -464,6 +475,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 a.state[3 * a.lds + ci] = cur.td;
                 a.state[4 * a.lds + ci] = cur.nd;
                 if (a.passes) a.passes[a.ntotal + ci] = count;
+                a.meta[ci] = -1; // completed (a later launch over the same list leaves it alone)
                 done = true;
             }
         } else {
@@ -471,7 +483,8 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         }
         if (__all(done)) break;
     }
-    if (!done) { // park the job (its start-of-pass state) and queue the cell for the next phase
+    if (!done && valid && !finished_before && !(READBACK && !cached)) { // park the job (its start-of-pass
+                                                                        // state), queue the cell for the next phase
         a.state[ci] = s_e[0][threadIdx.x];
         a.state[a.lds + ci] = s_e[1][threadIdx.x];
         a.state[2 * a.lds + ci] = s_e[2][threadIdx.x];
@@ -1439,7 +1452,9 @@ hipError_t launch_snow_threshold(size_t ncell, int nt, const double* tc, size_t 
 hipError_t launch_spin_phase(const SpinPhaseArgs& a, hipStream_t s)
 {
     if (a.ncell == 0) return hipSuccess;
-    if (a.cache)
+    if (a.readback)
+        hipLaunchKernelGGL((k_spin_phase<true, true>), dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
+    else if (a.cache)
         hipLaunchKernelGGL(k_spin_phase<true>, dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
     else
         hipLaunchKernelGGL(k_spin_phase<false>, dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);

@@ -74,6 +74,8 @@ struct SpinPhaseArgs {
     size_t cache_cap;       // jobs (launch positions) the cache has room for
     size_t cell0;           // phase 0 runs in blocks of cache_cap cells: first cell of this launch
     size_t ntotal;          // cells of the whole call (row stride of `passes`)
+    size_t slot0;           // first launch position this launch handles (tail: jobs beyond the cache)
+    int readback;           // 1: the read-back kernel (every job's records are in the cache already)
 };
 size_t spin_cache_bytes_per_slot();
 
