@@ -1561,6 +1561,7 @@ hipError_t launch_sinkfill(int H, int W, const double* elev, double resolution_m
     }
     if (sweeps_out) *sweeps_out = sweeps;
     (void)hipFreeAsync(changed, s);
+    if (e == hipSuccess && h_changed) e = hipErrorNotReady; // still relaxing at the bound: never seen
     return e != hipSuccess ? e : hipGetLastError();
 }
 
