@@ -272,7 +272,7 @@ int splash_unswc_run(size_t ncell, int nt, const double* wn /*[nt][ncell]*/,
                      double* theta, char* err, size_t errlen);
 
 /* test hook: the device build of the FP64 log/exp/pow/acos used by the day step, for n arguments
- * (host pointers): out [5][n] = flog(x), fexp(x), fpow(x,y), facos(x), fsqrt(x) */
+ * (host pointers): out [7][n] = flog(x), fexp(x), fpow(x,y), facos(x), fsqrt(x), fatan(x), fatan2(x,y) */
 int splash_dev_math_probe(size_t n, const double* x, const double* y, double* out);
 
 /* test hook: the day loop's own forms of SPLASH::moist_surf (z = 10 cm, src/SPLASH.cpp:1265,

@@ -331,10 +331,10 @@ def evap_batch(lat, elv, sw, n, y, sw_in, tc, slop, asp, snow, nd):
 
 
 def math_probe(x, y):
-    """test hook: device flog(x), fexp(x), fpow(x, y), facos(x), fsqrt(x) -> [5, n]"""
+    """test hook: device flog(x), fexp(x), fpow(x, y), facos(x), fsqrt(x), fatan(x), fatan2(x, y) -> [7, n]"""
     xa, xp = _d(x)
     ya, yp = _d(y)
-    out = np.empty((5, len(xa)))
+    out = np.empty((7, len(xa)))
     check(lib.splash_dev_math_probe(len(xa), xp, yp, out.ctypes.data_as(_dp)),
           "splash_dev_math_probe")
     return out

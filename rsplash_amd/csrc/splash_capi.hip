@@ -806,12 +806,12 @@ extern "C" int splash_dev_math_probe(size_t n, const double* x, const double* y,
     DevBuf dx, dy, dout;
     HIP_TRY(dx.alloc(n * 8), nullptr, 0);
     HIP_TRY(dy.alloc(n * 8), nullptr, 0);
-    HIP_TRY(dout.alloc(5 * n * 8), nullptr, 0);
+    HIP_TRY(dout.alloc(7 * n * 8), nullptr, 0);
     HIP_TRY(hipMemcpy(dx.p, x, n * 8, hipMemcpyHostToDevice), nullptr, 0);
     HIP_TRY(hipMemcpy(dy.p, y, n * 8, hipMemcpyHostToDevice), nullptr, 0);
     HIP_TRY(launch_math_probe(n, dx.as<double>(), dy.as<double>(), dout.as<double>(), nullptr),
             nullptr, 0);
-    HIP_TRY(hipMemcpy(out, dout.p, 5 * n * 8, hipMemcpyDeviceToHost), nullptr, 0);
+    HIP_TRY(hipMemcpy(out, dout.p, 7 * n * 8, hipMemcpyDeviceToHost), nullptr, 0);
     return SPLASH_OK;
 }
 

@@ -1052,6 +1052,8 @@ __global__ __launch_bounds__(kBlock) void k_math_probe(size_t n, const double* x
     out[2 * n + i] = fpow(x[i], y[i]);
     out[3 * n + i] = facos(x[i]);
     out[4 * n + i] = fsqrt(x[i]);
+    out[5 * n + i] = fatan(x[i]);
+    out[6 * n + i] = fatan2(x[i], y[i]);
 }
 
 // The day loop's own forms of moist_surf() and inf_GA() (splash_device.hpp: shared log/exp algebra,
@@ -1799,14 +1801,16 @@ __global__ __launch_bounds__(kBlock) void k_terrain(int H, int W, const double* 
     double a, b, c, d, z, f, g, h, k; // a b c / d z f / g h k  (north row first)
     window_row(elev, H, W, r0 - 1, cidx, a, b, c);
     window_row(elev, H, W, r0, cidx, d, z, f);
+    window_row(elev, H, W, r0 + 1, cidx, g, h, k);
     const int r1 = r0 + kStripRows < H ? r0 + kStripRows : H;
     for (int r = r0; r < r1; r++) {
-    window_row(elev, H, W, r + 1, cidx, g, h, k);
+    // the row after next is requested now and waited for before this row's stores are issued
+    // (loads and stores share one counter: see k_run_all), a whole row of arithmetic later
+    double gn, hn, kn;
+    window_row(elev, H, W, r + 2, cidx, gn, hn, kn);
     const double* s_row = rows + (size_t)r * kRowTerms;
     const size_t i = (size_t)r * W + cidx;
     const double lat = s_row[0], dx = s_row[1], dy = s_row[2], dd = s_row[3];
-    if (lat_o) __builtin_nontemporal_store((z == z) ? lat : __builtin_nan(""), lat_o + i);
-    if (res_o) __builtin_nontemporal_store((z == z) ? s_row[4] : __builtin_nan(""), res_o + i);
     const bool inner = r > 0 && r < H - 1 && cidx > 0 && cidx < W - 1;
     double sl = __builtin_nan(""), as = __builtin_nan(""), fd = __builtin_nan("");
     if (inner && z == z) {
@@ -1814,11 +1818,11 @@ __global__ __launch_bounds__(kBlock) void k_terrain(int H, int W, const double* 
         if (sum8 == sum8) {
             const double zx = div_cr((c + 2.0 * f + k) - (a + 2.0 * d + g), 8.0 * dx, s_row[8]); // eastward
             const double zy = div_cr((a + 2.0 * b + c) - (g + 2.0 * h + k), 8.0 * dy, s_row[9]); // northward
-            sl = atan(sqrt(zx * zx + zy * zy)) / kPir;
+            sl = fatan(fsqrt_nn(zx * zx + zy * zy)) * (1.0 / kPir);
             if (zx == 0.0 && zy == 0.0) {
                 as = 90.0;
             } else {
-                as = atan2(-zx, -zy) / kPir; // azimuth of the downslope direction
+                as = fatan2(-zx, -zy) * (1.0 / kPir); // azimuth of the downslope direction
                 if (as < 0.0) as += 360.0;
             }
         }
@@ -1846,11 +1850,15 @@ __global__ __launch_bounds__(kBlock) void k_terrain(int H, int W, const double* 
         if (sl != sl) sl = 0.0;
         if (as != as) as = 0.0;
     }
+    asm volatile("" : "+v"(gn), "+v"(hn), "+v"(kn) : : "memory");
+    if (lat_o) __builtin_nontemporal_store((z == z) ? lat : __builtin_nan(""), lat_o + i);
+    if (res_o) __builtin_nontemporal_store((z == z) ? s_row[4] : __builtin_nan(""), res_o + i);
     if (slope) __builtin_nontemporal_store(sl, slope + i);
     if (aspect) __builtin_nontemporal_store(as, aspect + i);
     if (flowdir) flowdir[i] = fd; // read again by k_ncellflow: default cache policy
     a = d; b = z; c = f; // the window slides down one row
     d = g; z = h; f = k;
+    g = gn; h = hn; k = kn;
     }
     }
 }

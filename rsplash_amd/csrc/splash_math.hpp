@@ -305,4 +305,54 @@ SPL_HD void facos2(double x1, double x2, double& a1, double& a2)
     a2 = small2 ? as2 : al2;
 }
 
+// arc tangent, fdlibm s_atan.c scheme (argument reduction at 7/16, 11/16, 19/16, 39/16 with
+// atan(0.5), atan(1), atan(1.5), atan(inf) in two parts; odd/even polynomial in the reduced
+// argument), branch-free: the reduction's numerator, denominator and the two table parts are
+// selected, one reciprocal serves every range.  < 1.5 ulp.  NaN -> NaN, +-inf -> +-pi/2.
+SPL_HD double fatan(double x)
+{
+    const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01,
+                 aT2 = 1.42857142725034663711e-01, aT3 = -1.11111104054623557880e-01,
+                 aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
+                 aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02,
+                 aT8 = 4.97687799461593236017e-02, aT9 = -3.65315727442169155270e-02,
+                 aT10 = 1.62858201153657823623e-02;
+    const double ax = fabs(x);
+    // range  num        den        hi                          lo
+    // <7/16  ax         1          0                           0
+    // <11/16 2ax-1      2+ax       atan(0.5)
+    // <19/16 ax-1       ax+1       atan(1)
+    // <39/16 ax-1.5     1+1.5ax    atan(1.5)
+    // else   -1         ax         atan(inf)
+    const bool r0 = ax < 0.4375, r1 = ax < 0.6875, r2 = ax < 1.1875, r3 = ax < 2.4375;
+    const double num = r0 ? ax : (r1 ? 2.0 * ax - 1.0 : (r2 ? ax - 1.0 : (r3 ? ax - 1.5 : -1.0)));
+    const double den = r0 ? 1.0 : (r1 ? 2.0 + ax : (r2 ? ax + 1.0 : (r3 ? 1.0 + 1.5 * ax : ax)));
+    const double hi = r0 ? 0.0 : (r1 ? 4.63647609000806093515e-01 : (r2 ? 7.85398163397448278999e-01
+                                  : (r3 ? 9.82793723247329054082e-01 : 1.57079632679489655800e+00)));
+    const double lo = r0 ? 0.0 : (r1 ? 2.26987774529616870924e-17 : (r2 ? 3.06161699786838301793e-17
+                                  : (r3 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17)));
+    // den >= 1 except in the last range, where it is ax >= 2.4375 (+inf gives t = -0): ordinary
+    const double rd = frcp(den < 1.0e300 ? den : 1.0e300);
+    double t = num * rd;
+    t = fma(fma(-den, t, num), rd, t); // one correction step: the quotient to ~0.5 ulp
+    t = (ax == HUGE_VAL) ? -0.0 : t;
+    const double z = t * t, w = z * z;
+    const double s1 = z * horner5(aT10, w, aT8, aT6, aT4, aT2, aT0);
+    const double s2 = w * horner4(aT9, w, aT7, aT5, aT3, aT1);
+    const double small = t - t * (s1 + s2);
+    const double big = hi - ((t * (s1 + s2) - lo) - t);
+    const double r = r0 ? small : big;
+    return (x != x) ? x : ((x < 0.0) ? -r : r);
+}
+
+// atan2(y, x) with fdlibm's quadrant rules (e_atan2.c) for finite arguments that are not both zero
+// (the caller's case); y/x is an IEEE division, so x = 0 gives atan(inf) = pi/2.
+SPL_HD double fatan2(double y, double x)
+{
+    const double pi = 3.1415926535897931160e+00, pi_lo = 1.2246467991473531772e-16;
+    const double z = fatan(fabs(y / x));
+    const double q = (x < 0.0) ? pi - (z - pi_lo) : z; // quadrants II/III mirror about pi/2
+    return (y < 0.0) ? -q : q;
+}
+
 } // namespace splash

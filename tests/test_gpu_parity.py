@@ -99,6 +99,16 @@ def test_device_math_vs_libm(api):
               -1 + rng.uniform(0, 1e-9, n // 4)]
     oa = api.math_probe(c, y)[3]
     assert ulp(oa, np.arccos(c)).max() <= 2.5
+    # arc tangents of the static-raster kernel: every reduction range, both signs, the quadrants
+    t = np.r_[rng.uniform(-3, 3, n // 2), np.exp(rng.uniform(-30, 30, n // 4)) * rng.choice([-1, 1], n // 4),
+              rng.choice([0.4375, 0.6875, 1.1875, 2.4375], n // 4) * (1 + rng.uniform(-1e-12, 1e-12, n // 4))]
+    yy = rng.uniform(-5, 5, n)
+    yy[:100] = 0.0           # x = 0 in fatan2(y = t, x = yy): +-pi/2
+    ot = api.math_probe(t, yy)
+    assert ulp(ot[5], np.arctan(t)).max() <= 2.0
+    assert ulp(ot[6], np.arctan2(t, yy)).max() <= 2.5
+    st = api.math_probe(np.array([np.inf, -np.inf, np.nan, 0.0, -0.0]), np.ones(5))[5]
+    assert st[0] == np.pi / 2 and st[1] == -np.pi / 2 and np.isnan(st[2]) and st[3] == 0 and st[4] == 0
     sp = api.math_probe(np.array([0.0, -1.0, np.inf, np.nan, 1.0]), np.ones(5))
     assert sp[0][0] == -np.inf and np.isnan(sp[0][1]) and sp[0][2] == np.inf and np.isnan(sp[0][3])
     assert sp[0][4] == 0.0 and sp[1][0] == 1.0 and sp[1][2] == np.inf and np.isnan(sp[1][3])
