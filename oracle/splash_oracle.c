@@ -964,6 +964,16 @@ void orc_run_one_day(double lat, double elv, int n, int y, double wn, double sw_
 }
 
 /* src/SPLASH.cpp:1594-1749 */
+/* analysis hook (tools/tail_periods.py): when set, every pass of the NEXT spin-ups records the state
+ * after its day 1 -- (sm, swe, qin, tdrain, nds) -- as row `pass` of buf [cap][5] */
+static __thread double* g_spin_trace = NULL;
+static __thread int g_spin_trace_cap = 0;
+void orc_set_spin_trace(double* buf, int cap)
+{
+    g_spin_trace = buf;
+    g_spin_trace_cap = cap;
+}
+
 int orc_spin_up(double lat, double elv, int n, int y, const double* sw_in, const double* tair,
                 const double* pn, double slop, double asp, const double* snowfall,
                 const double* soil_info, double* sm_o, double* snow_o, double* qin_o,
@@ -1035,6 +1045,14 @@ int orc_spin_up(double lat, double elv, int n, int y, const double* sw_in, const
             nds_prev_vec[i] = dsm.nd;
         }
         start_sm = wn_vec[0];
+        if (g_spin_trace && spin_count < g_spin_trace_cap) {
+            double* t5 = g_spin_trace + 5 * (size_t)spin_count;
+            t5[0] = wn_vec[0];
+            t5[1] = snow_vec[0];
+            t5[2] = qin_prev_vec[0];
+            t5[3] = tdrain_vec[0];
+            t5[4] = nds_prev_vec[0];
+        }
         orc_run_one_day(lat, elv, 1, y, wn_vec[n - 1], sw_in[0], tair[0], pn[0], slop, asp,
                         snow_vec[n - 1], snowfall[0], soil_info, qin_prev_vec[n - 1],
                         tdrain_vec[n - 1], nds_prev_vec[n - 1], &dsm, NULL);

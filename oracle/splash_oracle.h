@@ -199,6 +199,7 @@ void orc_synth_forcing(uint64_t seed, int H, int W, int64_t cell0, int ncell, in
 int orc_calendar(int year0, int nt, int* doy, int* year, int* month, int* month_id);
 
 int orc_max_threads(void);
+void orc_set_spin_trace(double* buf, int cap);
 int orc_threads_obtained(int n);
 
 #ifdef __cplusplus

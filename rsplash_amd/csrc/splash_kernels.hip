@@ -475,7 +475,11 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 a.state[3 * a.lds + ci] = cur.td;
                 a.state[4 * a.lds + ci] = cur.nd;
                 if (a.passes) a.passes[a.ntotal + ci] = count;
+#ifdef SPL_TAIL_STATS
+                a.meta[ci] = -(it + 2) - (READBACK ? 100000 : 0); // executed iterations of this launch
+#else
                 a.meta[ci] = -1; // completed (a later launch over the same list leaves it alone)
+#endif
                 done = true;
             }
         } else {
