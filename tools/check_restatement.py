@@ -148,6 +148,7 @@ ORACLE_ONLY = [
     (r"^if\(Au>0\.0&&wtd>=depth&&", "conditioning monitors (orc_fragile_events / orc_critical_events): no effect on results"),
     (r"^if\(dvap_out\)$|^if\((sm|snow|qin|tdrain|ro|snwage|pet)_o\)$", "optional outputs"),
     (r"^\w+_vec=|^nb=sizeof|^p=\(i==0\)", "spin_up: one malloc'd block instead of std::vectors; previous-day index"),
+    (r"^if\(g_spin_trace&&|^t5=g_spin_trace\+|^t5\[\d\]=", "spin_up: analysis hook recording the state after day 1 of a pass (tools/tail_periods.py): no effect on results"),
     (r"^k=\(size_t\)i\*ostride$|^if\(o\[\d+\]\)$|^if\(state_end\)$|^(wn|swe|qin|td|nd)=\w|^o\[7\]\[k\]=dv\.rn_d/1e6$", "run_all: strided outputs, optional series, the carried state; o[7] = netr_vec[i] = dvap.rn_d/1e6 (:1907)"),
 ]
 
