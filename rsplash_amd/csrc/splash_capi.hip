@@ -416,7 +416,7 @@ extern "C" size_t splash_dev_spin_up_work_size(size_t ncell)
 
 // phases [ph0, ph1) of the spin-up (see k_spin_phase): all but the last finish all but a few cells
 // per thousand, the last is the long tail
-constexpr int kSpinPhases = 6;
+constexpr int kSpinPhases = 8;
 static int spin_phases(const splash_calendar* cal, size_t ncell, const double* sw_in,
                        const double* tc, const double* pn, size_t ldf, const double* Tt,
                        double* cellpar, size_t ldp, double* state, size_t lds, int* passes,
@@ -461,9 +461,9 @@ static int spin_phases(const splash_calendar* cal, size_t ncell, const double* s
     // A wavefront runs as many passes as its slowest lane, so the early phases are short and the
     // worklist is compacted after each (synthetic grid: 20-50 % of the cells need 2 passes of
     // spin-up #2, 35-60 % 3, 6-20 % 4, 2-8 % 5, 3-12 % more): phase 0 = the pass of spin-up #1 + 2
-    // passes of #2 for every cell, then 1, 2, 4 and 16 passes for those that are left.
-    static const int budget_full[kSpinPhases] = {8, 8, 16, 32, 64, 2100},
-                     budget_fast[kSpinPhases] = {3, 1, 2, 4, 16, 1100};
+    // passes of #2 for every cell, then 1, 1, 1, 2, 4 and 16 passes for those that are left.
+    static const int budget_full[kSpinPhases] = {8, 4, 4, 8, 16, 32, 64, 2100},
+                     budget_fast[kSpinPhases] = {3, 1, 1, 1, 2, 4, 16, 1100};
     const int* budget = passes ? budget_full : budget_fast;
     double* const cache_all = (double*)(w + o_cache);
     a.cache_cap = spin_cache_cap(ncell);
