@@ -479,10 +479,27 @@ static int spin_phases(const splash_calendar* cal, size_t ncell, const double* s
         // the cache of day terms pays from the second pass of a launch on
         a.cache = budget[ph] >= 2 ? cache_all : nullptr;
         if (ph == 0) { // every cell, in blocks the size of the cache
+            // per block: one pass of the general kernel (spin-up #1's pass: it stores the block's
+            // records), then the other passes of the phase by the read-back kernel, which is the
+            // smaller program (see k_spin_phase<true, true>) and does the queueing
+            const bool split = a.cache != nullptr && budget[ph] >= 2;
             for (size_t c0 = 0; c0 < ncell; c0 += a.cache_cap) {
                 a.cell0 = c0;
                 a.ncell = std::min(a.cache_cap, ncell - c0);
-                HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+                if (split) {
+                    a.budget = 1;
+                    a.no_queue = 1;
+                    HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+                    a.budget = budget[ph] - 1;
+                    a.no_queue = 0;
+                    a.fresh = 0;
+                    a.readback = 1;
+                    HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+                    a.readback = 0;
+                    a.fresh = 1;
+                } else {
+                    HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+                }
             }
             a.cell0 = 0;
             a.ncell = ncell;

@@ -495,9 +495,11 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         a.state[3 * a.lds + ci] = s_e[3][threadIdx.x];
         a.state[4 * a.lds + ci] = s_e[4][threadIdx.x];
         a.meta[ci] = (stage << 16) | count;
-        if (a.pending) a.pending[ci] = 1;
-        const uint32_t k = atomicAdd(a.n_out, 1u);
-        a.wl_out[k] = (uint32_t)ci;
+        if (!a.no_queue) {
+            if (a.pending) a.pending[ci] = 1;
+            const uint32_t k = atomicAdd(a.n_out, 1u);
+            a.wl_out[k] = (uint32_t)ci;
+        }
     }
 }
 

@@ -76,6 +76,8 @@ struct SpinPhaseArgs {
     size_t ntotal;          // cells of the whole call (row stride of `passes`)
     size_t slot0;           // first launch position this launch handles (tail: jobs beyond the cache)
     int readback;           // 1: the read-back kernel (every job's records are in the cache already)
+    int no_queue;           // 1: park unfinished jobs without queueing them (a launch over the same
+                            //    cells follows and does the queueing)
 };
 size_t spin_cache_bytes_per_slot();
 
