@@ -383,7 +383,12 @@ extern "C" int splash_dev_snow_threshold(size_t ncell, int nt, const double* tc,
 // Phase 0 walks the cells in blocks of that many; the later phases' worklists are far shorter.
 static size_t spin_cache_cap(size_t ncell)
 {
-    size_t cap = std::min<size_t>(ncell, (size_t)1 << 19);
+    size_t lim = (size_t)1 << 19;
+    // test / tuning aid: a small capacity makes small grids walk phase 0 in several blocks and gives
+    // the later phases jobs beyond the cache (read once: the workspace layout depends on it)
+    static const char* env = getenv("SPLASH_HIP_SPIN_CACHE_CAP");
+    if (env && atol(env) >= 64) lim = (size_t)atol(env);
+    size_t cap = std::min<size_t>(ncell, lim);
     return (cap + 63) & ~(size_t)63;
 }
 

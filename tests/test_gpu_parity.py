@@ -1169,6 +1169,60 @@ def test_sinkfill_and_flow_accumulation_vs_oracle(api, oracle):
         api.static_rasters(np.full((4, 4), np.nan), 60.0, 0.0025, 0.0025)   # all NA: no mean resolution
 
 
+def test_spin_up_blocking_and_cache_overflow_give_the_same_bits():
+    """The spin-up's launches depend on the capacity of the day-term cache: phase 0 walks the grid in
+    blocks of it (a fill launch + a read-back launch per block), the later phases send the jobs beyond
+    it through the general kernel.  With a capacity of 128 slots (SPLASH_HIP_SPIN_CACHE_CAP, read once
+    per process: hence the child processes) a 64 x 128 grid exercises every one of those paths; states,
+    aridity index and pass counts must be bit-identical to the default layout, in both pass modes."""
+    import subprocess, sys, tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from rsplash_amd import api
+dev = torch.device("cuda:0")
+H, W, nt = 64, 128, 365
+n = H * W
+cal = api.Calendar.from_dates(np.datetime64("2001-01-01") + np.arange(nt))
+f64 = dict(dtype=torch.float64, device=dev)
+lat, elev, slop, asp, res = (torch.empty(n, **f64) for _ in range(5))
+soil, au = torch.empty(6, n, **f64), torch.empty(3, n, **f64)
+api.dev_synth_statics(777000, H, W, 0, n, 1, lat, elev, slop, asp, res, soil, au)
+sw, tc, pn = (torch.empty(nt, n, **f64) for _ in range(3))
+api.dev_synth_forcing(777000, cal, 0, nt, 0, n, lat, elev, sw, tc, pn, n)
+par0 = torch.empty(api.NPAR, n, **f64); Tt = torch.empty(n, **f64)
+api.dev_soil_hydro(n, lat, elev, slop, asp, res, soil, au, par0)
+api.dev_snow_threshold(n, nt, tc, n, par0, n, Tt)
+out = {}
+for mode in ("fast", "passes"):
+    par, state = par0.clone(), torch.empty(api.NSTATE, n, **f64)
+    work = torch.empty(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
+    passes = torch.zeros(2, n, dtype=torch.int32, device=dev) if mode == "passes" else None
+    api.dev_spin_up(cal, n, sw, tc, pn, n, Tt, par, n, state, n, work, passes=passes)
+    torch.cuda.synchronize()
+    out[mode + "_state"] = state.cpu().numpy()
+    out[mode + "_ai"] = par[15].cpu().numpy()
+    if passes is not None: out["passes"] = passes.cpu().numpy()
+np.savez(sys.argv[1], **out)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, cap in (("default", None), ("cap128", "128")):
+            env = dict(os.environ)
+            env.pop("SPLASH_HIP_SPIN_CACHE_CAP", None)
+            if cap:
+                env["SPLASH_HIP_SPIN_CACHE_CAP"] = cap
+            f = os.path.join(d, tag + ".npz")
+            subprocess.run([sys.executable, "-c", code, f], env=env, check=True)
+            res[tag] = dict(np.load(f))
+    a, b = res["default"], res["cap128"]
+    for k in a:
+        assert np.array_equal(a[k].view(np.int64) if a[k].dtype == np.float64 else a[k],
+                              b[k].view(np.int64) if b[k].dtype == np.float64 else b[k]), k
+    assert np.array_equal(a["fast_state"].view(np.int64), a["passes_state"].view(np.int64))
+    assert a["passes"][1].max() == 1000 and a["passes"][1].min() >= 1   # the tail is exercised
+
+
 def test_overlapped_spin_up_gives_the_same_bits(api, oracle):
     """splash_dev_spin_up_begin / _finish with the transient run of the finished cells in between
     (skip mask) and the late cells in list mode afterwards == the plain sequence, bit for bit, water-
