@@ -508,15 +508,19 @@ static int spin_phases(const splash_calendar* cal, size_t ncell, const double* s
             }
             a.cell0 = 0;
             a.ncell = ncell;
-        } else if (ph == kSpinPhases - 1 && a.cache && budget[ph] > 1) {
-            // The tail as three launches over the SAME worklist (launch positions = cache slots):
-            // one pass of the general kernel stores every job's 365 records; the read-back kernel --
-            // a far smaller program: see k_spin_phase<true, true> -- runs the other passes of the jobs
-            // that have a slot; the general kernel runs the jobs beyond the cache's capacity, if any
-            // (a list longer than 2^19 jobs: grid blocks past the list's end return at once).
+        } else if (a.cache && budget[ph] > 1) {
+            // A phase of several passes as three launches over the SAME worklist (launch positions =
+            // cache slots): one pass of the general kernel stores every job's 365 records (it parks
+            // the jobs without queueing them); the read-back kernel -- a far smaller program: see
+            // k_spin_phase<true, true> -- runs the other passes of the jobs that have a slot and
+            // queues what is left; the general kernel does the same for the jobs beyond the cache's
+            // capacity, if any (a list longer than 2^19 jobs: grid blocks past the list's end return
+            // at once).
             const size_t n_all = a.ncell;
             a.budget = 1;
+            a.no_queue = 1;
             HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+            a.no_queue = 0;
             a.budget = budget[ph] - 1;
             a.readback = 1;
             a.ncell = std::min(n_all, a.cache_cap);
