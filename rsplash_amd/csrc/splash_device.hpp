@@ -952,7 +952,11 @@ __device__ __forceinline__ double inf_GA(const CellConst& c, double wn, double K
     const double tdur = 6.0;
     const double r = P * (1.0 / 6.0); // P/tdur
     double I = P;
+#if defined(SPL_ABLATE) && SPL_ABLATE == 11
+    if (false) {
+#else
     if (!(r <= Ksat)) {
+#endif
         SPL_SITE();
         const double theta_i = moist_surf(c, wn);
         const double delta_theta = (c.theta_s - theta_i);
@@ -1112,7 +1116,11 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
     const double T_uns1 = transmittance_uns(c, Ksat_visc, sm, Acs_out);
     const double sm1 = sm;
     double T_uns = T_uns1, T_sat;
+#if defined(SPL_ABLATE) && SPL_ABLATE == 12
+    if (false) {
+#else
     if (c.deep) { // depth >= 2.0: vertical drainage corrections :1433-1450
+#endif
         SPL_SITE();
         // :984-990 clamp of the start-of-day volumetric content, :1267 theta_m
         // (both quotients with the reference's rounding: the exponent 3 + 2/lambda reaches 1e4, so
@@ -1180,7 +1188,11 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
     // :1511-1547 transmittance after upslope inflow (no vertical-drainage correction here);
     // identical to the first evaluation whenever the inflow left sm unchanged
     double Acs2 = Acs_out, T_uns2 = T_uns1;
+#if defined(SPL_ABLATE) && SPL_ABLATE == 13
+    if (false) {
+#else
     if (sm != sm1) {
+#endif
         SPL_SITE();
         T_uns2 = transmittance_uns(c, Ksat_visc, sm, Acs2);
     }
