@@ -243,16 +243,26 @@ int splash_dev_sinkfill(int H, int W, const double* elev, double resolution_m, d
 int splash_dev_flow_accumulation(int H, int W, const double* flowdir, const double* elev,
                                  int tau_codes, const double* resolution_m, double* ups_ncell,
                                  double* ups_area, int* levels, void* stream);
+/* Contributing area by the multiple-flow-direction algorithm of Quinn et al. (1991) -- what
+ * `topmodel::topidx(as.matrix(elev), resolution)$area` returns for R/upslope_area.R:21 (small areas;
+ * third-party code outside the reference tree: the published algorithm, parity unpinned).  Every
+ * cell starts with resolution_m^2 and passes its accumulated area to all lower neighbours in
+ * proportion to tan(beta) * contour length (0.5 and 0.354 cell sizes).  elev: the (sink-filled)
+ * surface, NaN = NA; area [H*W] in m2.  Deterministic (pull order fixed).  Synchronises the stream. */
+int splash_dev_mfd_area(int H, int W, const double* elev, double resolution_m, double* area,
+                        int* levels, void* stream);
 
 /* The static rasters in ONE call on host buffers (what an R caller binds): everything
  * R/splash.grid.R:96-110 and upslope_area() (R/upslope_area.R:12-58) derive from the elevation
  * matrix.  elev [H*W] row-major (raster::as.matrix / getValues order), NaN = NA.  Outputs [H*W], any
  * may be NULL: slope, aspect (degrees, of the RAW dem as splash.grid takes them), lat, resolution (m);
  * filled (sink-filled surface: degree as in sinkfill(dem, mean resolution, degree)), flowdir (raster
- * codes, of the FILLED surface), ups_ncell, ups_area (m2), ncellin, ncellout (met='top' windows). */
+ * codes, of the FILLED surface), ups_ncell, ups_area (m2: D8, as upslope_areav2), ncellin, ncellout
+ * (met='top' windows), ups_area_mfd (m2: as upslope_area's topidx). */
 typedef struct splash_static_out {
     double *slope, *aspect, *lat, *resolution;
     double *filled, *flowdir, *ups_ncell, *ups_area, *ncellin, *ncellout;
+    double* ups_area_mfd; /* topidx()$area: multiple-flow-direction area of the filled surface, m2 */
 } splash_static_out;
 int splash_static_rasters_run(int H, int W, const double* elev, double ymax, double yres, double xres,
                               int na_to_zero, double degree, const splash_static_out* out,

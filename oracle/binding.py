@@ -127,6 +127,7 @@ class Oracle:
         L.orc_terrain.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_double, C.c_double, C.c_int] + [_dp] * 5
         L.orc_ncellflow.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
         L.orc_sinkfill.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_double, _dp]
+        L.orc_mfd_area.argtypes = [C.c_int, C.c_int, _dp, C.c_double, _dp]
         L.orc_flow_accumulation.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]
         L.orc_synth_statics.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int] + \
             [_dp] * 7
@@ -360,6 +361,14 @@ class Oracle:
         H, W = e.shape
         out = np.empty((H, W))
         self.lib.orc_sinkfill(H, W, ep, C.c_double(resolution_m), C.c_double(degree), out.ctypes.data_as(_dp))
+        return out
+
+    def mfd_area(self, elev, resolution_m):
+        """Quinn et al. (1991) multiple-flow-direction contributing area (serial restatement)"""
+        e, ep = _d(elev)
+        H, W = e.shape
+        out = np.empty((H, W))
+        self.lib.orc_mfd_area(H, W, ep, C.c_double(resolution_m), out.ctypes.data_as(_dp))
         return out
 
     def flow_accumulation(self, flowdir, elev=None, resolution=None, tau=False):

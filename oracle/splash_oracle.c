@@ -1856,6 +1856,59 @@ void orc_flow_accumulation(int H, int W, const double* fd, const double* elev, i
     free(fifo);
 }
 
+/* Multiple-flow-direction contributing area (Quinn et al. 1991; topmodel::topidx()$area of
+ * R/upslope_area.R:21 is third-party code outside the reference tree: parity unpinned).  Serial
+ * statement: cells in order of descending elevation; each takes its own res^2 plus, from every higher
+ * neighbour (E, SE, S, SW, W, NW, N, NE), that neighbour's area times its weight towards this cell
+ * over the neighbour's weight total. */
+static double orc_mfd_weight(double zhi, double zlo, int q, double res)
+{
+    double dist = (q & 1) ? res * 1.4142135623730951 : res;
+    double contour = ((q & 1) ? 0.354 : 0.5) * res;
+    return ((zhi - zlo) / dist) * contour;
+}
+static const double* g_sort_z;
+static int orc_cmp_desc(const void* a, const void* b)
+{
+    double za = g_sort_z[*(const size_t*)a], zb = g_sort_z[*(const size_t*)b];
+    return (za < zb) - (za > zb);
+}
+void orc_mfd_area(int H, int W, const double* z, double res, double* area)
+{
+    static const int DR[8] = {0, 1, 1, 1, 0, -1, -1, -1}, DC[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+    size_t n = (size_t)H * W, m = 0;
+    double* wsum = (double*)calloc(n, sizeof(double));
+    size_t* order = (size_t*)malloc(n * sizeof(size_t));
+    for (size_t i = 0; i < n; i++) {
+        area[i] = NAN;
+        if (isnan(z[i])) continue;
+        order[m++] = i;
+        int r = (int)(i / W), c = (int)(i % W);
+        for (int q = 0; q < 8; q++) {
+            int rr = r + DR[q], cc = c + DC[q];
+            if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+            double zn = z[(size_t)rr * W + cc];
+            if (zn < z[i]) wsum[i] += orc_mfd_weight(z[i], zn, q, res);
+        }
+    }
+    g_sort_z = z;
+    qsort(order, m, sizeof(size_t), orc_cmp_desc);
+    for (size_t k = 0; k < m; k++) {
+        size_t i = order[k];
+        int r = (int)(i / W), c = (int)(i % W);
+        double a = res * res;
+        for (int q = 0; q < 8; q++) {
+            int rr = r + DR[q], cc = c + DC[q];
+            if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+            size_t j = (size_t)rr * W + cc;
+            if (z[j] > z[i]) a += area[j] * (orc_mfd_weight(z[j], z[i], (q + 4) & 7, res) / wsum[j]);
+        }
+        area[i] = a;
+    }
+    free(wsum);
+    free(order);
+}
+
 /* ------------------------------------------------------------------ synthetic inputs */
 
 static inline uint64_t mix64(uint64_t z)

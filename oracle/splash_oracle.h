@@ -179,6 +179,7 @@ void orc_terrain(int H, int W, const double* elev, double ymax, double yres, dou
                  int na_to_zero, double* slope, double* aspect, double* lat, double* resolution,
                  double* flowdir);
 void orc_ncellflow(int H, int W, const double* flowdir, const double* codes9, int pad, double* out);
+void orc_mfd_area(int H, int W, const double* z, double res, double* area);
 void orc_sinkfill(int H, int W, const double* z, double resolution_m, double degree, double* w);
 void orc_flow_accumulation(int H, int W, const double* fd, const double* elev, int tau,
                            const double* resolution, double* ups_ncell, double* ups_area);

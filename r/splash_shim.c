@@ -169,16 +169,18 @@ SEXP C_splash_static_rasters(SEXP elev, SEXP ymax, SEXP yres, SEXP xres, SEXP de
     if (isNull(dim) || LENGTH(dim) != 2 || !isReal(elev)) error("elev must be a numeric [ncol x nrow] matrix");
     const int W = INTEGER(dim)[0], H = INTEGER(dim)[1];
     static const char* names[] = {"slope", "aspect", "lat", "resolution", "filled", "flowdir",
-                                  "ups_ncell", "areacatch", "ncellin", "ncellout", ""};
+                                  "ups_ncell", "areacatch_d8", "ncellin", "ncellout", "areacatch", ""};
     SEXP res = PROTECT(mkNamed(VECSXP, names));
-    double* p[10];
-    for (int k = 0; k < 10; k++) {
+    double* p[11];
+    for (int k = 0; k < 11; k++) {
         SEXP m = PROTECT(allocMatrix(REALSXP, W, H));
         SET_VECTOR_ELT(res, k, m);
         UNPROTECT(1);
         p[k] = REAL(m);
     }
-    splash_static_out out = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9]};
+    /* areacatch = the multiple-flow-direction area, as upslope_area()'s topidx; areacatch_d8 = count x
+     * cell area, as upslope_areav2()'s aread8 */
+    splash_static_out out = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10]};
     char msg[256] = "";
     const int rc = splash_static_rasters_run(H, W, REAL(elev), asReal(ymax), asReal(yres), asReal(xres),
                                              /* na_to_zero (R/splash.grid.R:107) */ 1, asReal(degree), &out,

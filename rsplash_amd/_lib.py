@@ -42,7 +42,7 @@ class DevOut(C.Structure):
 
 
 STATIC_NAMES = ("slope", "aspect", "lat", "resolution", "filled", "flowdir", "ups_ncell", "ups_area",
-                "ncellin", "ncellout")
+                "ncellin", "ncellout", "ups_area_mfd")
 
 
 class StaticOut(C.Structure):  # splash_static_out
@@ -102,6 +102,7 @@ def _load():
                                                 C.c_size_t]
         L.splash_dev_sinkfill.argtypes = [C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp,
                                           C.POINTER(C.c_int), _vp]
+        L.splash_dev_mfd_area.argtypes = [C.c_int, C.c_int, _vp, C.c_double, _vp, C.POINTER(C.c_int), _vp]
         L.splash_dev_flow_accumulation.argtypes = [C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp,
                                                    C.POINTER(C.c_int), _vp]
     L.splash_dev_run_all.argtypes = [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp, C.c_size_t,
@@ -146,7 +147,7 @@ SYMBOLS = (
     "splash_dev_spin_up_pending_count",
     "splash_dev_diag_acc_size", "splash_dev_diag_finalize", "splash_diag_finalize_host",
     "splash_dev_infiltration_probe", "splash_dev_terrain", "splash_dev_ncellflow",
-    "splash_dev_sinkfill", "splash_dev_flow_accumulation", "splash_static_rasters_run",
+    "splash_dev_sinkfill", "splash_dev_flow_accumulation", "splash_dev_mfd_area", "splash_static_rasters_run",
     "splash_dev_run_all", "splash_dev_synth_statics", "splash_dev_synth_forcing",
     "splash_dev_evap_batch", "splash_dev_math_probe", "splash_dev_unswc", "splash_unswc_run",
     "splash_grid_run", "splash_point_run", "splash_mod_spin_up",

@@ -551,10 +551,21 @@ def dev_flow_accumulation(H, W, flowdir, ups_ncell=None, ups_area=None, elev=Non
     return n.value
 
 
-def upslope_area(dem, ymax, yres, xres, degree=1.0):
+def dev_mfd_area(H, W, elev, resolution_m, area, stream=None):
+    """R/upslope_area.R:21 (topidx(...)$area): multiple-flow-direction contributing area in m2 of a
+    (sink-filled) device raster; returns the number of levels"""
+    n = C.c_int(0)
+    check(lib.splash_dev_mfd_area(int(H), int(W), _ptr(elev), float(resolution_m), _ptr(area), C.byref(n),
+                                  stream), "splash_dev_mfd_area")
+    return n.value
+
+
+def upslope_area(dem, ymax, yres, xres, degree=1.0, method="top"):
     """upslope_area(dem, resolution) of R/upslope_area.R:12-58 for a host lon/lat elevation array
-    [H, W]: sink fill with the mean resolution (:14-16), contributing area (:21), flow direction of
-    the FILLED surface and the cells draining in and out (:31-33).  Returns dict(areacatch, ncellin,
+    [H, W]: sink fill with the mean resolution (:14-16), contributing area (method "top": :21, the
+    multiple-flow-direction area of topidx; "tau": the D8 count times the cell area of
+    upslope_areav2, :74, 85-96), flow direction of the FILLED surface and the cells draining in and
+    out (:31-33).  Returns dict(areacatch, ncellin,
     ncellout) like the reference's stack, plus ups_ncell, flowdir and the filled surface."""
     import torch
     e = torch.as_tensor(np.ascontiguousarray(dem, dtype=np.float64), device="cuda")
@@ -568,7 +579,9 @@ def upslope_area(dem, ymax, yres, xres, degree=1.0):
     mean_res = float(m0 + (rv - m0).sum() / rv.size)
     dev_sinkfill(H, W, e, mean_res, filled, degree)
     dev_terrain(H, W, filled, ymax, yres, xres, flowdir=fd)
-    dev_flow_accumulation(H, W, fd, cnt, area, elev=filled, resolution=res)
+    dev_flow_accumulation(H, W, fd, cnt, area, elev=filled, resolution=res)  # :74, 85-96 (TauDEM twin)
+    if method == "top":  # :21 topidx(as.matrix(elev), resolution = mean)$area
+        dev_mfd_area(H, W, filled, mean_res, area)
     for out, codes in ((nin, FLOW_IN_TOP), (nout, FLOW_OUT_TOP)):
         dev_ncellflow(H, W, fd, torch.tensor(codes, dtype=torch.float64, device="cuda"), out)
     torch.cuda.synchronize()

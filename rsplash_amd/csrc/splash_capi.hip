@@ -757,6 +757,17 @@ extern "C" int splash_dev_flow_accumulation(int H, int W, const double* flowdir,
     return SPLASH_OK;
 }
 
+extern "C" int splash_dev_mfd_area(int H, int W, const double* elev, double resolution_m,
+                                   double* area, int* levels, void* stream)
+{
+    REQ(elev && area && H > 0 && W > 0, "mfd_area: NULL argument or empty grid");
+    REQ(resolution_m > 0, "mfd_area: resolution must be positive");
+    REQ((size_t)H * W < ((size_t)1 << 32), "mfd_area: more than 2^32-1 cells");
+    if (int rc = need_device(nullptr, 0)) return rc;
+    HIP_TRY(launch_mfd_area(H, W, elev, resolution_m, area, levels, (hipStream_t)stream), nullptr, 0);
+    return SPLASH_OK;
+}
+
 // unSWC epilogue on device-resident rasters (R/unsSWC.R:14-88, R/unsSWC.grid.R)
 extern "C" int splash_dev_unswc(size_t ncell, int nt, const double* wn, size_t ldw,
                                 const double* soil, double uns_depth, double* wn_z, double* wtd,
@@ -1406,8 +1417,8 @@ extern "C" int splash_static_rasters_run(int H, int W, const double* elev, doubl
     if (int rc = need_device(err, errlen)) return rc;
     const size_t n = (size_t)H * W, nb = n * sizeof(double);
     const bool graph = out->filled || out->flowdir || out->ups_ncell || out->ups_area || out->ncellin ||
-                       out->ncellout;
-    DevBuf de, dsl, das, dla, dre, dfi, dfd, dcn, dar, dni, dno, dcodes;
+                       out->ncellout || out->ups_area_mfd;
+    DevBuf de, dsl, das, dla, dre, dfi, dfd, dcn, dar, dni, dno, dcodes, dmf;
     HIP_TRY(de.alloc(nb), err, errlen);
     HIP_TRY(hipMemcpy(de.p, elev, nb, hipMemcpyHostToDevice), err, errlen);
     if (out->slope) HIP_TRY(dsl.alloc(nb), err, errlen);
@@ -1448,6 +1459,10 @@ extern "C" int splash_static_rasters_run(int H, int W, const double* elev, doubl
             rc = splash_dev_flow_accumulation(H, W, dfd.as<double>(), dfi.as<double>(), 0, dre.as<double>(),
                                               dcn.as<double>(), dar.as<double>(), nullptr, nullptr);
         }
+        if (!rc && out->ups_area_mfd) {
+            HIP_TRY(dmf.alloc(nb), err, errlen);
+            rc = splash_dev_mfd_area(H, W, dfi.as<double>(), mean_res, dmf.as<double>(), nullptr, nullptr);
+        }
         if (!rc && (out->ncellin || out->ncellout)) {
             static const double in_top[9] = {2, 1, 128, 4, 0, 64, 8, 16, 32}; // R/upslope_area.R:142
             double codes[18];
@@ -1471,7 +1486,8 @@ extern "C" int splash_static_rasters_run(int H, int W, const double* elev, doubl
     HIP_TRY(hipDeviceSynchronize(), err, errlen);
     struct { double* h; DevBuf* d; } back[] = {{out->slope, &dsl}, {out->aspect, &das}, {out->lat, &dla},
                                                {out->filled, &dfi}, {out->flowdir, &dfd}, {out->ups_ncell, &dcn},
-                                               {out->ups_area, &dar}, {out->ncellin, &dni}, {out->ncellout, &dno}};
+                                               {out->ups_area, &dar}, {out->ncellin, &dni}, {out->ncellout, &dno},
+                                               {out->ups_area_mfd, &dmf}};
     for (auto& b : back)
         if (b.h) HIP_TRY(hipMemcpy(b.h, b.d->p, nb, hipMemcpyDeviceToHost), err, errlen);
     return SPLASH_OK;

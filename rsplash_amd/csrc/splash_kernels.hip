@@ -1415,6 +1415,103 @@ __global__ __launch_bounds__(kFaTailBlock) void k_fa_tail(int H, int W, const do
     }
 }
 
+// Multiple-flow-direction contributing area (Quinn et al. 1991), what `topmodel::topidx()$area`
+// computes for R/upslope_area.R:21 (third-party code outside the reference tree: the published
+// algorithm, parity unpinned).  Every cell passes its accumulated area to ALL lower neighbours, in
+// proportion to tan(beta) * contour length (0.5 dx across an edge, 0.354 dx across a corner); a cell
+// starts with its own dx^2.  Order: a cell is ready once every higher neighbour has been settled; it
+// then PULLS from those neighbours in a fixed order (E, SE, S, SW, W, NW, N, NE), so the sums are the
+// same doubles whatever the launch geometry -- no floating-point atomics.  wsum[n] = the weight
+// total of cell n's downslope directions (0: a pit or an outlet: its area stays put).
+__device__ __forceinline__ double mfd_weight(double zhi, double zlo, int q, double res)
+{
+#pragma clang fp contract(off) // the same roundings as a plain C evaluation, whatever the caller fuses
+    // weight of the direction q (0 E, 1 SE, ... 7 NE) from a cell at zhi to its neighbour at zlo
+    const bool diag = (q & 1) != 0;
+    const double dist = diag ? res * 1.4142135623730951 : res;
+    const double contour = (diag ? 0.354 : 0.5) * res;
+    return ((zhi - zlo) / dist) * contour;
+}
+__device__ __forceinline__ void d8_offset(int q, int& dr, int& dc)
+{
+    dr = (q >= 1 && q <= 3) ? 1 : ((q >= 5) ? -1 : 0);
+    dc = (q == 0 || q == 1 || q == 7) ? 1 : ((q >= 3 && q <= 5) ? -1 : 0);
+}
+
+__global__ __launch_bounds__(kBlock) void k_mfd_init(int H, int W, const double* __restrict__ z, double res,
+                                                    double* __restrict__ wsum, int* __restrict__ nhigher,
+                                                    double* __restrict__ area)
+{
+#pragma clang fp contract(off)
+    const int c = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (c >= W) return;
+    for (int r = (int)blockIdx.y; r < H; r += (int)gridDim.y) {
+        const size_t i = (size_t)r * W + c;
+        const double zc = z[i];
+        double ws = 0.0;
+        int nh = 0;
+        if (zc == zc) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                int dr, dc;
+                d8_offset(q, dr, dc);
+                const int rr = r + dr, cc = c + dc;
+                if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+                const double zn = z[(size_t)rr * W + cc];
+                if (zn < zc) ws += mfd_weight(zc, zn, q, res);
+                if (zn > zc) nh++;
+            }
+        }
+        wsum[i] = ws;
+        nhigher[i] = (zc == zc) ? nh : -1;
+        area[i] = (zc == zc) ? res * res : __builtin_nan("");
+    }
+}
+
+__device__ __forceinline__ void mfd_settle(unsigned i, int H, int W, const double* __restrict__ z, double res,
+                                           const double* __restrict__ wsum, int* nhigher, double* area,
+                                           unsigned* qout, unsigned* qout_n)
+{
+#pragma clang fp contract(off)
+    const int r = (int)(i / (unsigned)W), c = (int)(i % (unsigned)W);
+    const double zc = z[i];
+    double a = res * res;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { // pull from the higher neighbours, fixed order
+        int dr, dc;
+        d8_offset(q, dr, dc);
+        const int rr = r + dr, cc = c + dc;
+        if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+        const size_t j = (size_t)rr * W + cc;
+        const double zn = z[j];
+        if (zn > zc) {
+            const double an = __hip_atomic_load(area + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the neighbour's direction towards this cell is the opposite one: (q + 4) & 7
+            a += an * (mfd_weight(zn, zc, (q + 4) & 7, res) / wsum[j]);
+        }
+    }
+    __hip_atomic_store(area + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+#pragma unroll
+    for (int q = 0; q < 8; q++) { // one higher neighbour fewer to wait for, for every lower neighbour
+        int dr, dc;
+        d8_offset(q, dr, dc);
+        const int rr = r + dr, cc = c + dc;
+        if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+        const size_t j = (size_t)rr * W + cc;
+        if (z[j] < zc && atomicSub(nhigher + j, 1) == 1) qout[atomicAdd(qout_n, 1u)] = (unsigned)j;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_mfd_level(int H, int W, const double* __restrict__ z, double res,
+                                                     const double* __restrict__ wsum, int* nhigher,
+                                                     double* area, const unsigned* __restrict__ qin,
+                                                     unsigned nin, unsigned* qout, unsigned* qout_n)
+{
+    const unsigned k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < nin) mfd_settle(qin[k], H, W, z, res, wsum, nhigher, area, qout, qout_n);
+}
+
 // counts -> doubles (NA where there is no cell) and, optionally, the reference's contributing area
 // (R/upslope_area.R:85-96): fix_coast -- a cell with an elevation but no count gets 1 -- and
 // ups_ncell * cell area, here count * resolution^2 in m2.
@@ -1610,6 +1707,41 @@ hipError_t launch_flow_accumulation(int H, int W, const double* fd, const double
     }
     hipLaunchKernelGGL(k_fa_finish, dim3(nblk(n, kBlock)), dim3(kBlock), 0, s, n, count, indeg, resolution,
                        ups_ncell, ups_area);
+    if (levels_out) *levels_out = levels;
+    const hipError_t e2 = hipGetLastError();
+    (void)hipFreeAsync(w, s);
+    return e != hipSuccess ? e : e2;
+}
+
+hipError_t launch_mfd_area(int H, int W, const double* elev, double resolution_m, double* area,
+                           int* levels_out, hipStream_t s)
+{
+    const size_t n = (size_t)H * W;
+    if (n == 0) return hipSuccess;
+    // stream-ordered scratch: weight totals (f64), higher-neighbour counts, two queues, 2 counters
+    char* w = nullptr;
+    hipError_t e = hipMallocAsync((void**)&w, n * 20 + 64, s);
+    if (e != hipSuccess) return e;
+    double* wsum = (double*)w;
+    int* nhigher = (int*)(w + n * 8);
+    unsigned* q[2] = {(unsigned*)(w + n * 12), (unsigned*)(w + n * 16)};
+    unsigned* qn = (unsigned*)(w + n * 20);
+    const dim3 g1(nblk((size_t)W, kBlock), (unsigned)(H < 65535 ? H : 65535));
+    hipLaunchKernelGGL(k_mfd_init, g1, dim3(kBlock), 0, s, H, W, elev, resolution_m, wsum, nhigher, area);
+    e = hipMemsetAsync(qn, 0, 64, s);
+    hipLaunchKernelGGL(k_fa_seed, dim3(nblk(n, kBlock)), dim3(kBlock), 0, s, n, nhigher, q[0], qn); // count 0: peaks
+    int cur = 0, levels = 0;
+    while (e == hipSuccess) {
+        unsigned nin = 0;
+        e = hipMemcpyAsync(&nin, qn + cur, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess || nin == 0) break;
+        levels++;
+        e = hipMemsetAsync(qn + (cur ^ 1), 0, sizeof(unsigned), s);
+        hipLaunchKernelGGL(k_mfd_level, dim3(nblk((size_t)nin, kBlock)), dim3(kBlock), 0, s, H, W, elev,
+                           resolution_m, wsum, nhigher, area, q[cur], nin, q[cur ^ 1], qn + (cur ^ 1));
+        cur ^= 1;
+    }
     if (levels_out) *levels_out = levels;
     const hipError_t e2 = hipGetLastError();
     (void)hipFreeAsync(w, s);

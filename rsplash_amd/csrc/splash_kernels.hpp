@@ -133,6 +133,8 @@ hipError_t launch_ncellflow(int H, int W, const double* fd, const double* codes,
                             double* out, hipStream_t s);
 hipError_t launch_sinkfill(int H, int W, const double* elev, double resolution_m, double degree,
                            double* filled, int* sweeps_out, hipStream_t s);
+hipError_t launch_mfd_area(int H, int W, const double* elev, double resolution_m, double* area,
+                           int* levels_out, hipStream_t s);
 hipError_t launch_flow_accumulation(int H, int W, const double* fd, const double* elev, int tau,
                                     const double* resolution, double* ups_ncell, double* ups_area,
                                     int* levels_out, hipStream_t s);

@@ -1155,13 +1155,24 @@ def test_sinkfill_and_flow_accumulation_vs_oracle(api, oracle):
     mean_res = float(rv.sum() / rv.size + (rv - rv.sum() / rv.size).sum() / rv.size)   # R's mean()
     assert np.array_equal(u["filled"][~np.isnan(z)], oracle.sinkfill(z, mean_res, 1.0)[~np.isnan(z)])
     assert np.nanmin(u["ups_ncell"]) == 1 and np.isnan(u["areacatch"][105, 220])
-    assert np.allclose(u["areacatch"][m], (u["ups_ncell"] * res ** 2)[m], rtol=1e-15)
+    # multiple-flow-direction area of the filled surface (topidx()$area): pull order fixed, no
+    # contraction: the same doubles as the serial statement
+    filled_t = torch.as_tensor(ref, device=dev)
+    mfd = torch.empty(H * W, dtype=torch.float64, device=dev)
+    lv = api.dev_mfd_area(H, W, filled_t, 250.0, mfd)
+    mo = oracle.mfd_area(ref, 250.0)
+    gm = mfd.cpu().numpy().reshape(H, W)
+    assert lv > 10 and np.array_equal(np.isnan(gm), np.isnan(mo))
+    assert np.array_equal(gm[~np.isnan(mo)], mo[~np.isnan(mo)])
+    assert np.array_equal(u["areacatch"][~np.isnan(z)], oracle.mfd_area(u["filled"], mean_res)[~np.isnan(z)])
+    u_tau = api.upslope_area(z, 60.0, 0.0025, 0.0025, method="tau")
     # the host-buffer entry point the R shim binds gives the same rasters in one call
     sr = api.static_rasters(z, 60.0, 0.0025, 0.0025)
     for k, ku in (("filled", "filled"), ("flowdir", "flowdir"), ("ups_ncell", "ups_ncell"),
                   ("ups_area", "areacatch"), ("ncellin", "ncellin"), ("ncellout", "ncellout")):
-        a, b = sr[k], u[ku]
+        a, b = sr[k], u_tau[ku]
         assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(a)]), k
+    assert np.array_equal(sr["ups_area_mfd"][~np.isnan(z)], u["areacatch"][~np.isnan(z)])
     t0 = api.terrain(z, 60.0, 0.0025, 0.0025)
     for k in ("slope", "aspect", "lat", "resolution"):
         assert np.array_equal(np.isnan(sr[k]), np.isnan(t0[k])) and np.array_equal(sr[k][~np.isnan(sr[k])], t0[k][~np.isnan(sr[k])]), k

@@ -407,3 +407,37 @@ def test_sinkfill_and_flow_accumulation_hand_cases(oracle):
     fd = np.array([[1.0, np.nan, 16.0]])
     cnt, _ = oracle.flow_accumulation(fd)
     assert cnt[0, 0] == 1 and np.isnan(cnt[0, 1]) and cnt[0, 2] == 1
+
+
+def test_mfd_area_hand_cases(oracle):
+    """Quinn et al. (1991) contributing area (topidx()$area of R/upslope_area.R:21, restated from the
+    published algorithm): mass is conserved, a plane splits its flow 0.5 : 0.354/sqrt(2) between the
+    straight and the two diagonal lower neighbours, a ridge cell keeps its own area, NA stays NA."""
+    H, W, res = 5, 6, 10.0
+    z = (10.0 - np.arange(W))[None, :].repeat(H, 0).astype(float)   # descends eastwards
+    a = oracle.mfd_area(z, res)
+    assert np.all(a[:, 0] == res * res)                               # the ridge column: own area only
+    assert np.isclose(a[:, -1].sum(), H * W * res * res, rtol=1e-14)  # everything leaves through the outlet column
+    # middle row, second column: from the three western neighbours (W straight, NW and SW diagonal)
+    ws, wd = 0.5, 0.354 / np.sqrt(2.0)                                # tan(beta)*L per unit drop/res
+    frac_straight, frac_diag = ws / (ws + 2 * wd), wd / (ws + 2 * wd)
+    assert np.isclose(a[2, 1], res * res * (1 + frac_straight + 2 * frac_diag))
+    # edge rows lose one diagonal: their straight share is ws/(ws + wd)
+    assert np.isclose(a[0, 1], res * res * (1 + ws / (ws + wd) + frac_diag))
+    z2 = z.copy()
+    z2[2, 3] = np.nan
+    a2 = oracle.mfd_area(z2, res)
+    assert np.isnan(a2[2, 3]) and np.isfinite(np.delete(a2.ravel(), 2 * W + 3)).all()
+    # a pit keeps what arrives: total over all sinks/outlets still equals the grid's area
+    rng = np.random.default_rng(3)
+    z3 = rng.random((30, 40)) * 50
+    a3 = oracle.mfd_area(z3, 25.0)
+    lower = np.zeros_like(z3, bool)
+    for dr in (-1, 0, 1):
+        for dc in (-1, 0, 1):
+            if (dr, dc) != (0, 0):
+                zz = np.full_like(z3, np.inf)
+                zz[max(0, -dr):z3.shape[0] - max(0, dr), max(0, -dc):z3.shape[1] - max(0, dc)] = \
+                    z3[max(0, dr):z3.shape[0] - max(0, -dr), max(0, dc):z3.shape[1] - max(0, -dc)]
+                lower |= zz < z3
+    assert np.isclose(a3[~lower].sum(), z3.size * 625.0, rtol=1e-12)  # cells without a lower neighbour hold it all

@@ -34,7 +34,10 @@ t3, sweeps = wall(lambda: api.dev_sinkfill(G, G, zr, 250.0, filled, 1.0))
 api.dev_terrain(G, G, filled, 60.0, 0.005, 0.005, resolution=resg, flowdir=fdg)
 api.dev_flow_accumulation(G, G, fdg, cnt, elev=filled)
 t4, levels = wall(lambda: api.dev_flow_accumulation(G, G, fdg, cnt, elev=filled))
-graph = {"graph_cells": G * G, "sinkfill_ms": t3, "sinkfill_sweeps": sweeps, "flow_accumulation_ms": t4,
+mfd = torch.empty(G * G, dtype=torch.float64, device=dev)
+api.dev_mfd_area(G, G, filled, 250.0, mfd)
+t5, mlevels = wall(lambda: api.dev_mfd_area(G, G, filled, 250.0, mfd))
+graph = {"mfd_area_ms": t5, "mfd_levels": mlevels, "graph_cells": G * G, "sinkfill_ms": t3, "sinkfill_sweeps": sweeps, "flow_accumulation_ms": t4,
          "flow_accumulation_host_levels": levels, "largest_catchment_cells": float(cnt[~torch.isnan(cnt)].max().item())}
 print(json.dumps(graph))
 print(json.dumps({"cells": n, "terrain_ms": t1, "terrain_alg_bytes_per_cell": 48, "terrain_GBs": 48 * n / t1 / 1e6,
