@@ -951,7 +951,7 @@ __global__ __launch_bounds__(kBlock) void k_unswc(size_t ncell, int nt,
     const double gfac = (100 + gravel) / 100, gout = (1 - (gravel / 100));
     const double u1000 = uns_depth * 1000;
     const double inv_lm1 = 1 / (lambda - 1);
-    const double inv_d1000 = 1 / d1000, inv_dth = 1 / dth, inv_u1000 = 1 / u1000;
+    const double inv_d1000 = 1 / d1000, inv_dth = 1 / dth, inv_u1000 = 1 / u1000, inv_bub = 1 / bub;
     // the next step's column water is requested a step ahead and waited for before this step's
     // stores are issued (loads and stores share one counter: see k_run_all)
     double w_next = nt > 0 ? __builtin_nontemporal_load(&wn[i]) : 0.0;
@@ -964,12 +964,14 @@ __global__ __launch_bounds__(kBlock) void k_unswc(size_t ncell, int nt,
         if (theta_i <= theta_r) theta_i = theta_r + 0.0001;
         const double Theta = (theta_i - theta_r) * inv_dth; // in (0, 1) after the two clamps (or NaN)
         const double L = flog<kLogPositive>(Theta);
-        const double psi_m = bub * fexp(-L * inv_lambda); // bub / Theta^(1/lambda), :67
+        const double Pm = fexp(-L * inv_lambda);          // Theta^(-1/lambda) >= 1
+        const double psi_m = bub * Pm;                    // bub / Theta^(1/lambda), :67
         const double wtdini = (bub - psi_m) * 1.0e-3;     // UnsWater, :36-37
         const double wtd = (wtdini > depth) ? depth : ((wtdini < 0) ? 0 : wtdini);
         const double z_uns = (wtd <= uns_depth) ? wtd * 1000 : u1000; // :39
-        // :41-43  (bub/(psi_m+z))^lambda = exp(lambda*log(..)); psi_m + z <= bub < 0: the base is in (0, 1]
-        const double pz = fexp(lambda * flog<kLogPositive>(bub * frcp(psi_m + z_uns)));
+        // :41-43  (bub/(psi_m+z))^lambda = (Theta^(-1/lambda) + z/bub)^(-lambda): psi_m + z <= bub < 0, so
+        // the bracket is >= 1 -- the logarithm of the reciprocal base, without the reciprocal
+        const double pz = fexp(-lambda * flog<kLogPositive>(Pm + z_uns * inv_bub));
         const double p0 = Theta; // (bub/psi_m)^lambda at z = 0 is Theta itself
         const double w_uns_z = theta_r * z_uns + (((psi_m + z_uns) * (theta_r - theta_s) * pz) * inv_lm1);
         const double w_uns_0 = ((psi_m * (theta_r - theta_s) * p0) * inv_lm1);
