@@ -14,6 +14,8 @@ forcing, cellpar, Tt, spun-up state0 and the product's daily series) -- see DESI
                at most 5 % of the critical-event cells may actually differ, and >= 1 - 1e-5 of ALL
                cell-days must be within tolerance with nothing set aside.
 """
+import os
+
 import numpy as np
 
 RTOL, ATOL = 1e-5, 1e-9
@@ -170,8 +172,54 @@ def assert_trajectory(oracle, p, name="", **kw):
     return r
 
 
+_VARIANTS = None
+
+
+def reference_variants():
+    """The oracle's own source in two further legal builds (tools/conditioning_evidence.py):
+    B  -O3 -march=native -ffp-contract=fast;  C  every libm result moved by -1/0/+1 ulp.
+    Built on first use into the temp directory (gcc is on the build container and the GPU box)."""
+    global _VARIANTS
+    if _VARIANTS is None:
+        import subprocess
+        import tempfile
+        from .binding import Oracle
+        src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "splash_oracle.c")
+        out = {}
+        for tag, flags in (("B", ["-O3", "-march=native", "-ffp-contract=fast"]),
+                           ("C", ["-O2", "-DORC_PERTURB_LIBM"])):
+            so = os.path.join(tempfile.gettempdir(), f"liboracle_parity_{tag}_{os.getpid()}.so")
+            subprocess.check_call(["gcc", "-std=c11", "-fPIC", "-fopenmp", "-shared", "-Wl,-Bsymbolic"] + flags +
+                                  ["-o", so, src, "-lm"])
+            out[tag] = Oracle(so)
+        _VARIANTS = out
+    return _VARIANTS
+
+
+def reference_disagrees_with_itself(cells, ref, aux, statics, forcing, names):
+    """For each of `cells` (whole-pipeline inputs: statics dict, forcing = (doy, year, month, mid, nm,
+    sw, tc, pn)): does another legal build of the reference's statements (B or C) leave the tolerance
+    of the pinned build's result, or count other spin-up passes?  Such a cell -- a spin-up on a
+    non-periodic orbit that never meets the 1 mm criterion, a threshold met by a hair -- has no
+    reference value to be compared with (class 4)."""
+    doy, year, month, mid, nm, sw, tc, pn = forcing
+    res = np.zeros(len(cells), bool)
+    for n_, c in enumerate(cells):
+        sl = slice(int(c), int(c) + 1)
+        st1 = {k: (v[:, sl] if np.ndim(v) == 2 else v[sl]) for k, v in statics.items()}
+        for oo in reference_variants().values():
+            r2, a2 = oo.grid(doy, year, month, mid, nm, np.ascontiguousarray(sw[:, sl]),
+                             np.ascontiguousarray(tc[:, sl]), np.ascontiguousarray(pn[:, sl]), st1["lat"],
+                             st1["elev"], st1["slop"], st1["asp"], st1["soil"], st1["au"], st1["resolution"],
+                             monthly_out=(ref[names[0]].shape[0] != len(doy)), n_threads=1)
+            differs = any(_bad(r2[k][:, 0], ref[k][:, c]).any() for k in names)
+            differs |= int(a2["passes1"][0]) != int(aux["passes1"][c]) or int(a2["passes2"][0]) != int(aux["passes2"][c])
+            res[n_] |= bool(differs)
+    return res
+
+
 def assert_whole_pipeline(oracle, g, ref, aux, statics, doy, year, name="", names=None,
-                          monthly_mid=None, max_flip_frac=0.05):
+                          monthly_mid=None, max_flip_frac=0.05, forcing=None):
     """splash_grid (GPU: soil_hydro, snow threshold, both spin-ups, run_all, sm_lim) against the
     oracle's splash.grid restatement, each from its own spin-up.
 
@@ -205,6 +253,13 @@ def assert_whole_pipeline(oracle, g, ref, aux, statics, doy, year, name="", name
         e = np.where(graz | np.isnan(b), 0.0, np.maximum(np.abs(a - b) - ATOL, 0.0) / np.maximum(np.abs(b), 1e-300))
         worst[k] = float(e[:, ok].max()) if ok.any() else 0.0
     stray = bad_cell & ~flagged
+    self_dis = 0
+    if stray.any() and forcing is not None and stray.sum() <= 16:
+        # no event of the oracle's run explains these cells: does the reference agree with ITSELF there?
+        cells = np.where(stray)[0]
+        excused = reference_disagrees_with_itself(cells, ref, aux, statics, forcing, list(names))
+        stray[cells[excused]] = False
+        self_dis = int(excused.sum())
     assert not stray.any(), f"{name}: cells {np.where(stray)[0][:8]} out of tolerance without a critical event"
     flips = int((bad_cell & flagged).sum())
     assert flips <= max(3, max_flip_frac * flagged.sum()), \
@@ -212,4 +267,5 @@ def assert_whole_pipeline(oracle, g, ref, aux, statics, doy, year, name="", name
     assert bad_cell.mean() <= 5e-3, f"{name}: {bad_cell.mean():.2e} of the cells set aside"
     assert graz.mean() <= 2e-2, f"{name}: {graz.mean():.2e} of the cell-days after a grazing-sun day"
     return dict(cells=int(flagged.size), critical_event_cells=int(flagged.sum()), set_aside=flips,
+                reference_disagrees_with_itself=self_dis,
                 grazing_cell_days=int(graz.sum()), max_rel_err=worst, ok=~bad_cell)

@@ -40,7 +40,8 @@ for g in range(ngrid):
                           want_aux=True)
     t_gpu = time.time() - t0
     try:
-        r = assert_whole_pipeline(o, got, ref, aux, st, doy, year, f"grid {g}")
+        r = assert_whole_pipeline(o, got, ref, aux, st, doy, year, f"grid {g}",
+                                  forcing=(doy, year, month, mid, nm, sw, tc, pn))
         ok = r.pop("ok")
         worst, nbad = r["max_rel_err"], 0
     except AssertionError as e:
@@ -51,9 +52,21 @@ for g in range(ngrid):
         worst_all[k] = max(worst_all.get(k, 0.0), v)
     passes_equal = bool(np.array_equal(got["aux"]["passes2"][ok], aux["passes2"][ok]) and
                         np.array_equal(got["aux"]["passes1"][ok], aux["passes1"][ok]))
+    if not passes_equal:
+        # a pass count that differs in a cell within tolerance: a stopping rule met by a hair?  Then
+        # the reference's own builds count differently too (oracle/parity.py)
+        from oracle.parity import reference_disagrees_with_itself
+        mm = np.where(ok & ((got["aux"]["passes2"] != aux["passes2"]) | (got["aux"]["passes1"] != aux["passes1"])))[0]
+        exc = reference_disagrees_with_itself(mm[:16], ref, aux, st, (doy, year, month, mid, nm, sw, tc, pn),
+                                              ["wn", "ro", "aet", "pet", "snow"])
+        print("PASSES", g, [(int(c), int(got["aux"]["passes1"][c]), int(aux["passes1"][c]),
+                             int(got["aux"]["passes2"][c]), int(aux["passes2"][c]), bool(e))
+                            for c, e in zip(mm[:16], exc)], flush=True)
+        passes_equal = bool(len(mm) <= 16 and exc.all())
     bad_total += nbad + (0 if passes_equal else 1)
     print(json.dumps({"grid": g, "seed": seed, "terrain": terrain, "cells": H * W, "days": nt,
                       "critical_event_cells": r["critical_event_cells"], "set_aside": r["set_aside"],
+                      "reference_disagrees_with_itself": r.get("reference_disagrees_with_itself", 0),
                       "failures": nbad, "spin_up_pass_counts_equal": passes_equal,
                       "max_passes": int(aux["passes2"].max()), "max_rel_err": worst,
                       "oracle_s": round(t_cpu, 1), "gpu_call_s": round(t_gpu, 1)}), flush=True)
