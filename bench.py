@@ -432,7 +432,10 @@ def cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp):
                   f"GPU's spun-up state), OpenMP over cells with {cores} threads, {tcpu:.1f} s; one thread: "
                   f"{ns1} cells in {t1:.1f} s",
     }
-    # the same cells on the GPU, all 11 series, checked on EVERY cell-day (oracle/parity.py)
+    # the same cells on the GPU, all 11 series, checked on EVERY cell-day (oracle/parity.py); at most
+    # the first 2^19 cells, so that the sample -- and what it reports -- is the same on any host
+    # whose cores get that far in the time budget
+    ns2 = min(ns2, 1 << 19)
     f64 = dict(dtype=torch.float64, device=ctx["dev"])
     gs = {k: torch.empty(nt, ns2, **f64) for k in SERIES11}
     st = state0[:, :ns2].clone()
