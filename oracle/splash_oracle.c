@@ -891,7 +891,10 @@ void orc_run_one_day(double lat, double elv, int n, int y, double wn, double sw_
     double q_in_f = 0.0;
     td -= 1.0;
     if ((R > 0.0) && (sm > Wmax)) {
-        if (Au > 0.0 && wtd >= depth && fabs(psi_m) > 4.4e12 * (wtd * 1000.0) &&
+        /* the difference of the two powers of :1422 is ~e*u of either one, u = wtd*1000/psi_m, and
+         * carries the rounding of both: a relative noise of 1.6e-16/(e*u), which passes 2e-6 (a fifth
+         * of the tolerance, e <= 4) at |psi_m| = 2e10 * wtd*1000 -- the drainage time divides by it */
+        if (Au > 0.0 && wtd >= depth && fabs(psi_m) > 2.0e10 * (wtd * 1000.0) &&
             fabs(psi_m) < 2.6e16 * (wtd * 1000.0))
             tl_fragile_events++;
         if (Au > 0.0 && wtd >= depth && isfinite(psi_m) &&

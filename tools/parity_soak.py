@@ -1,0 +1,34 @@
+"""One-step and trajectory parity (oracle/parity.py) on many independent synthetic grids (GPU box):
+the rules the GPU tests apply to four fixed cases, over seeds they have not seen.
+    python tools/parity_soak.py [n_grids=12] [cells=8192] [days=730]"""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from rsplash_amd import api
+from oracle.binding import Oracle
+from oracle.parity import assert_one_step, trajectory_summary
+from gpu_pipeline import device_pipeline
+ng = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+nt = int(sys.argv[3]) if len(sys.argv) > 3 else 730
+o = Oracle()
+bad = 0
+for g in range(ng):
+    seed = 911000 + 104729 * g
+    p = device_pipeline(api, seed, n // 128, 128, 0, n, nt, 0 if g % 6 == 5 else 1)
+    msg = []
+    try:
+        r1 = assert_one_step(o, p, f"grid {g}")
+    except AssertionError as e:
+        r1 = {}
+        msg.append("one-step: " + str(e)[:300])
+    r2 = trajectory_summary(o, p)
+    msg += ["trajectory: " + v[:300] for v in r2["violations"]]
+    bad += len(msg)
+    print(json.dumps({"grid": g, "seed": seed, "one_step": {k: v for k, v in r1.items() if not hasattr(v, "shape")},
+                      "trajectory": {k: r2[k] for k in ("set_aside_cell_days", "critical_event_cells",
+                                                         "critical_event_cells_that_differ", "max_abs_dwn_mm")},
+                      "problems": msg}, default=str)[:900], flush=True)
+print(json.dumps({"grids": ng, "problems": bad}))
+sys.exit(1 if bad else 0)
