@@ -85,9 +85,27 @@ def assert_one_step(oracle, p, name="", max_event_frac=5e-3, n_threads=0):
     n_cd = ev.size
     assert graz.mean() <= max_event_frac and td_noise.mean() <= max_event_frac
     worst = {}
+    self_dis = 0
     for k in SERIES11:
         mask = graz | resid | (td_noise if k == "tdrain" else False)
         b = bad[k] & ~mask
+        if b.any() and b.sum() <= 16:
+            # no event bit names these cell-days: does the reference agree with ITSELF on them?  Its
+            # two other builds redo the day from the same previous state (reference_variants()).
+            prev = np.stack([p["out"][s_] for s_ in ("wn", "snow", "qin_prev", "tdrain", "snwage")])
+            hp = p["par"]
+            for t, c in np.argwhere(b):
+                sl = slice(int(c), int(c) + 1)
+                for oo in reference_variants().values():
+                    r2 = oo.grid_transient2(p["doy"], p["year"], p["month"], p["sw"][:, sl].copy(),
+                                            p["tc"][:, sl].copy(), p["pn"][:, sl].copy(), hp[0, sl], hp[1, sl],
+                                            hp[2, sl], hp[3, sl], hp[4:16, sl].copy(), p["Tt"][sl],
+                                            p["state0"][:, sl].copy(), prev=prev[:, :, sl].copy(), names=(k,),
+                                            n_threads=1)[0]
+                    if _bad(r2[k][t:t + 1, 0], r["ref"][k][t:t + 1, c]).any():
+                        b[t, c] = False
+                        self_dis += 1
+                        break
         if b.any():
             t, c = np.argwhere(b)[0]
             raise AssertionError(
@@ -100,7 +118,7 @@ def assert_one_step(oracle, p, name="", max_event_frac=5e-3, n_threads=0):
                          np.maximum(np.abs(a - f) - ATOL, 0.0) / np.maximum(np.abs(f), 1e-300))
         worst[k] = float(np.nanmax(e))
     return dict(cell_days=n_cd, grazing=int(graz.sum()), noise_denominator=int(td_noise.sum()),
-                max_rel_err=worst)
+                reference_disagrees_with_itself=self_dis, max_rel_err=worst)
 
 
 def trajectory_report(oracle, p, n_threads=0):
