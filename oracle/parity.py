@@ -149,6 +149,7 @@ def trajectory_summary(oracle, p, min_frac_all=1.0 - 1e-5, max_flip_frac=0.05, n
     crit_after = np.cumsum((ev & (EV_CRITICAL | EV_RESIDUAL)) != 0, axis=0) > 0
     flagged = crit_after.any(0)
     frac_all, frac_kept, worst, viol = {}, {}, {}, []
+    self_dis = set()
     bads = {k: _bad(p["out"][k], ref[k], floor=_floor(k, ref)) for k in names}
     flipped = np.zeros(flagged.shape, bool)
     for k in names:
@@ -163,6 +164,20 @@ def trajectory_summary(oracle, p, min_frac_all=1.0 - 1e-5, max_flip_frac=0.05, n
             viol.append(f"only {frac_kept[k]:.8f} of the cell-days of cells without a flipped critical event "
                         f"within tolerance for {k}")
         bm = b & ~graz_after & ~crit_after
+        if bm.any() and np.unique(np.argwhere(bm)[:, 1]).size <= 16:
+            # cells that leave the tolerance without an event: does the reference's own trajectory
+            # from the same state survive another legal build (reference_variants())?
+            for c in np.unique(np.argwhere(bm)[:, 1]):
+                sl = slice(int(c), int(c) + 1)
+                for oo in reference_variants().values():
+                    r2 = oo.grid_transient2(p["doy"], p["year"], p["month"], p["sw"][:, sl].copy(),
+                                            p["tc"][:, sl].copy(), p["pn"][:, sl].copy(), hp[0, sl], hp[1, sl],
+                                            hp[2, sl], hp[3, sl], hp[4:16, sl].copy(), p["Tt"][sl],
+                                            p["state0"][:, sl].copy(), names=(k,), n_threads=1)[0]
+                    if _bad(r2[k][:, 0], ref[k][:, c]).any():
+                        bm[:, c] = False
+                        self_dis.add(int(c))
+                        break
         if bm.any():
             t, c = np.argwhere(bm)[0]
             viol.append(f"{k} out of tolerance on {int(bm.sum())} cell-days outside the mask; first: day {t} "
@@ -187,6 +202,7 @@ def trajectory_summary(oracle, p, min_frac_all=1.0 - 1e-5, max_flip_frac=0.05, n
                 cells_after_a_grazing_day=int(graz_after.any(0).sum()),
                 critical_event_cells=int(flagged.sum()),
                 critical_event_cells_that_differ=int(flipped.sum()),
+                cells_on_which_the_reference_disagrees_with_itself=len(self_dis),
                 fraction_of_all_cell_days_within_tolerance=frac_all,
                 fraction_within_tolerance_without_flipped_cells=frac_kept, max_rel_err=worst,
                 max_abs_dwn_mm=float(np.abs(p["out"]["wn"] - ref["wn"])[keep].max()), violations=viol)
