@@ -1,7 +1,7 @@
 """Whole-pipeline parity sweep on the GPU box: splash_grid (soil_hydro, snow threshold, both
 spin-ups, run_all, sm_lim) against the oracle's splash.grid restatement on several independent
 synthetic grids.  Prints one JSON line per grid and a summary; exit code 1 if a well-conditioned
-cell is out of tolerance.      python tools/parity_sweep.py [cells_per_grid] [n_grids] [days]
+cell is out of tolerance.      python tools/parity_sweep.py [cells_per_grid] [n_grids] [days] [monthly]
 """
 import json
 import os
@@ -18,6 +18,7 @@ from oracle.parity import assert_whole_pipeline
 ncell = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 ngrid = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 nt = int(sys.argv[3]) if len(sys.argv) > 3 else 730
+monthly = len(sys.argv) > 4 and sys.argv[4] == "monthly"
 o = Oracle()
 W = 128
 H = ncell // W
@@ -32,15 +33,16 @@ for g in range(ngrid):
     sw, tc, pn = o.synth_forcing(seed, H, W, 0, H * W, 0, doy, st["lat"], st["elev"])
     t0 = time.time()
     ref, aux = o.grid(doy, year, month, mid, nm, sw, tc, pn, st["lat"], st["elev"], st["slop"], st["asp"],
-                      st["soil"], st["au"], st["resolution"], monthly_out=False)
+                      st["soil"], st["au"], st["resolution"], monthly_out=monthly)
     t_cpu = time.time() - t0
     t0 = time.time()
     got = api.splash_grid(sw, tc, pn, st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"],
-                          st["resolution"], time_index=dates, sim_control=dict(monthly_out=False),
+                          st["resolution"], time_index=dates, sim_control=dict(monthly_out=monthly),
                           want_aux=True)
     t_gpu = time.time() - t0
     try:
         r = assert_whole_pipeline(o, got, ref, aux, st, doy, year, f"grid {g}",
+                                  monthly_mid=mid if monthly else None,
                                   forcing=(doy, year, month, mid, nm, sw, tc, pn))
         ok = r.pop("ok")
         worst, nbad = r["max_rel_err"], 0
