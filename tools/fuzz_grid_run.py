@@ -1,0 +1,59 @@
+"""Randomised invariants of the host-buffer entry point (splash_grid_run through api.splash_grid), GPU box:
+for random grid shapes, NA masks, launch blockings, device lists {0,0}/{0,0,0}, single-precision
+transport, monthly/daily outputs and basin maps, the results must equal the plain call BITWISE on
+every valid cell, NA cells must come back NaN, and the per-basin totals must be identical limbs.
+    python tools/fuzz_grid_run.py [n_cases=12]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import rsplash_amd.api as api
+from oracle.binding import Oracle
+o = Oracle()
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(20221130)
+bad = 0
+for case in range(n_cases):
+    H, W = int(rng.integers(3, 20)), int(rng.integers(5, 90))
+    nt = int(rng.choice([365, 400, 731]))
+    monthly = bool(rng.integers(0, 2))
+    seed = int(rng.integers(1, 2**31))
+    doy, year, month, mid, nm = o.calendar(2001, nt)
+    dates = np.datetime64("2001-01-01") + np.arange(nt)
+    st = o.synth_statics(seed, H, W, 0, H * W, 1)
+    sw, tc, pn = o.synth_forcing(seed, H, W, 0, H * W, 0, doy, st["lat"], st["elev"])
+    n = H * W
+    mask = rng.random(n) < rng.choice([0.0, 0.3, 0.7])
+    mask[int(rng.integers(0, n))] = False
+    elev = st["elev"].copy(); elev[mask] = np.nan
+    swm, tcm, pnm = sw.copy(), tc.copy(), pn.copy()
+    swm[:, mask] = np.nan; tcm[:, mask] = np.nan; pnm[:, mask] = np.nan
+    basin = rng.integers(0, 5, n).astype(np.int32)
+    kw = dict(time_index=dates, sim_control=dict(monthly_out=monthly), want_diag=True, basin=basin, n_basin=5)
+    args = (elev, st["soil"], st["lat"], st["slop"], st["asp"], st["au"], st["resolution"])
+    ref = api.splash_grid(swm, tcm, pnm, *args, **kw)
+    variants = {
+        "blocked": dict(max_cells_per_launch=int(rng.integers(64, 400))),
+        "two workers": dict(devices=[0, 0]),
+        "three workers, blocked": dict(devices=[0, 0, 0], max_cells_per_launch=int(rng.integers(64, 300))),
+    }
+    names = [k for k in ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "sm_lim") if k in ref]
+    msgs = []
+    for k in names:
+        if not (np.isnan(ref[k][:, mask]).all() and np.isfinite(ref[k][:, ~mask]).all()):
+            msgs.append(f"NaN pattern of {k}")
+    for tag, extra in variants.items():
+        g = api.splash_grid(swm, tcm, pnm, *args, **kw, **extra)
+        for k in names:
+            if not np.array_equal(g[k][:, ~mask].view(np.int64), ref[k][:, ~mask].view(np.int64)):
+                msgs.append(f"{tag}: {k} differs")
+        for k in g["diag"]:
+            if not np.array_equal(np.asarray(g["diag"][k]).view(np.int64), np.asarray(ref["diag"][k]).view(np.int64)):
+                msgs.append(f"{tag}: basin totals of {k} differ")
+    g32 = api.splash_grid(swm.astype(np.float32), tcm.astype(np.float32), pnm.astype(np.float32), *args, **kw)
+    for k in names:  # the synthetic forcing is float-representable: single-precision transport is lossless
+        if not np.array_equal(g32[k][:, ~mask].view(np.int64), ref[k][:, ~mask].view(np.int64)):
+            msgs.append(f"f32 transport: {k} differs")
+    bad += len(msgs)
+    print(f"case {case}: {H}x{W} x {nt} d, {int(mask.sum())} NA cells, monthly={monthly}: {'ok' if not msgs else msgs[:4]}", flush=True)
+print("problems", bad)
+sys.exit(1 if bad else 0)
