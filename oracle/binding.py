@@ -445,10 +445,14 @@ def grazing_mask(oracle, lat, slop, asp_c, doy, year, hs_deg=0.01):
 class Ref:
     """The real reference SOLAR/EVAP classes (oracle/_ref); raises if it was never built."""
 
-    def __init__(self):
-        path = os.path.join(_HERE, "_ref", "libsplash_ref.so")
+    def __init__(self, variant=None):
+        """variant: None = the pinned build; "B" / "K" = the other legal builds of the same sources
+        (oracle/Makefile `ref-variants`; tools/conditioning_real_reference.py)"""
+        path = os.path.join(_HERE, "_ref", f"libsplash_ref{'_' + variant if variant else ''}.so")
         if not os.path.exists(path):
             build()
+            if variant:
+                subprocess.check_call(["make", "-C", _HERE, "ref-variants"], stdout=subprocess.DEVNULL)
         self.lib = L = C.CDLL(path)
         L.ref_solar.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int] + [C.c_double] * 7 + [_dp]
         L.ref_evap.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int] + \

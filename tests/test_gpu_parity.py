@@ -149,6 +149,8 @@ def test_day_step_transitions_random_and_edges(api, oracle):
     names = ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "qin_prev", "tdrain")
     worst = 0.0
     ncase = 0
+    skipped = dict(fragile=0, grazing=0, residual=0)
+    ncmp = nloose = 0  # the bulk: comparisons beyond 1e-9 relative (+1e-12)
     for it in range(700):
         soil = [rng.uniform(15, 70), rng.uniform(8, 25), rng.uniform(0.3, 8), rng.uniform(0, 40),
                 rng.choice([np.nan, rng.uniform(0.9, 1.6)]), rng.choice([2.0, rng.uniform(0.6, 2.0)])]
@@ -172,25 +174,32 @@ def test_day_step_transitions_random_and_edges(api, oracle):
         s1, e1 = oracle.run_one_day(lat, elv, doy, yr, wn, sw_in, tc, pn, slop, asp, snow, snf, si, qin,
                                     td, nd)
         from oracle.binding import grazing_mask
-        if oracle.fragile_events() > 0 or \
-                grazing_mask(oracle, np.array([lat]), np.array([slop]), np.array([asp]),
-                             np.array([doy], np.int32), np.array([yr], np.int32)).any():
-            continue  # conditioning classes (DESIGN "Conditioning")
+        # conditioning classes (DESIGN "Conditioning"): tallied by kind and bounded below -- a change
+        # that made the test skip more of its cases fails it
+        if oracle.fragile_events() > 0:
+            skipped["fragile"] += 1
+            continue
+        if grazing_mask(oracle, np.array([lat]), np.array([slop]), np.array([asp]),
+                        np.array([doy], np.int32), np.array([yr], np.int32)).any():
+            skipped["grazing"] += 1
+            continue
         oracle.lib.orc_debug_ptr.restype = C.POINTER(C.c_double * 16)
         dbg = oracle.lib.orc_debug_ptr().contents
-        if 0.0 < abs(dbg[6]) < 1e-10:
-            # the bucket started at SAT and overflowed: what is left of the recharge after
-            # `R -= ro_d` (src/SPLASH.cpp:1386-1390) is the rounding residual of (SAT + R) - SAT,
-            # +-1e-13, and its SIGN switches the drainage branch of :1470 on or off -- no two
-            # evaluations of R that differ in the last bit agree on it (only reachable when a day
-            # starts exactly at SAT, which a preceding day with drainage never produces)
-            continue
+        # the bucket started at SAT and overflowed: what is left of the recharge after
+        # `R -= ro_d` (src/SPLASH.cpp:1386-1390) is the rounding residual of (SAT + R) - SAT,
+        # +-1e-13, and its SIGN switches the drainage branch of :1470 on or off -- no two
+        # evaluations of R that differ in the last bit agree on it (only reachable when a day
+        # starts exactly at SAT, which a preceding day with drainage never produces).  The series
+        # upstream of that branch (radiation, evaporation, snow) are still compared.
+        residual = 0.0 < abs(dbg[6]) < 1e-10
+        if residual:
+            skipped["residual"] += 1
         g = api.SPLASH(lat, elv).run_all([doy], [yr], [sw_in], [tc], [pn], wn, slop, asp, snow, [snf], si,
                                          qin, td, nd)
         ref = dict(wn=s1["sm"], ro=s1["ro"], pet=e1["pet"], aet=e1["aet"], snow=s1["swe"], cond=e1["cond"],
                    bflow=s1["bflow"], netr=e1["rn_d"] / 1e6, qin_prev=s1["sqout"], tdrain=s1["tdr"])
-        ncase += 1
-        for k in names:
+        ncase += 0 if residual else 1
+        for k in (("pet", "aet", "snow", "cond", "netr") if residual else names):
             a, b = float(g[k][0]), float(ref[k])
             if np.isnan(b) or np.isinf(b):
                 assert (np.isnan(a) and np.isnan(b)) or a == b, (it, k, a, b)
@@ -198,9 +207,14 @@ def test_day_step_transitions_random_and_edges(api, oracle):
                 err = max(abs(a - b) - 1e-9, 0.0) / max(abs(b), 1e-300)
                 worst = max(worst, err)
                 assert err <= 1e-5, (it, k, a, b, dict(wn=wn, tc=tc, sw_in=sw_in, pn=pn, slop=slop, td=td))
+                ncmp += 1
+                nloose += abs(a - b) > 1e-9 * abs(b) + 1e-12
         assert float(g["snwage"][0]) == s1["nd"]
-    print("cases", ncase, "worst rel err", worst)
-    assert ncase > 600
+    print("cases", ncase, "skipped by class", skipped, "worst rel err", worst, "beyond 1e-9:", nloose, "of", ncmp)
+    # 700 seeded cases: 642 compared in full, 58 start exactly at SAT and overflow (compared upstream of
+    # the drainage branch only), none meets a noise denominator or a grazing sun
+    assert ncase >= 640 and skipped["residual"] <= 60 and skipped["fragile"] <= 2 and skipped["grazing"] <= 2, \
+        (ncase, skipped)
 
 
 def _bourne_prelude(oracle, b):

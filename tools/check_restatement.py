@@ -34,6 +34,9 @@ ORC = os.path.join(ROOT, "oracle", "splash_oracle.c")
 # (reference line range, oracle function)
 UNITS = [
     ("run_one_day", (920, 1588), "orc_run_one_day"),
+    # spin_up's day step (called at :1658, :1674, :1715, :1729): a second copy of run_one_day with other
+    # names for the EVAP result and the output struct, and without the bookkeeping of the public method
+    ("quick_run", (150, 918), "orc_run_one_day"),
     ("spin_up", (1594, 1749), "orc_spin_up"),
     ("run_all", (1833, 1916), "run_all_strided"),
     ("moist_surf", (1921, 1961), "orc_moist_surf"),
@@ -93,7 +96,16 @@ def statements(body):
 TYPE = r"(?:const\s+)?(?:double|float|int|long|size_t|orc_smr|orc_etr|smr|etr|vector<double>|List)\b\s*\*?\s*"
 
 
-def norm(s, oracle):
+# Per-unit renames applied to the REFERENCE side before the comparison -- names only, plus the one
+# literal quick_run spells differently from run_one_day (`Ksat_visc*24.0` at :505 vs `Ksat_visc*24` at
+# :1281: the int literal is converted to the same double 24.0 by the usual arithmetic conversions).
+RENAMES = {
+    "quick_run": [(r"\bdn\.", "dvap."), (r"^dn=", "dvap="), (r"\bdsm\b", "dsoil"),
+                  (r"\(infi/\(Ksat_visc\*24\.0\)\)", "(infi/(Ksat_visc*24))")],
+}
+
+
+def norm(s, oracle, unit=None):
     s = re.sub(r"\s+", "", re.sub(r"^\s*" + TYPE, "", s.strip()))
     s = re.sub(r"^else", "", s)
     if not oracle:
@@ -104,6 +116,8 @@ def norm(s, oracle):
         s = re.sub(r"\bmoist_surf\(", "orc_moist_surf(", s)
         s = re.sub(r"\binf_GA\(", "orc_inf_GA(", s)
         s = s.replace("this->", "")
+        for pat, rep in RENAMES.get(unit, ()):
+            s = re.sub(pat, rep, s)
     s = s.replace("1.0e6", "1e6").replace("*fstride", "")
     return s
 
@@ -200,7 +214,7 @@ def main():
     for unit, (l0, l1), fn in UNITS:
         rbody = "\n".join(ref_lines[l0 - 1:l1])
         rbody = rbody[rbody.index("{") + 1:]
-        rs = [norm(s, False) for s in statements(rbody)]
+        rs = [norm(s, False, unit) for s in statements(rbody)]
         os_ = [norm(s, True) for s in statements(oracle_function(orc_src, fn))]
         rc, oc = day_calls(rs, False), day_calls(os_, True)
         rs = [s for s in rs if arithmetic(s)]

@@ -5,7 +5,7 @@ The parity tests set aside a few cell-days on which the reference's own result i
 the reference disagrees WITH ITSELF, and that little else is set aside:
 
   A  oracle/liboracle.so            pinned flags (gcc -O2, no -march, no contraction)
-  B  -O3 -march=native -ffp-contract=fast     another legal build of the same source
+  B  -O3 -march=x86-64-v3 -ffp-contract=fast     another legal build of the same source
   C  -DORC_PERTURB_LIBM             the same source against "another correct libm": every pow/exp/
                                     log/sin/cos/tan/acos result moved by -1/0/+1 ulp (hash of the
                                     arguments); exact cases and the float viscosity left alone
@@ -66,8 +66,8 @@ def main():
 
     A = Oracle()
     variants = {
-        "B (-O3 -march=native -ffp-contract=fast)":
-            Oracle(build_variant("fast", ["-O3", "-march=native", "-ffp-contract=fast"])),
+        "B (-O3 -march=x86-64-v3 -ffp-contract=fast)":
+            Oracle(build_variant("fast", ["-O3", "-march=x86-64-v3", "-ffp-contract=fast"])),
         "C (libm results +-1 ulp)": Oracle(build_variant("pert", ["-O2", "-DORC_PERTURB_LIBM"])),
         "D (libm results up to +-4 ulp)": Oracle(build_variant("pert4", ["-O2", "-DORC_PERTURB_LIBM",
                                                                          "-DORC_PERTURB_ULPS=4"])),

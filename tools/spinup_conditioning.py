@@ -1,7 +1,7 @@
 """Evidence for the fourth conditioning class: cells whose spin-up #2 never meets the
 1 mm criterion and is not periodic.  After 1000 passes of such an orbit the state the reference
 hands to run_all depends on its own last bits: for the given cells of tools/parity_sweep.py grids the
-oracle's source is run as built (A), as another legal build (B: -O3 -march=native -ffp-contract=fast)
+oracle's source is run as built (A), as another legal build (B: -O3 -march=x86-64-v3 -ffp-contract=fast)
 and against "another correct libm" (C: every libm result moved by -1/0/+1 ulp), whole pipeline.
 CPU only.     python tools/spinup_conditioning.py g:cell [g:cell ...]"""
 import os, sys
@@ -11,7 +11,7 @@ from oracle.binding import Oracle
 from tools.conditioning_evidence import build_variant
 nt, W, H = 730, 128, 64
 libs = {"A": None,
-        "B": build_variant("B", ["-O3", "-march=native", "-ffp-contract=fast"]),
+        "B": build_variant("B", ["-O3", "-march=x86-64-v3", "-ffp-contract=fast"]),
         "C": build_variant("C", ["-O2", "-ffp-contract=off", "-DORC_PERTURB_LIBM"])}
 orc = {k: Oracle(v) for k, v in libs.items()}
 o = orc["A"]
