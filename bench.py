@@ -176,18 +176,13 @@ def main():
 
 
 def allreduce_(ctx, t, op=None):
-    """in-place all-reduce of a device tensor (RCCL), or through the host with the gloo rehearsal"""
-    dist, torch = ctx["dist"], ctx["torch"]
+    """in-place all-reduce of a device tensor: rsplash_amd.dist.all_reduce_ (RCCL, or through the host
+    with the gloo rehearsal) -- the same function tests/test_dist_cpu.py exercises with two ranks"""
     if ctx["world"] == 1:
         return t
-    op = op or dist.ReduceOp.SUM
-    if ctx["backend"] == "nccl":
-        dist.all_reduce(t, op=op)
-    else:
-        h = t.cpu()
-        dist.all_reduce(h, op=op)
-        t.copy_(h)
-    return t
+    from rsplash_amd.dist import all_reduce_
+    dist = ctx["dist"]
+    return all_reduce_(t, "max" if op == dist.ReduceOp.MAX else "sum")
 
 
 def timed_region(ctx, step, steps, warmup):

@@ -55,7 +55,9 @@ splash.point <- function(sw_in, tc, pn, lat, elev, slop = 0, asp = 0, soil_data,
   long = c("Soil water content", "surface runoff", "potential evapotranspiration",
            "actual evapotranspiration", "snow water equivalent", "condensation", "drainage",
            "daytime net radiation", "fraction of available water content"),
-  ret  = c("wn", "ro", "pet", "aet", "snow", "bflow", "cond", "netrad", "sm_lim"),  # names of :449
+  # name of the same brick in the list splash.grid returns (R/splash.grid.R:449) -- POSITIONAL with
+  # `key`: the returned list is re-ordered by name afterwards, never relabelled
+  ret  = c("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netrad", "sm_lim"),
   stringsAsFactors = FALSE)
 
 # splash.grid with the reference's signature (R/splash.grid.R:28).  Static preparation (upslope

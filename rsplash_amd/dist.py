@@ -29,10 +29,36 @@ def row_block_partition(n_rows, n_cols, world, rank, valid_per_row=None):
     return dict(row0=r0, row1=r1, cell0=r0 * n_cols, ncell=(r1 - r0) * n_cols)
 
 
-def allreduce_diag(diag, group=None):
-    """Sum the [nmonth, NDIAG] monthly totals over all ranks, in place (one small all-reduce per
-    time chunk: latency bound, so xGMI bandwidth is irrelevant)."""
+def all_reduce_(t, op="sum", group=None):
+    """In-place all-reduce of a tensor over the ranks of torch.distributed: directly on the device
+    with the nccl (= RCCL) backend, through a host copy with gloo (CPU rehearsals, CPU tensors).
+    No-op outside a process group or with one rank.  This is the ONE collective of the gridded run
+    (bench.py and the multi-rank tests both go through it)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(diag, op=dist.ReduceOp.SUM, group=group)
-    return diag
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, op=rop, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=rop, group=group)
+    return t
+
+
+def allreduce_diag(diag_acc, group=None):
+    """Global water-balance totals: sums the EXACT fixed-point limbs `diag_acc` (int64
+    [n_basin, nmonth, NDIAG+1, 2], include/splash_hip.h: what k_run_all adds into
+    splash_dev_out.diag_acc / what splash_grid_out.diag_acc returns) over all ranks, in place.
+    Integer addition is associative: every rank ends with bitwise the same limbs, equal to those of
+    a single-process run over the whole grid, whatever the partition and the reduction order -- a
+    sum of doubles would have neither property.  A few KB per call: latency bound, xGMI bandwidth is
+    irrelevant.  Returns (diag_acc, diag) with diag = the totals as doubles [n_basin, nmonth, NDIAG]
+    (splash_diag_finalize_host: one rounding per total)."""
+    import torch
+    if diag_acc.dtype != torch.int64:
+        raise TypeError("allreduce_diag reduces the int64 limbs (diag_acc), not rounded doubles")
+    all_reduce_(diag_acc, "sum", group)
+    from . import api
+    return diag_acc, api.diag_finalize_host(diag_acc.cpu().numpy())[0]

@@ -94,3 +94,32 @@ def test_cpp_host_mirror_compiles_and_links(tmp_path):
     r = subprocess.run([build_cpp_mirror(str(tmp_path))], capture_output=True, text=True)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_r_wrapper_labels_results_positionally():
+    """r/splash_hip.R (no R interpreter here: checked as text): the list splash.grid() returns is
+    labelled with `.splash_outputs$ret`, which must name, position by position, the brick that
+    `.splash_outputs$key` -- the order the C shim returns them in -- holds there (round 2 had bflow and
+    cond swapped), and the shim's own order must be that of SPLASH_OUT_* in the header."""
+    import re
+    txt = open(os.path.join(ROOT, "r", "splash_hip.R")).read()
+    tab = txt[txt.index(".splash_outputs <- data.frame("):]
+    tab = tab[:tab.index("stringsAsFactors")]
+
+    def col(name):
+        m = re.search(r"\b" + name + r"\s*=\s*c\(([^)]*)\)", tab)
+        return re.findall(r'"([^"]*)"', m.group(1))
+    key, ret, stem = col("key"), col("ret"), col("stem")
+    assert key == ["wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "sm_lim"]
+    assert ret == [{"netr": "netrad"}.get(k, k) for k in key]
+    assert stem == [{"wn": "swc", "snow": "swe", "netr": "netrad"}.get(k, k) for k in key]
+    # the order of the reference's return value (R/splash.grid.R:449) is restored BY NAME
+    assert 'out[c("wn", "ro", "pet", "aet", "snow", "bflow", "cond", "netrad", "sm_lim")]' in txt
+    hdr = open(os.path.join(ROOT, "include", "splash_hip.h")).read()
+    m = re.search(r"#define SPLASH_NOUT 9\s*/\*\s*([a-z_, ]+?)\s*\(", hdr)
+    assert [x.strip() for x in m.group(1).split(",")] == key
+    shim = open(os.path.join(ROOT, "r", "splash_shim.c")).read()
+    for m in re.finditer(r'names\[\] = \{([^}]*)\}', shim):
+        got = re.findall(r'"([^"]*)"', m.group(1))
+        if got[0] == "wn":
+            assert got == key

@@ -42,6 +42,28 @@ def _free_port():
     return p
 
 
+NDIAG = 6
+
+
+def _limbs(res, pn, mid, nm):
+    """The exact fixed-point limbs k_run_all accumulates (include/splash_hip.h), formed
+    here from the oracle's rasters: per cell and month precipitation, aet, ro, bflow summed, wn and
+    snow at the month's last day; v = a/2^16 + r, a = rint(v*2^16), b = rint(r*2^48); int64 sums
+    over cells.  Layout [1, nmonth, NDIAG+1, 2]; the last record counts cell-months."""
+    acc = np.zeros((1, nm, NDIAG + 1, 2), np.int64)
+    for m in range(nm):
+        days = np.where(mid == m)[0]
+        figs = [pn[days].sum(0), res["aet"][days].sum(0), res["ro"][days].sum(0), res["bflow"][days].sum(0),
+                res["wn"][days[-1]], res["snow"][days[-1]]]
+        for q, v in enumerate(figs):
+            a = np.rint(v * 65536.0)
+            r = v - a / 65536.0
+            acc[0, m, q, 0] = a.astype(np.int64).sum()
+            acc[0, m, q, 1] = np.rint(r * 281474976710656.0).astype(np.int64).sum()
+        acc[0, m, NDIAG, 0] = v.size
+    return acc
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -58,18 +80,17 @@ def _worker(rank, world, port, q):
                                  st["elev"])
     res, _ = o.grid(doy, year, month, mid, nm, sw, tc, pn, st["lat"], st["elev"], st["slop"],
                     st["asp"], st["soil"], st["au"], st["resolution"], n_threads=2)
-    # per-rank monthly totals in the layout of SPLASH_NDIAG (aet, ro, bflow columns)
-    diag = torch.zeros(nm, 6, dtype=torch.float64)
-    for j, k in ((1, "aet"), (2, "ro"), (3, "bflow")):
-        for m in range(nm):
-            diag[m, j] = res[k][mid == m].sum()
-    allreduce_diag(diag)
-    q.put((rank, p, diag.numpy(), res["wn"]))
+    # this rank's limbs, then THE collective of the gridded run (what bench.py issues per step)
+    acc = torch.from_numpy(_limbs(res, pn, mid, nm))
+    acc, diag = allreduce_diag(acc)
+    with pytest.raises(TypeError):  # rounded doubles are refused: their sum depends on the order
+        allreduce_diag(torch.zeros(1, nm, NDIAG))
+    q.put((rank, p, acc.numpy().copy(), diag, res["wn"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_partition_and_diag_allreduce(oracle):
+def test_two_rank_partition_and_exact_limb_allreduce(oracle):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -88,14 +109,21 @@ def test_two_rank_partition_and_diag_allreduce(oracle):
     sw, tc, pn = oracle.synth_forcing(20221130, H, W, 0, H * W, 0, doy, st["lat"], st["elev"])
     res, _ = oracle.grid(doy, year, month, mid, nm, sw, tc, pn, st["lat"], st["elev"], st["slop"],
                          st["asp"], st["soil"], st["au"], st["resolution"])
-    # every rank holds the global totals; the rank blocks tile the grid exactly
-    wn = np.concatenate([g[3] for g in got], axis=1)
+    # the rank blocks tile the grid exactly
+    wn = np.concatenate([g[4] for g in got], axis=1)
     assert np.array_equal(wn, res["wn"])
-    for _, _, d, _ in got:
-        for j, k in ((1, "aet"), (2, "ro"), (3, "bflow")):
-            ref = np.array([res[k][mid == m].sum() for m in range(nm)])
-            assert np.allclose(d[:, j], ref, rtol=1e-12)
-    assert np.array_equal(got[0][2], got[1][2])
+    # every rank ends with the limbs of the single-process run, BITWISE, and so with the same doubles
+    whole = _limbs(res, pn, mid, nm)
+    for _, _, acc, diag, _ in got:
+        assert acc.dtype == np.int64 and np.array_equal(acc, whole)
+    assert np.array_equal(got[0][3], got[1][3])
+    # the doubles (splash_diag_finalize_host) are the totals to the last bit or so
+    from rsplash_amd import api
+    d1, cnt = api.diag_finalize_host(whole)
+    assert np.array_equal(d1, got[0][3]) and (cnt[0, :, 0] == H * W).all()
+    for qi, k in ((1, "aet"), (2, "ro"), (3, "bflow")):
+        ref = np.array([res[k][mid == m].astype(np.longdouble).sum() for m in range(nm)], dtype=np.longdouble)
+        assert np.allclose(d1[0, :, qi], ref.astype(np.float64), rtol=1e-13, atol=1e-9)
 
 
 def test_bench_launches_its_own_ranks():

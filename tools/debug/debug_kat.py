@@ -1,7 +1,7 @@
 """Largest deviations of the HIP SOLAR+EVAP path from the real reference's known answers
 (tests/golden/ref_evap_kat.npz), per output, with the row's inputs (GPU box)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from rsplash_amd import api
 k = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "ref_evap_kat.npz"))

@@ -1,7 +1,7 @@
 """GPU box: parity failure rate versus pore-size index lambda (which cells are really chaotic?)"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import rsplash_amd
 rsplash_amd.build_library()

@@ -1,6 +1,6 @@
 """debug aid: one cell-day of the benchmark grid in one-step mode -- the GPU against the oracle as built\n(A) and its two other builds (B, C of oracle/parity.py).  python tools/debug_onestep_variants.py row cell day"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from rsplash_amd import api

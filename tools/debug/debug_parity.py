@@ -2,7 +2,7 @@
 print the worst cell-days per output."""
 import os, sys, json
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import rsplash_amd
 rsplash_amd.build_library()

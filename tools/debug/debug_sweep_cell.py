@@ -2,7 +2,7 @@
 first day and series of divergence, oracle events around it.
     python tools/debug_sweep_cell.py <grid index g> <cell> [cells_per_grid=8192] [days=730]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import rsplash_amd.api as api
 from oracle.binding import Oracle
