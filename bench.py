@@ -11,8 +11,11 @@ ranks already exist and nothing is spawned.
 Workloads (BASELINE.json configs; --config selects, default 2 = the configuration the metric is
 quoted on):
   1  256 x 256 flat-terrain grid, 365 days, 1 GPU
-  2  4096 x 4096 grid with slope/aspect/upslope area, 365 days; with N ranks every rank owns a
-     4096-row block of a (4096*N)-row grid (weak scaling)
+  2  4096 x 4096 grid with slope/aspect/upslope area, 365 days.  With N ranks (`--scaling`):
+       strong (default)  THE 4096 x 4096 grid of the metric, row blocks of `--chunk-rows` rows dealt
+                         round-robin to the ranks (rank r owns blocks r, r+N, ...: every rank gets
+                         every latitude band, so the ranks finish together)
+       weak              every rank owns a 4096-row block of a (4096*N)-row grid
   3  30 years of daily forcing with spin-up, one rank's share (512 x 4096 cells = 1/8 of 4096^2)
      streamed one calendar year at a time through two forcing buffers (a 30-year raster cannot be
      resident: 11.8 TB for the whole grid), state carried in HBM
@@ -93,6 +96,9 @@ def parse_args(argv=None):
     ap.add_argument("--block-rows", type=int, default=512, help="rows per run_all launch")
     ap.add_argument("--flat", action="store_true", help="flat terrain (implied by --config 1)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="configs 1/2 with N > 1: split THE grid over the ranks, or one grid per rank")
+    ap.add_argument("--chunk-rows", type=int, default=64, help="strong scaling: rows per dealt row block")
     return ap.parse_args(argv)
 
 
@@ -217,7 +223,8 @@ def base_line(ctx, value, steps, warmup, dt, workload, extra_cfg):
     cfg.update(extra_cfg)
     return {"metric": metric, "value": value, "unit": "cell-days/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg}
+            "scaling": extra_cfg.get("scaling", "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": cfg}
 
 
 def roofline(avg_launch_s, units_per_launch, key, kernel):
@@ -233,6 +240,8 @@ def roofline(avg_launch_s, units_per_launch, key, kernel):
             traffic = None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "profiles/traffic.json: separate rocprofv3 --pmc passes of this command on an "
+                              "earlier run (tools/pmc_fetch.sh), not measured in this run; so is valu_busy_frac",
             "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS, "kernel": kernel,
             "avg_launch_ms": avg_launch_s * 1e3, "units_per_launch": units_per_launch,
             "alg_bytes_per_unit": ALG_BYTES_PER_CELL_DAY, "valu_busy_frac": valu_busy,
@@ -249,10 +258,21 @@ def run_resident(ctx):
     nt = args.days or 365
     steps = args.steps if args.steps is not None else 3
     warmup = args.warmup if args.warmup is not None else 1
-    n = H * W
     terrain = 0 if flat else 1
-    cell0 = rank * n
-    Htot = H * world
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        # THE H x W grid, cut into row blocks of chunk_rows rows that are dealt round-robin
+        Htot = H
+        cr = max(1, min(args.chunk_rows, H))
+        starts = list(range(0, H, cr))
+        chunks = [(r0, min(cr, H - r0)) for k, r0 in enumerate(starts) if k % world == rank]
+        cr_eff = cr
+    else:
+        Htot = H * world
+        chunks = [(rank * H, H)]
+        cr_eff = H
+    n = sum(nr for _, nr in chunks) * W
+    total_cells = float(Htot) * W
     dates = np.datetime64("2001-01-01") + np.arange(nt)
     cal = api.Calendar.from_dates(dates)
     nm = cal.nmonth
@@ -264,9 +284,23 @@ def run_resident(ctx):
     t_setup = time.time()
     lat, elev, slop, asp, res = (torch.empty(n, **f64) for _ in range(5))
     soil, au = torch.empty(6, n, **f64), torch.empty(3, n, **f64)
-    api.dev_synth_statics(SEED, Htot, W, cell0, n, terrain, lat, elev, slop, asp, res, soil, au, sp)
     sw, tc, pn = (torch.empty(nt, n, **f64) for _ in range(3))
-    api.dev_synth_forcing(SEED, cal, 0, nt, cell0, n, lat, elev, sw, tc, pn, n, sp)
+    off = 0
+    for r0, nr in chunks:  # counter-based generators: any range of cells of the grid, anywhere
+        nc = nr * W
+        if len(chunks) == 1:
+            api.dev_synth_statics(SEED, Htot, W, r0 * W, nc, terrain, lat, elev, slop, asp, res, soil, au, sp)
+        else:
+            t5 = [torch.empty(nc, **f64) for _ in range(5)]
+            tso, tau = torch.empty(6, nc, **f64), torch.empty(3, nc, **f64)
+            api.dev_synth_statics(SEED, Htot, W, r0 * W, nc, terrain, *t5, tso, tau, sp)
+            for dst, src in zip((lat, elev, slop, asp, res), t5):
+                dst[off:off + nc] = src
+            soil[:, off:off + nc] = tso
+            au[:, off:off + nc] = tau
+        api.dev_synth_forcing(SEED, cal, 0, nt, r0 * W, nc, lat[off:], elev[off:], sw[:, off:], tc[:, off:],
+                              pn[:, off:], n, sp)
+        off += nc
     par = torch.empty(api.NPAR, n, **f64)
     Tt = torch.empty(n, **f64)
     state = torch.empty(api.NSTATE, n, **f64)
@@ -285,7 +319,7 @@ def run_resident(ctx):
     del work
     state0 = state.clone()
 
-    bn = min(args.block_rows, H) * W                       # cells per run_all launch
+    bn = min(args.block_rows, n // W) * W                  # cells per run_all launch
     blocks = [(c0, min(c0 + bn, n)) for c0 in range(0, n, bn)]
     outb = {k: torch.empty(nt, bn, **f64) for k in OUT5}
     acc = torch.zeros(1, nm, api.DIAG_REC, dtype=torch.int64, device=dev)
@@ -313,7 +347,7 @@ def run_resident(ctx):
         api.dev_diag_finalize(acc, 1, nm, diag, stream=sp)
 
     dt = timed_region(ctx, step, steps, warmup)
-    cell_days_step = float(n) * nt * world
+    cell_days_step = total_cells * nt
     value = cell_days_step * steps / dt
     k_ms = np.array([a.elapsed_time(b) for a, b, _ in ev])
     k_cells = np.array([c for _, _, c in ev], dtype=np.float64)
@@ -321,13 +355,26 @@ def run_resident(ctx):
     avg_launch_s = float(k_ms[full].mean()) / 1e3
     units_per_launch = float(k_cells.max()) * nt
 
-    brows = min(args.block_rows, H)
+    brows = min(args.block_rows, n // W)
+    kind = 'flat' if flat else 'slope/aspect + lateral flow'
+    if world == 1:
+        split = "one GPU"
+        mode = "weak"
+    elif strong:
+        split = (f"split over {world} GPUs: row blocks of {cr_eff} rows dealt round-robin, {n // W} rows "
+                 f"({n} cells) per GPU")
+        mode = "strong"
+    else:
+        split = f"one {H}x{W} block per GPU ({world} GPUs: a {Htot}x{W} grid in all)"
+        mode = "weak"
     line = base_line(ctx, value, steps, warmup, dt,
-                     f"{H}x{W} synthetic grid per GPU, {'flat' if flat else 'slope/aspect + lateral flow'}, "
-                     f"{nt} days, daily outputs wn/snow/ro/aet/pet, row blocks of {brows}",
-                     {"grid_rows_per_gpu": H, "grid_cols": W, "days": nt, "block_rows": brows,
+                     f"{Htot}x{W} synthetic grid in total, {split}; {kind}, {nt} days, daily outputs "
+                     f"wn/snow/ro/aet/pet, run_all launches of {brows} rows",
+                     {"scaling": mode, "grid_rows_total": Htot, "grid_rows_per_gpu": n // W, "grid_cols": W,
+                      "days": nt, "block_rows": brows,
                       "timed": "K2 snow threshold + K5 run_all + K7 monthly water-balance totals "
                                "(+ all-reduce), inputs resident in HBM"})
+    line["config"].pop("scaling", None)
     line["roofline"] = roofline(avg_launch_s, units_per_launch, f"{brows}x{W}x{nt}", "k_run_all<daily,diag>")
     # both spin-ups of every cell + one transient pass: what a whole splash.grid call costs.
     # Measured as the library runs it for a host caller: the spin-up's long tail (a few cells per
@@ -337,7 +384,7 @@ def run_resident(ctx):
     work = torch.empty(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
     mask_p, cells_p, ncells_p = api.dev_spin_up_pending(work, n)
     late_cap = max(4096, n // 64)
-    late = {k: torch.empty(nt, late_cap, **f64) for k in OUT5}
+    late = {k: torch.empty(nt, late_cap, **f64) for k in OUT5}  # noqa
     s2 = torch.cuda.Stream(device=dev)
     par_i = par.clone()
     par_i[15] = par0_cellout
@@ -382,12 +429,16 @@ def run_resident(ctx):
                       "note": "both spin-ups of every cell (2..1000 passes of 365 days each, data "
                               "dependent) run alone on one stream, untimed setup of the steps above"}
     line["setup_s"] = setup_s
-    line["water_balance"] = {"annual_precip_mm_per_cell": float(diag[0, :, 0].sum().item()) / (n * world),
-                             "annual_aet_mm_per_cell": float(diag[0, :, 1].sum().item()) / (n * world),
-                             "annual_runoff_mm_per_cell": float(diag[0, :, 2].sum().item()) / (n * world)}
+    line["water_balance"] = {"annual_precip_mm_per_cell": float(diag[0, :, 0].sum().item()) / total_cells,
+                             "annual_aet_mm_per_cell": float(diag[0, :, 1].sum().item()) / total_cells,
+                             "annual_runoff_mm_per_cell": float(diag[0, :, 2].sum().item()) / total_cells}
 
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    # rank 0 (at any N): CPU baseline on a bounded sample of ITS cells + the parity figures of the same
+    # sample; the other ranks wait at the barrier so that the group is torn down together
+    if rank == 0 and args.cpu_seconds > 0:
         cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp)
+    if world > 1:
+        ctx["dist"].barrier()
     cal.close()
     return line
 
@@ -607,6 +658,38 @@ def run_streamed(ctx):
                       "timed": "per year: forcing generation (second stream, overlapped) + K5 run_all + K7; "
                                "one all-reduce of the totals at the end"})
     line["roofline"] = roofline(avg_launch_s, units_per_launch, f"stream{n}", "k_run_all (one calendar year)")
+    # What the overlapped figure hides: the stand-in generator of the NEXT year's forcing runs on the
+    # second stream beside every run_all launch and takes its share of the machine.  Measured apart,
+    # after the timed region: one year of generation alone, one run_all launch with the generator idle.
+    torch.cuda.synchronize()
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(gen_stream):
+        g0.record(gen_stream)
+    generate(ybounds[0], ybounds[1], 0)
+    with torch.cuda.stream(gen_stream):
+        g1.record(gen_stream)
+    torch.cuda.synchronize()
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st_tmp = state0.clone()
+    acc_tmp = torch.zeros_like(acc)
+    k0.record(stream)
+    if cfg4:
+        api.dev_run_all(cal, 0, ybounds[1], n, *bufs[0], n, Tt, par, n, st_tmp, n, outs, n, monthly=True,
+                        diag_acc=acc_tmp, basin=basin, n_basin=n_basin, stream=sp)
+    else:
+        api.dev_run_all(cal, 0, ybounds[1], n, *bufs[0], n, Tt, par, n, st_tmp, n, outs, n, monthly=False,
+                        diag_acc=acc_tmp, stream=sp)
+    k1.record(stream)
+    freed[0].record(stream)
+    torch.cuda.synchronize()
+    idle_s = k0.elapsed_time(k1) / 1e3
+    idle = ALG_BYTES_PER_CELL_DAY * float(n) * ybounds[1] / idle_s / 1e9
+    line["generator"] = {"ms_per_year": g0.elapsed_time(g1), "run_all_ms_per_year_overlapped": avg_launch_s * 1e3,
+                         "run_all_ms_per_year_generator_idle": idle_s * 1e3,
+                         "roofline_frac_generator_idle": idle / HBM_PEAK_GBS,
+                         "note": "the synthetic-forcing generator (stand-in for the input stream of a real 30-year "
+                                 "run) shares the GPU with run_all in the timed region; `roofline` is the overlapped "
+                                 "launch, this is the same launch (first year) with the second stream idle"}
     if cfg4:
         line["roofline"]["note"] = ("monthly outputs: algorithmic bytes are 24 B per cell-day, not 64; the "
                                     "figure is kept on the 64 B convention for comparability. "

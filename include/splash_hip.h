@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPLASH_ABI_VERSION 2
+#define SPLASH_ABI_VERSION 3
 
 enum {
     SPLASH_OK = 0,
@@ -322,6 +322,10 @@ typedef struct {
      * GPU).  Results are independent of the split, bit for bit, totals included. */
     int n_devices;
     const int* devices;
+    /* (ABI 3) share of a device's free memory this call may plan its blocks with; 0 = 0.85.  A
+     * caller that keeps several calls in flight on one device (splash_grid_submit) gives each its
+     * share, e.g. 0.4 for two. */
+    double mem_fraction;
 } splash_opts;
 
 typedef struct {
@@ -340,6 +344,20 @@ typedef struct {
  * days of possible snowfall, NaN state from the first such day). */
 int splash_grid_run(const splash_grid_in* in, const splash_opts* opt, const splash_grid_out* out,
                     char* err, size_t errlen);
+
+/* The same call in two halves, for a host loop over row blocks that wants more than one block in
+ * flight (the reference's receive loop, R/splash.grid.R:359-400, keeps every worker of its cluster
+ * busy while it writes the block that came back): _submit starts the call on its own host thread
+ * and streams and returns at once; _wait blocks until the results are in `out` and returns the
+ * call's code (the job is freed either way).  Every array behind `in`, `opt` and `out` must stay
+ * valid and untouched until _wait returns; the three structs themselves are copied.  Calls in flight
+ * on the same device share its memory: give each a splash_opts.mem_fraction.  Inside ONE call the
+ * blocks are pipelined already (transfers of neighbouring blocks overlap the kernels, and the
+ * spin-up's long tail runs once per call): a caller that can hand over a large block should. */
+typedef struct splash_grid_job splash_grid_job;
+int splash_grid_submit(const splash_grid_in* in, const splash_opts* opt, const splash_grid_out* out,
+                       splash_grid_job** job, char* err, size_t errlen);
+int splash_grid_wait(splash_grid_job* job, char* err, size_t errlen);
 
 /* splash.point (R/splash.point.R:29-225) for one site: the same pipeline with ncell = 1.
  * au: pointer to 1 value (scalar Au, ncellin=ncellout=3) when n_au==1, or 3 values. */

@@ -72,45 +72,55 @@ ATOL_STRICT = 1e-12                                   # exact zero
 # (fraction, rtol) pairs: at least `fraction` of all cell-days within rtol*|ref| + ATOL_STRICT.
 # Trajectory / whole-pipeline comparisons carry the state, so an ulp of one day is amplified by the
 # bucket's own dynamics over the following year; one-step comparisons restart every day.
-BULK_ONE_STEP = ((1.0 - 1e-5, 1e-9), (1.0 - 2e-6, 1e-7))
-BULK_TRAJECTORY = ((1.0 - 1e-3, 1e-9), (1.0 - 1e-4, 1e-7))
+# Levels (profiles/r03_parity_histograms.md, a decade above what was measured): one-step, 4 grids, 1.6e7
+# cell-days: at most 5.2e-5 of a series' cell-days beyond 1e-9 (tdrain; aet 2.4e-5, pet 1.5e-5: low sun),
+# 2.6e-6 beyond 1e-7; trajectory: 2.6e-5 (wn) and 2.5e-6 (aet).  Whole pipeline (each side from its own
+# spin-up, 24 grids, 1.4e8 cell-days, cells set aside for a flipped critical event left out): 7e-5 and
+# 4e-5 -- a spin-up that ends 1e-6 mm apart stays apart for the whole run of that cell, so those
+# levels are counted in cells: `min_cells` cells' worth of cell-days may always differ.
+BULK_ONE_STEP = dict(levels=((1.0 - 5e-4, 1e-9), (1.0 - 5e-5, 1e-7)), min_cells=0)
+BULK_TRAJECTORY = dict(levels=((1.0 - 5e-4, 1e-9), (1.0 - 5e-5, 1e-7)), min_cells=1)
+BULK_PIPELINE = dict(levels=((1.0 - 2e-3, 1e-9), (1.0 - 1e-3, 1e-7)), min_cells=2)
 
 
 def error_profile(a, f, floor=None):
     """a, f: product and reference arrays of one series (any shape).  Returns a dict of plain ints/floats:
-      n            cell-days compared (NaN == NaN and equal infinities count as exact)
-      exact        bit-for-bit equal values
-      hist         counts by decade of |a-f|/|f| over the cell-days with f != 0 that are not exact:
-                   hist[i] = count with error <= DECADES[i] (and > DECADES[i-1]); hist[-1]: > 1e-5
-      ref_zero     cell-days with f == 0;  ref_zero_exact: of which a == 0;  ref_zero_max_abs: max |a| there;
-                   ref_zero_over_1e-12: of which |a| > ATOL_STRICT
+      n            cell-days compared
+      exact        bit-for-bit equal values (NaN == NaN and equal infinities count as exact)
+      tiny         0 < |a-f| <= 1e-12 absolute (SURVEY.md 8d's tolerance for exact zeros): neither exact nor
+                   in the decades below -- a relative error of a value of 1e-30 mm/day says nothing
+      hist         the rest, by decade of |a-f|/|f|: hist[i] = count with error <= DECADES[i] (and >
+                   DECADES[i-1]); hist[-1]: > 1e-5 (a reference value of exactly 0 with |a| > 1e-12 lands here)
+      ref_zero     cell-days with f == 0;  ref_zero_over_1e_12: of which |a| > 1e-12
+      beyond_1e_9, beyond_1e_7   cell-days with |a-f| > r|f| + 1e-12 for r = 1e-9, 1e-7 (the bulk levels)
       only_atol    pass with atol 1e-9 but not with 1e-12 (|d| <= rtol|f| + 1e-9, > rtol|f| + 1e-12)
       only_floor   pass only through the series' floor (aet: 1e-7 pet, ro: 1e-10 wn)
       out_of_tol   fail the parity tolerance (floor included)"""
+    rows = int(np.shape(a)[0]) if np.ndim(a) == 2 else 1  # cell-days per cell ([nt, ncell] arrays)
     a = np.asarray(a, dtype=np.float64).ravel()
     f = np.asarray(f, dtype=np.float64).ravel()
-    with np.errstate(invalid="ignore", divide="ignore"):
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
         same = (a == f) | (np.isnan(a) & np.isnan(f))
         d = np.abs(a - f)
         d = np.where(same, 0.0, np.where(np.isnan(d), np.inf, d))
-        fz = f == 0.0
-        rel = d[~fz & ~same] / np.abs(f[~fz & ~same])
+        tiny = ~same & (d <= ATOL_STRICT)
+        rest = ~same & ~tiny
+        rel = d[rest] / np.abs(f[rest])
         hist = np.bincount(np.searchsorted(np.array(DECADES), np.nan_to_num(rel, nan=np.inf), side="left"),
                            minlength=len(DECADES) + 1)
-        lim0 = RTOL * np.abs(f)
-        lim0 = np.where(np.isnan(lim0), 0.0, lim0)
+        af = np.where(np.isnan(f), 0.0, np.abs(f))
+        lim0 = RTOL * af
         p_strict = d <= lim0 + ATOL_STRICT
         p_atol = d <= lim0 + ATOL
         fl = np.nan_to_num(np.asarray(floor, dtype=np.float64).ravel(), nan=0.0, posinf=0.0) if floor is not None else 0.0
         p_floor = d <= lim0 + ATOL + fl
-        within = {r: int((d <= r * np.where(np.isnan(f), 0.0, np.abs(f)) + ATOL_STRICT).sum()) for r in (1e-9, 1e-7)}
-    az = np.abs(a[fz])
-    return dict(n=int(a.size), exact=int(same.sum()), hist=[int(x) for x in hist],
-                ref_zero=int(fz.sum()), ref_zero_exact=int((az == 0.0).sum()),
-                ref_zero_max_abs=float(az.max()) if az.size else 0.0,
-                ref_zero_over_1e_12=int((az > ATOL_STRICT).sum()),
+        beyond = {r: int((d > r * af + ATOL_STRICT).sum()) for r in (1e-9, 1e-7)}
+    fz = f == 0.0
+    return dict(n=int(a.size), rows_per_cell=rows, exact=int(same.sum()), tiny=int(tiny.sum()), hist=[int(x) for x in hist],
+                ref_zero=int(fz.sum()), ref_zero_over_1e_12=int((np.abs(a[fz]) > ATOL_STRICT).sum()),
+                beyond_1e_9=beyond[1e-9], beyond_1e_7=beyond[1e-7],
                 only_atol=int((p_atol & ~p_strict).sum()), only_floor=int((p_floor & ~p_atol).sum()),
-                out_of_tol=int((~p_floor).sum()), within_1e_9=within[1e-9], within_1e_7=within[1e-7])
+                out_of_tol=int((~p_floor).sum()))
 
 
 def merge_profiles(ps):
@@ -123,34 +133,36 @@ def merge_profiles(ps):
         for k, v in p.items():
             if k == "hist":
                 out[k] = [x + y for x, y in zip(out[k], v)]
-            elif k == "ref_zero_max_abs":
+            elif k == "rows_per_cell":
                 out[k] = max(out[k], v)
             else:
                 out[k] += v
     return out
 
 
-def bulk_violations(profiles, levels, name=""):
-    """profiles: {series: error_profile}.  levels: BULK_ONE_STEP / BULK_TRAJECTORY."""
+def bulk_violations(profiles, bulk, name=""):
+    """profiles: {series: error_profile}.  bulk: BULK_ONE_STEP / BULK_TRAJECTORY / BULK_PIPELINE."""
     viol = []
     for k, p in profiles.items():
-        for frac, rt in levels:
-            got = p["within_1e_9" if rt == 1e-9 else "within_1e_7"] / max(p["n"], 1)
-            if got < frac:
-                viol.append(f"{name}{k}: only {got:.8f} of {p['n']} cell-days within {rt:g}|ref| + {ATOL_STRICT:g} "
-                            f"(the bulk must hold {frac:.7f})")
+        for frac, rt in bulk["levels"]:
+            beyond = p["beyond_1e_9" if rt == 1e-9 else "beyond_1e_7"]
+            allowed = max((1.0 - frac) * p["n"], bulk["min_cells"] * p["rows_per_cell"])
+            if beyond > allowed:
+                viol.append(f"{name}{k}: {beyond} of {p['n']} cell-days beyond {rt:g}|ref| + {ATOL_STRICT:g} "
+                            f"(the bulk allows {allowed:.0f})")
     return viol
 
 
 def format_profiles(profiles, title=""):
     """markdown table of error_profile dicts, one row per series"""
-    head = ["series", "cell-days", "bit-equal"] + [f"<={e:.0e}" for e in DECADES] + [">1e-5", "ref=0", "ref=0: |x|>1e-12",
-                                                                                  "only atol 1e-9", "only floor", "out of tol."]
+    head = ["series", "cell-days", "bit-equal", "|d|<=1e-12"] + [f"<={e:.0e}" for e in DECADES] + \
+        [">1e-5", "beyond 1e-9", "beyond 1e-7", "ref=0", "ref=0: |x|>1e-12", "only atol 1e-9", "only floor", "out of tol."]
     L = ([title, ""] if title else []) + ["| " + " | ".join(head) + " |", "|" + "---|" * len(head)]
     for k, p in profiles.items():
-        L.append("| " + " | ".join([k, str(p["n"]), str(p["exact"])] + [str(x) for x in p["hist"]] +
-                                   [str(p["ref_zero"]), str(p["ref_zero_over_1e_12"]), str(p["only_atol"]),
-                                    str(p["only_floor"]), str(p["out_of_tol"])]) + " |")
+        L.append("| " + " | ".join([k, str(p["n"]), str(p["exact"]), str(p["tiny"])] + [str(x) for x in p["hist"]] +
+                                   [str(p["beyond_1e_9"]), str(p["beyond_1e_7"]), str(p["ref_zero"]),
+                                    str(p["ref_zero_over_1e_12"]), str(p["only_atol"]), str(p["only_floor"]),
+                                    str(p["out_of_tol"])]) + " |")
     return "\n".join(L)
 
 
@@ -391,7 +403,7 @@ def reference_disagrees_with_itself(cells, ref, aux, statics, forcing, names):
 
 
 def assert_whole_pipeline(oracle, g, ref, aux, statics, doy, year, name="", names=None,
-                          monthly_mid=None, max_flip_frac=0.05, forcing=None, bulk=BULK_TRAJECTORY, n_worst=0):
+                          monthly_mid=None, max_flip_frac=0.05, forcing=None, bulk=BULK_PIPELINE, n_worst=0):
     """splash_grid (GPU: soil_hydro, snow threshold, both spin-ups, run_all, sm_lim) against the
     oracle's splash.grid restatement, each from its own spin-up.
 
@@ -423,8 +435,11 @@ def assert_whole_pipeline(oracle, g, ref, aux, statics, doy, year, name="", name
         prof[k] = error_profile(a, b, fl)
         bad = _bad(a, b, floor=fl) & ~graz
         bad_cell |= bad.any(0)
-        ok = ~bad_cell
-        e = np.where(graz | np.isnan(b), 0.0, np.maximum(np.abs(a - b) - ATOL, 0.0) / np.maximum(np.abs(b), 1e-300))
+    ok = ~bad_cell  # the cells finally kept (a cell set aside for ANY series is out of every series' figure)
+    for k in names:
+        a, b = np.asarray(g[k]).reshape(ref[k].shape), ref[k]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            e = np.where(graz | np.isnan(b), 0.0, np.maximum(np.abs(a - b) - ATOL, 0.0) / np.maximum(np.abs(b), 1e-300))
         worst[k] = float(e[:, ok].max()) if ok.any() else 0.0
     stray = bad_cell & ~flagged
     self_dis = 0
@@ -440,8 +455,14 @@ def assert_whole_pipeline(oracle, g, ref, aux, statics, doy, year, name="", name
         f"{name}: {flips} of {int(flagged.sum())} critical-event cells differ"
     assert bad_cell.mean() <= 5e-3, f"{name}: {bad_cell.mean():.2e} of the cells set aside"
     assert graz.mean() <= 2e-2, f"{name}: {graz.mean():.2e} of the cell-days after a grazing-sun day"
-    bv = bulk_violations(prof, bulk, name + ": whole pipeline ") if bulk else []
-    assert not bv, "; ".join(bv)
+    if bulk:  # the bulk of the cells that are not set aside (those are counted and bounded above)
+        kept = {}
+        for k in names:
+            a, b = np.asarray(g[k]).reshape(ref[k].shape), ref[k]
+            fl = _floor(k, ref) if monthly_mid is None else None
+            kept[k] = error_profile(a[:, ok], b[:, ok], fl[:, ok] if fl is not None else None)
+        bv = bulk_violations(kept, bulk, name + ": whole pipeline ")
+        assert not bv, "; ".join(bv)
     worst_rows = []
     if n_worst:
         keep = ~graz & ~bad_cell[None, :]

@@ -27,7 +27,7 @@ class GridIn(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("monthly_out", C.c_int), ("device", C.c_int), ("max_cells_per_launch", C.c_size_t),
-                ("n_devices", C.c_int), ("devices", _ip)]
+                ("n_devices", C.c_int), ("devices", _ip), ("mem_fraction", C.c_double)]
 
 
 class GridOut(C.Structure):
@@ -117,6 +117,9 @@ def _load():
     L.splash_unswc_run.argtypes = [C.c_size_t, C.c_int, _dp, _dp, C.c_double, _dp, _dp, _dp,
                                    C.c_char_p, C.c_size_t]
     L.splash_dev_math_probe.argtypes = [C.c_size_t, _dp, _dp, _dp]
+    L.splash_grid_submit.argtypes = [C.POINTER(GridIn), C.POINTER(Opts), C.POINTER(GridOut),
+                                     C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    L.splash_grid_wait.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.splash_grid_run.argtypes = [C.POINTER(GridIn), C.POINTER(Opts), C.POINTER(GridOut),
                                   C.c_char_p, C.c_size_t]
     L.splash_point_run.argtypes = [C.c_int, _ip, _ip, _ip, _dp, _dp, _dp] + [C.c_double] * 4 + \
@@ -150,7 +153,7 @@ SYMBOLS = (
     "splash_dev_sinkfill", "splash_dev_flow_accumulation", "splash_dev_mfd_area", "splash_static_rasters_run",
     "splash_dev_run_all", "splash_dev_synth_statics", "splash_dev_synth_forcing",
     "splash_dev_evap_batch", "splash_dev_math_probe", "splash_dev_unswc", "splash_unswc_run",
-    "splash_grid_run", "splash_point_run", "splash_mod_spin_up",
+    "splash_grid_run", "splash_grid_submit", "splash_grid_wait", "splash_point_run", "splash_mod_spin_up",
     "splash_mod_run_all", "splash_mod_run_one_year", "splash_mod_moist_surf", "splash_mod_inf_GA",
 )
 

@@ -105,7 +105,8 @@ def splash_point(sw_in, tc, pn, lat, elev, slop=0.0, asp=0.0, soil_data=None, Au
 def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=250.0,
                 time_index=None, sim_control=None, outputs=OUT_NAMES, device=0,
                 max_cells_per_launch=0, want_aux=False, want_diag=False, outdir=None, lon=None,
-                basin=None, n_basin=0, devices=None, out=None, want_state=True):
+                basin=None, n_basin=0, devices=None, out=None, want_state=True, submit=False,
+                mem_fraction=0.0):
     """R/splash.grid.R:28 on arrays.  sw_in/tc/pn: [nt, ncell] (or [nt, H, W]) daily rasters;
     elev/lat/slop/asp: [ncell]; soil: [6, ncell]; Au: [3, ncell] (area, ncellin, ncellout) or
     None.  The static rasters the reference derives with raster/GDAL/TauDEM (lat, slope, aspect,
@@ -122,7 +123,10 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     ([n_basin, nmonth] per quantity).  devices: list of HIP ordinals to split the cells over inside
     the one call (one host thread per entry; the same ordinal may repeat).
     out: dict name -> preallocated float64 array [nt_out, ...] to receive that series (what an R
-    caller's allocMatrix is); series not in `out` are allocated here."""
+    caller's allocMatrix is); series not in `out` are allocated here.
+    submit=True: splash_grid_submit -- the call runs on its own host thread and streams; a GridJob
+    comes back at once and its wait() returns what this function would have (a host loop over row
+    blocks keeps two or more in flight, each with its mem_fraction of the device's free memory)."""
     if time_index is None:
         raise ValueError("time_index is required")
     monthly = True if sim_control is None else bool(sim_control.get("monthly_out", True))
@@ -157,6 +161,7 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     if f32:
         gin.sw_in_f32, gin.tc_f32, gin.pn_f32 = f[0][1], f[1][1], f[2][1]
     nbas = 1
+    bas = None
     if basin is not None:
         bas = np.ascontiguousarray(np.asarray(basin, dtype=np.int32)).reshape(ncell)
         nbas = int(n_basin) if n_basin else int(bas.max()) + 1
@@ -178,7 +183,7 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     if want_state:
         state_end = np.empty((NSTATE,) + shp)
         gout.state_end = state_end.ctypes.data_as(_dp)
-    aux = diag = None
+    aux = diag = acc = None
     if want_aux:
         aux = np.empty((4,) + shp)
         gout.aux = aux.ctypes.data_as(_dp)
@@ -187,14 +192,48 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
         gout.diag = diag.ctypes.data_as(_dp)
         acc = np.zeros((nbas, nm, DIAG_REC), np.int64)
         gout.diag_acc = acc.ctypes.data_as(C.POINTER(C.c_int64))
-    opt = _lib.Opts(int(monthly), int(device), int(max_cells_per_launch), 0, None)
+    opt = _lib.Opts(int(monthly), int(device), int(max_cells_per_launch), 0, None, float(mem_fraction))
+    dv = None
     if devices is not None:
         dv = np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
         opt.n_devices, opt.devices = len(dv), dv.ctypes.data_as(_ip)
     err = C.create_string_buffer(512)
+    if submit:
+        job = C.c_void_p()
+        rc = lib.splash_grid_submit(C.byref(gin), C.byref(opt), C.byref(gout), C.byref(job), err, 512)
+        if rc:
+            raise SplashError(f"splash_grid_submit failed ({rc}): {err.value.decode()}")
+        keep = (f, st, so, au, ia, gin, opt, gout, dv, res, state_end, aux, diag, bas, acc)
+        return GridJob(job, keep, lambda: _grid_results(res, shp, lat, lon, outdir, time_index, monthly, want_state,
+                                                         state_end, want_aux, aux, want_diag, diag, acc, basin))
     rc = lib.splash_grid_run(C.byref(gin), C.byref(opt), C.byref(gout), err, 512)
     if rc:
         raise SplashError(f"splash_grid_run failed ({rc}): {err.value.decode()}")
+    return _grid_results(res, shp, lat, lon, outdir, time_index, monthly, want_state, state_end, want_aux, aux,
+                         want_diag, diag, acc, basin)
+
+
+class GridJob:
+    """a splash_grid call in flight (splash_grid_submit); wait() -> the results dict"""
+
+    def __init__(self, job, keep, finish):
+        self._job, self._keep, self._finish = job, keep, finish
+
+    def wait(self):
+        if self._job is None:
+            raise SplashError("GridJob.wait() called twice")
+        err = C.create_string_buffer(512)
+        rc = lib.splash_grid_wait(self._job, err, 512)
+        self._job = None
+        if rc:
+            raise SplashError(f"splash_grid_run failed ({rc}): {err.value.decode()}")
+        r = self._finish()
+        self._keep = None
+        return r
+
+
+def _grid_results(res, shp, lat, lon, outdir, time_index, monthly, want_state, state_end, want_aux, aux,
+                  want_diag, diag, acc, basin):
     if outdir is not None:
         if len(shp) != 2:
             raise ValueError("outdir needs [nt, H, W] rasters")

@@ -8,7 +8,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cmath>
 #include <cstdarg>
@@ -88,7 +90,10 @@ struct DevCtx {
     std::vector<PoolSlot> pool;
 };
 DevCtx g_ctx[64];
-std::mutex g_ctx_mu;
+// one lock per device: pool bookkeeping, the sizing + allocation phase of a grid worker (so that a
+// second job on the same device plans with what the first has left), the viscosity table
+std::recursive_mutex g_dev_mu[64];
+std::recursive_mutex& device_alloc_mutex(int dev) { return g_dev_mu[(dev >= 0 && dev < 64) ? dev : 0]; }
 
 void pool_release_idle(DevCtx& c)
 {
@@ -102,13 +107,26 @@ void pool_release_idle(DevCtx& c)
     }
 }
 
+// bytes of device `dev` held by idle pooled buffers: free memory as far as a new call is concerned
+// (hipMemGetInfo does not count them; a call that sized its blocks from the free figure alone shrank
+// with every call after the first multi-block one)
+size_t pool_idle_bytes(int dev)
+{
+    if (dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::recursive_mutex> lk(g_dev_mu[dev]);
+    size_t n = 0;
+    for (auto& s : g_ctx[dev].pool)
+        if (!s.busy) n += s.bytes;
+    return n;
+}
+
 hipError_t pool_alloc(void** out, size_t bytes)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || getenv("SPLASH_HIP_NO_POOL")) return hipMalloc(out, bytes);
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    std::lock_guard<std::recursive_mutex> lk(g_dev_mu[dev]);
     DevCtx& c = g_ctx[dev];
     PoolSlot* best = nullptr;
     for (auto& s : c.pool)
@@ -120,6 +138,10 @@ hipError_t pool_alloc(void** out, size_t bytes)
         *out = best->p;
         return hipSuccess;
     }
+    // no slot of that size: idle slots of other sizes are released first when the new buffer would
+    // not fit beside them (they were counted as free when the caller sized its blocks)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes + ((size_t)256 << 20) > free_b) pool_release_idle(c);
     e = hipMalloc(out, bytes);
     if (e != hipSuccess) { // make room and try once more
         (void)hipGetLastError();
@@ -133,13 +155,14 @@ hipError_t pool_alloc(void** out, size_t bytes)
 void pool_free(void* p)
 {
     if (!p) return;
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
-    for (int d = 0; d < 64; d++)
+    for (int d = 0; d < 64; d++) {
+        std::lock_guard<std::recursive_mutex> lk(g_dev_mu[d]);
         for (auto& s : g_ctx[d].pool)
             if (s.p == p) {
                 s.busy = false;
                 return;
             }
+    }
     (void)hipFree(p); // not pooled (SPLASH_HIP_NO_POOL)
 }
 
@@ -148,7 +171,7 @@ int visc_tables(ViscTables& vt)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
         return fail(SPLASH_ENODEV, nullptr, 0, "no current HIP device");
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    std::lock_guard<std::recursive_mutex> lk(g_dev_mu[dev]);
     DevCtx& c = g_ctx[dev];
     if (!c.rtab) {
         float* r = nullptr;
@@ -169,10 +192,10 @@ int visc_tables(ViscTables& vt)
 
 extern "C" void splash_hip_release_cache(void)
 {
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
     int cur = 0;
     (void)hipGetDevice(&cur);
     for (int d = 0; d < 64; d++) {
+        std::lock_guard<std::recursive_mutex> lk(g_dev_mu[d]);
         if (g_ctx[d].pool.empty()) continue;
         if (hipSetDevice(d) != hipSuccess) continue;
         pool_release_idle(g_ctx[d]);
@@ -917,293 +940,641 @@ struct GridPlan {
     int nt, nmonth, nt_out, n_out, monthly, n_basin;
     size_t max_cells;
     bool want_diag;
+    double mem_fraction; // share of the device's free memory one worker may plan with
 };
 
-// Valid cells [v0, v1) on `device`: what clFun does for a row block (R/splash.grid.R:277-308),
-// in HBM-sized blocks.  `share` = workers using this device (they split its free memory).
-// acc: this worker's host copy of the exact diagnostic limbs (summed by the caller).
-int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, int64_t* acc,
-                char* err, size_t errlen)
+inline double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// fn(i) for i in [0, n) on a few host threads (the gather/scatter loops of masked grids and the
+// patching of late cells: single-threaded they ran at ~1 GB/s)
+template <class F>
+void parallel_rows(size_t n, size_t bytes_per_row, F fn)
+{
+    unsigned nthr = std::thread::hardware_concurrency();
+    nthr = nthr == 0 ? 4 : (nthr > 8 ? 8 : nthr);
+    if (n * bytes_per_row < ((size_t)8 << 20) || n < 2 * nthr) nthr = 1;
+    if (nthr == 1) {
+        for (size_t i = 0; i < n; i++) fn(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < nthr; w++)
+        pool.emplace_back([=]() {
+            for (size_t i = w; i < n; i += nthr) fn(i);
+        });
+    for (auto& t : pool) t.join();
+}
+
+struct Stream {
+    hipStream_t s = nullptr;
+    ~Stream()
+    {
+        if (s) {
+            (void)hipStreamSynchronize(s); // nothing of this call may still run when its buffers go back to the pool
+            (void)hipStreamDestroy(s);
+        }
+    }
+    hipError_t create() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+};
+struct Event {
+    hipEvent_t e = nullptr;
+    ~Event()
+    {
+        if (e) (void)hipEventDestroy(e);
+    }
+    hipError_t create() { return hipEventCreateWithFlags(&e, hipEventDisableTiming); }
+};
+
+// The stragglers of all blocks of one worker: the jobs the first seven spin-up phases leave behind
+// (a few cells per ten thousand; the reference runs them up to 1000 passes, src/SPLASH.cpp:1697) are
+// copied here by k_pool_gather as soon as a block's phases are done -- forcing columns, parameters,
+// parked job -- so that the block's buffers are free for the next block and the tail, a latency
+// chain of over a second whatever the number of cells, runs ONCE per call instead of once per block.
+struct Pool {
+    size_t cap = 0;
+    DevBuf force, par, state, tt, origin, pass, basin, work, out;
+    double* sw() const { return force.as<double>(); }
+};
+
+// One lane of the pipeline: a host thread with its own stream, block buffers and spin-up workspace.
+// Lanes take the blocks in turn; while one lane's thread sits in a host<->device copy the other
+// lane's kernels have the GPU, so H2D of block k+1, the kernels of block k and D2H of block k-1
+// overlap (the SOCK cluster of R/splash.grid.R:359-400 overlapped its workers the same way).
+struct Lane {
+    DevBuf d_force, d_f32, d_out, d_par, d_state, d_stat, d_tt, d_pass, d_swork, d_basin, d_res, d_late;
+    std::vector<double> stage, hstat, hsmall;
+    std::vector<float> stage32;
+    std::vector<int> hpass;
+    std::vector<int32_t> hbasin;
+    int rc = SPLASH_OK;
+    char msg[512] = "";
+    Event ev_gather;
+    Stream st; // declared last = destroyed first: the stream is drained before the buffers above return to the pool
+};
+
+struct Worker {
+    const GridPlan& P;
+    int device;
+    size_t v0, v1, nb_max;
+    splash_calendar* cal = nullptr;
+    bool f32;
+    Pool pool;
+    DevBuf d_acc;
+    std::vector<Lane> lanes;
+    std::mutex mu;
+    std::condition_variable cv;
+    int lanes_gathered = 0;     // lanes whose last block's gather is enqueued (or that gave up)
+    std::atomic<bool> abort{false};
+    std::atomic<bool> prefaulted{false};
+    bool trace;
+    // what finish_pool brings back for patch_pool
+    uint32_t n_pool = 0;
+    std::vector<uint64_t> origin;
+    std::vector<double> patch, pstate, paux;
+    std::vector<int> ppass_h;
+    double t_pool[3] = {0, 0, 0};
+
+    Worker(const GridPlan& P_, int dev, size_t a, size_t b) : P(P_), device(dev), v0(a), v1(b), nb_max(0)
+    {
+        f32 = (P.in->sw_in == nullptr);
+        trace = getenv("SPLASH_TRACE") != nullptr;
+    }
+    ~Worker() { splash_calendar_destroy(cal); }
+
+    size_t nblocks() const { return (v1 - v0 + nb_max - 1) / nb_max; }
+    int lane_fail(Lane& L, int code, const char* what, hipError_t e)
+    {
+        snprintf(L.msg, sizeof L.msg, "%s: %s", what, e == hipSuccess ? g_err.c_str() : hipGetErrorString(e));
+        L.rc = code;
+        abort = true;
+        return code;
+    }
+    void lane_gathered()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        lanes_gathered++;
+        cv.notify_all();
+    }
+    int run_lane(int li);
+    int run_block(Lane& L, size_t k, bool last_of_lane, bool& signalled);
+    int late_fallback(Lane& L, size_t b0, size_t nb, const splash_dev_out& dout, uint32_t n_late);
+    int finish_pool(char* err, size_t errlen);
+    void patch_pool();
+};
+
+#define LANE_TRY(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return lane_fail(L, e__ == hipErrorOutOfMemory ? SPLASH_ENOMEM : SPLASH_EHIP, #expr, e__); \
+    } while (0)
+#define LANE_RC(expr)                                                 \
+    do {                                                              \
+        int rc__ = (expr);                                            \
+        if (rc__) return lane_fail(L, rc__, #expr, hipSuccess);       \
+    } while (0)
+
+int Worker::run_lane(int li)
+{
+    Lane& L = lanes[li];
+    bool signalled = false;
+    if (hipSetDevice(device) != hipSuccess) {
+        lane_fail(L, SPLASH_ENODEV, "hipSetDevice", hipErrorInvalidDevice);
+    } else {
+        const size_t nblk = nblocks(), nl = lanes.size();
+        size_t last = nblk; // this lane's last block
+        for (size_t k = li; k < nblk; k += nl) last = k;
+        for (size_t k = li; k < nblk && !abort; k += nl)
+            if (run_block(L, k, k == last, signalled)) break;
+    }
+    if (!signalled) lane_gathered();
+    return L.rc;
+}
+
+// Valid cells [b0, b0+nb) of the worker's range: what clFun does for a row block
+// (R/splash.grid.R:277-308).
+int Worker::run_block(Lane& L, size_t k, bool last_of_lane, bool& signalled)
 {
     const splash_grid_in* in = P.in;
     const splash_grid_out* out = P.out;
     const size_t N = P.N;
-    const int nt = P.nt, nt_out = P.nt_out, n_out = P.n_out;
-    HIP_TRY(hipSetDevice(device), err, errlen);
-    if (v1 <= v0) return SPLASH_OK;
-    splash_calendar* cal = nullptr;
-    if (int rc = splash_calendar_create(nt, in->doy, in->year, in->month, &cal, err, errlen)) return rc;
-    struct CalGuard {
-        splash_calendar* c;
-        ~CalGuard() { splash_calendar_destroy(c); }
-    } cg{cal};
-    const bool f32 = (in->sw_in == nullptr);
-
-    // cells per launch from free HBM
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b), err, errlen);
-    const size_t per_cell = (size_t)nt * 3 * 8 + (f32 ? (size_t)nt * 4 : 0) +
-                            (size_t)nt_out * n_out * 8 +
-                            (SPLASH_NPAR + SPLASH_NSTATE + 6 + 5 + 3 + 1 + 4 + 4 + 1) * 8 + 64;
-    // the spin-up's cache of day terms: 55 KB per slot, min(cells, 2^19) slots
-    const double budget = (double)free_b * 0.85 / (double)std::max(share, 1);
-    const size_t want = v1 - v0;
-    size_t nb_max = want;
-    auto need = [&](size_t nb) {
-        return (double)nb * (double)per_cell + (double)splash_dev_spin_up_work_size(nb);
-    };
-    if (need(nb_max) > budget) { // largest block that fits (bisection on a monotone function)
-        size_t lo = 0, hi = nb_max;
-        while (hi - lo > 256) {
-            const size_t mid = lo + (hi - lo) / 2;
-            if (need(mid) > budget) hi = mid; else lo = mid;
-        }
-        nb_max = lo;
-    }
-    if (P.max_cells) nb_max = std::min(nb_max, P.max_cells);
-    if (nb_max == 0) return fail(SPLASH_ENOMEM, err, errlen, "grid_run: not enough device memory");
-    nb_max = std::min(nb_max, v1 - v0);
-    nb_max = std::min(nb_max, kMaxCellsPerLaunch);
-    if (nb_max > 256) nb_max -= nb_max % 256;
-
-    const double t_w0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    DevBuf d_force, d_f32, d_out, d_par, d_state, d_stat, d_tt, d_pass, d_acc, d_swork, d_basin;
-    HIP_TRY(d_force.alloc((size_t)nt * 3 * nb_max * 8), err, errlen);
-    if (f32) HIP_TRY(d_f32.alloc((size_t)nt * nb_max * 4), err, errlen);
-    HIP_TRY(d_out.alloc((size_t)nt_out * std::max(n_out, 1) * nb_max * 8), err, errlen);
-    HIP_TRY(d_par.alloc((size_t)SPLASH_NPAR * nb_max * 8), err, errlen);
-    HIP_TRY(d_state.alloc((size_t)SPLASH_NSTATE * nb_max * 8), err, errlen);
-    HIP_TRY(d_stat.alloc((size_t)(5 + 6 + 3) * nb_max * 8), err, errlen);
-    HIP_TRY(d_tt.alloc(nb_max * 8), err, errlen);
-    HIP_TRY(d_pass.alloc(2 * nb_max * sizeof(int)), err, errlen);
-    HIP_TRY(d_swork.alloc(splash_dev_spin_up_work_size(nb_max)), err, errlen);
-    const size_t acc_bytes = splash_dev_diag_acc_size(P.n_basin, P.nmonth);
-    if (P.want_diag) {
-        HIP_TRY(d_acc.alloc(acc_bytes), err, errlen);
-        HIP_TRY(hipMemset(d_acc.p, 0, acc_bytes), err, errlen);
-        if (in->basin) HIP_TRY(d_basin.alloc(nb_max * sizeof(int32_t)), err, errlen);
-    }
-    std::vector<double> stage; // host gather/scatter buffer for masked grids
-    std::vector<float> stage32;
-    std::vector<double> hstat((size_t)(5 + 6 + 3) * nb_max), hsmall(5 * nb_max);
-    std::vector<int> hpass(2 * nb_max);
-    std::vector<int32_t> hbasin(in->basin && P.want_diag ? nb_max : 0);
-    if (!P.dense) {
-        stage.resize((size_t)std::max(f32 ? 0 : nt, nt_out) * nb_max);
-        if (f32) stage32.resize((size_t)nt * nb_max);
-    }
-
-    if (getenv("SPLASH_TRACE"))
-        fprintf(stderr, "[splash] device %d: calendar + allocations %.3f s\n", device,
-                std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_w0);
-    // two non-blocking streams: s1 the main sequence, s2 the spin-up's tail and the late cells
-    struct Streams {
-        hipStream_t a = nullptr, b = nullptr;
-        ~Streams()
-        {
-            if (a) (void)hipStreamDestroy(a);
-            if (b) (void)hipStreamDestroy(b);
-        }
-    } st_;
-    struct Event {
-        hipEvent_t e = nullptr;
-        ~Event()
-        {
-            if (e) (void)hipEventDestroy(e);
-        }
-    } ev;
-    HIP_TRY(hipStreamCreateWithFlags(&st_.a, hipStreamNonBlocking), err, errlen);
-    HIP_TRY(hipStreamCreateWithFlags(&st_.b, hipStreamNonBlocking), err, errlen);
-    HIP_TRY(hipEventCreateWithFlags(&ev.e, hipEventDisableTiming), err, errlen);
-    hipStream_t s1 = st_.a, s2 = st_.b;
-    const size_t late_cap = std::min(nb_max, std::max<size_t>(4096, nb_max / 64));
-    DevBuf d_late;
-    HIP_TRY(d_late.alloc((size_t)nt_out * std::max(n_out, 1) * late_cap * 8), err, errlen);
-    hipStream_t s = s1;
-    bool prefaulted = false;
-    // SPLASH_TRACE=1: wall-clock of the stages of every block on stderr (host-path tuning aid)
-    const bool trace = getenv("SPLASH_TRACE") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    for (size_t b0 = v0; b0 < v1; b0 += nb_max) {
-        double t_a = now();
-        const size_t nb = std::min(nb_max, v1 - b0);
-        const size_t* idx = P.idx + b0; // idx[j] = grid cell of the block's j-th cell
-        const size_t c0 = idx[0];       // dense: the block is cells [c0, c0+nb)
-        double* F = d_force.as<double>();
-        double* ddst[3] = {F, F + (size_t)nt * nb, F + (size_t)2 * nt * nb};
-        double *dsw = ddst[0], *dtc = ddst[1], *dpn = ddst[2];
+    const int nt = P.nt, nt_out = P.nt_out;
+    hipStream_t s = L.st.s;
+    const double t_a = now_s();
+    const size_t b0 = v0 + k * nb_max, nb = std::min(nb_max, v1 - b0);
+    const size_t* idx = P.idx + b0; // idx[j] = grid cell of the block's j-th cell
+    const size_t c0 = idx[0];       // dense: the block is cells [c0, c0+nb)
+    double* F = L.d_force.as<double>();
+    double* ddst[3] = {F, F + (size_t)nt * nb, F + (size_t)2 * nt * nb};
+    double *dsw = ddst[0], *dtc = ddst[1], *dpn = ddst[2];
+    // ---- host -> device.  (Pageable sources: the copies return when the source may be reused, so
+    // the staging vectors can be refilled at once; on the device they are ordered by the stream.)
+    for (int v = 0; v < 3; v++) {
         if (!f32) {
-            const double* hsrc[3] = {in->sw_in, in->tc, in->pn};
-            for (int v = 0; v < 3; v++) {
-                if (P.dense) {
-                    HIP_TRY(hipMemcpy2D(ddst[v], nb * 8, hsrc[v] + c0, N * 8, nb * 8, (size_t)nt,
-                                        hipMemcpyHostToDevice), err, errlen);
-                } else {
-                    for (int t = 0; t < nt; t++)
-                        for (size_t j = 0; j < nb; j++)
-                            stage[(size_t)t * nb + j] = hsrc[v][(size_t)t * N + idx[j]];
-                    HIP_TRY(hipMemcpy(ddst[v], stage.data(), (size_t)nt * nb * 8,
-                                      hipMemcpyHostToDevice), err, errlen);
-                }
+            const double* hsrc = v == 0 ? in->sw_in : (v == 1 ? in->tc : in->pn);
+            if (P.dense) {
+                LANE_TRY(hipMemcpy2DAsync(ddst[v], nb * 8, hsrc + c0, N * 8, nb * 8, (size_t)nt,
+                                          hipMemcpyHostToDevice, s));
+            } else {
+                double* stg = L.stage.data();
+                parallel_rows((size_t)nt, nb * 8, [=](size_t t) {
+                    const double* src = hsrc + t * N;
+                    double* dst = stg + t * nb;
+                    for (size_t j = 0; j < nb; j++) dst[j] = src[idx[j]];
+                });
+                LANE_TRY(hipMemcpyAsync(ddst[v], stg, (size_t)nt * nb * 8, hipMemcpyHostToDevice, s));
             }
         } else { // single-precision transport, widened on the device (lossless for FLT4S rasters)
-            const float* hsrc[3] = {in->sw_in_f32, in->tc_f32, in->pn_f32};
-            for (int v = 0; v < 3; v++) {
-                if (P.dense) {
-                    HIP_TRY(hipMemcpy2D(d_f32.p, nb * 4, hsrc[v] + c0, N * 4, nb * 4, (size_t)nt,
-                                        hipMemcpyHostToDevice), err, errlen);
-                } else {
-                    for (int t = 0; t < nt; t++)
-                        for (size_t j = 0; j < nb; j++)
-                            stage32[(size_t)t * nb + j] = hsrc[v][(size_t)t * N + idx[j]];
-                    HIP_TRY(hipMemcpy(d_f32.p, stage32.data(), (size_t)nt * nb * 4,
-                                      hipMemcpyHostToDevice), err, errlen);
-                }
-                HIP_TRY(launch_widen_f32(d_f32.as<float>(), (size_t)nt * nb, ddst[v], s), err, errlen);
-                HIP_TRY(hipStreamSynchronize(s), err, errlen); // d_f32 is reused by the next series
+            const float* hsrc = v == 0 ? in->sw_in_f32 : (v == 1 ? in->tc_f32 : in->pn_f32);
+            if (P.dense) {
+                LANE_TRY(hipMemcpy2DAsync(L.d_f32.p, nb * 4, hsrc + c0, N * 4, nb * 4, (size_t)nt,
+                                          hipMemcpyHostToDevice, s));
+            } else {
+                float* stg = L.stage32.data();
+                parallel_rows((size_t)nt, nb * 4, [=](size_t t) {
+                    const float* src = hsrc + t * N;
+                    float* dst = stg + t * nb;
+                    for (size_t j = 0; j < nb; j++) dst[j] = src[idx[j]];
+                });
+                LANE_TRY(hipMemcpyAsync(L.d_f32.p, stg, (size_t)nt * nb * 4, hipMemcpyHostToDevice, s));
             }
+            LANE_TRY(launch_widen_f32(L.d_f32.as<float>(), (size_t)nt * nb, ddst[v], s)); // same stream: d_f32 is
+                                                                                           // free for the next series
         }
-        // statics: lat, elev, slop, asp, resolution, soil[6], au[3]
+    }
+    // statics: lat, elev, slop, asp, resolution, soil[6], au[3]
+    {
+        double* hs = L.hstat.data();
         const double* st1[5] = {in->lat, in->elev, in->slop, in->asp, in->resolution};
-        for (int k = 0; k < 5; k++)
-            for (size_t j = 0; j < nb; j++) hstat[(size_t)k * nb + j] = st1[k][idx[j]];
-        for (int k = 0; k < 6; k++)
-            for (size_t j = 0; j < nb; j++)
-                hstat[(size_t)(5 + k) * nb + j] = in->soil[(size_t)k * N + idx[j]];
-        if (in->au)
-            for (int k = 0; k < 3; k++)
-                for (size_t j = 0; j < nb; j++)
-                    hstat[(size_t)(11 + k) * nb + j] = in->au[(size_t)k * N + idx[j]];
-        double* S = d_stat.as<double>();
-        HIP_TRY(hipMemcpy(S, hstat.data(), (size_t)14 * nb * 8, hipMemcpyHostToDevice), err, errlen);
-        if (!hbasin.empty()) {
-            for (size_t j = 0; j < nb; j++) hbasin[j] = in->basin[idx[j]];
-            HIP_TRY(hipMemcpy(d_basin.p, hbasin.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice),
-                    err, errlen);
-        }
+        parallel_rows(14, nb * 8, [=](size_t r) {
+            const double* src = r < 5 ? st1[r] : (r < 11 ? in->soil + (r - 5) * N : (in->au ? in->au + (r - 11) * N : nullptr));
+            double* dst = hs + r * nb;
+            if (!src) return;
+            for (size_t j = 0; j < nb; j++) dst[j] = src[idx[j]];
+        });
+    }
+    double* S = L.d_stat.as<double>();
+    LANE_TRY(hipMemcpyAsync(S, L.hstat.data(), (size_t)14 * nb * 8, hipMemcpyHostToDevice, s));
+    const bool with_basin = !L.hbasin.empty();
+    if (with_basin) {
+        for (size_t j = 0; j < nb; j++) L.hbasin[j] = in->basin[idx[j]];
+        LANE_TRY(hipMemcpyAsync(L.d_basin.p, L.hbasin.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    }
+    const double t_b = now_s();
 
-        double t_b = now();
-        double* par = d_par.as<double>();
-        double* state = d_state.as<double>();
-        double* Tt = d_tt.as<double>();
-        int rc;
-        rc = splash_dev_soil_hydro(nb, S, S + nb, S + 2 * nb, S + 3 * nb, S + 4 * nb, S + 5 * nb,
-                                   in->au ? S + 11 * nb : nullptr, par, s1);
+    // ---- kernels
+    double* par = L.d_par.as<double>();
+    double* state = L.d_state.as<double>();
+    double* Tt = L.d_tt.as<double>();
+    LANE_RC(splash_dev_soil_hydro(nb, S, S + nb, S + 2 * nb, S + 3 * nb, S + 4 * nb, S + 5 * nb,
+                                  in->au ? S + 11 * nb : nullptr, par, s));
+    LANE_RC(splash_dev_snow_threshold(nb, nt, dtc, nb, par, nb, Tt, s));
+    int* dpass = out->aux ? L.d_pass.as<int>() : nullptr;
+    LANE_RC(splash_dev_spin_up_begin(cal, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, dpass, L.d_swork.p, s));
+    const unsigned char* d_mask = nullptr;
+    const uint32_t *d_cells = nullptr, *d_ncells = nullptr;
+    (void)splash_dev_spin_up_pending(L.d_swork.p, nb, &d_mask, &d_cells, &d_ncells);
+    {   // the block's stragglers move to the pool
+        size_t o_wl_b, o_meta, o_ai, o_cnt, p_wl_b, p_meta, p_ai, p_cnt;
+        spin_work_layout(nb, &o_wl_b, &o_meta, &o_ai, &o_cnt);
+        spin_work_layout(pool.cap, &p_wl_b, &p_meta, &p_ai, &p_cnt);
+        char* w = (char*)L.d_swork.p;
+        char* pw = (char*)pool.work.p;
+        PoolGatherArgs g{};
+        g.cells = d_cells;
+        g.n_cells = d_ncells;
+        g.nt = nt;
+        g.sw = dsw; g.tc = dtc; g.pn = dpn;
+        g.ldf = nb;
+        g.par = par; g.ldp = nb;
+        g.state = state; g.lds = nb;
+        g.Tt = Tt;
+        g.meta = (const int*)(w + o_meta);
+        g.ai = (const double*)(w + o_ai);
+        g.passes = dpass;
+        g.ntotal = nb;
+        g.basin = with_basin ? L.d_basin.as<int>() : nullptr;
+        g.origin0 = (uint64_t)(b0 - v0);
+        g.cap = pool.cap;
+        g.p_sw = pool.sw();
+        g.p_tc = pool.sw() + (size_t)nt * pool.cap;
+        g.p_pn = pool.sw() + (size_t)2 * nt * pool.cap;
+        g.p_par = pool.par.as<double>();
+        g.p_state = pool.state.as<double>();
+        g.p_Tt = pool.tt.as<double>();
+        g.p_meta = (int*)(pw + p_meta);
+        g.p_ai = (double*)(pw + p_ai);
+        g.p_passes = out->aux ? pool.pass.as<int>() : nullptr;
+        g.p_basin = with_basin ? pool.basin.as<int>() : nullptr;
+        g.p_origin = pool.origin.as<uint64_t>();
+        g.p_wl = (uint32_t*)pw; // worklist 0: what the tail phase reads
+        g.p_n = (uint32_t*)(pw + p_cnt) + (kSpinPhases - 2);
+        g.res = L.d_res.as<uint32_t>();
+        LANE_TRY(launch_pool_gather(g, s));
+        LANE_TRY(hipEventRecord(L.ev_gather.e, s));
+    }
+    if (last_of_lane) { // the worker's thread may start the tail once every lane is here
+        lane_gathered();
+        signalled = true;
+    }
+    splash_dev_out dout{};
+    int q = 0;
+    for (int kk = 0; kk < SPLASH_NOUT; kk++)
+        dout.out[kk] = out->out[kk] ? L.d_out.as<double>() + (size_t)(q++) * nt_out * nb : nullptr;
+    dout.ldo = nb;
+    dout.monthly = P.monthly;
+    if (P.want_diag) {
+        dout.diag_acc = d_acc.as<int64_t>();
+        dout.basin = with_basin ? L.d_basin.as<int32_t>() : nullptr;
+        dout.n_basin = P.n_basin;
+    }
+    dout.skip = d_mask;
+    LANE_RC(splash_dev_run_all(cal, 0, nt, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, &dout, s));
+    // The kernels of this block are queued; while they run, map the caller's (typically freshly
+    // allocated) output arrays: the first touch of tens of GB is otherwise paid page by page inside
+    // the device-to-host copies.
+    if (P.dense && !prefaulted.exchange(true))
+        prefault_outputs(out->out, SPLASH_NOUT, N, P.idx[v0], v1 - v0, (size_t)nt_out);
+    const double t_c = now_s();
+    LANE_TRY(hipStreamSynchronize(s));
+    const double t_d = now_s();
+
+    // ---- device -> host
+    uint32_t res[3] = {0, 0, 0};
+    LANE_TRY(hipMemcpy(res, L.d_res.p, sizeof res, hipMemcpyDeviceToHost));
+    for (int kk = 0; kk < SPLASH_NOUT; kk++) {
+        if (!out->out[kk]) continue;
+        if (P.dense) {
+            LANE_TRY(hipMemcpy2D(out->out[kk] + c0, N * 8, dout.out[kk], nb * 8, nb * 8, (size_t)nt_out,
+                                 hipMemcpyDeviceToHost));
+        } else {
+            double* stg = L.stage.data();
+            LANE_TRY(hipMemcpy(stg, dout.out[kk], (size_t)nt_out * nb * 8, hipMemcpyDeviceToHost));
+            double* dsth = out->out[kk];
+            parallel_rows((size_t)nt_out, nb * 8, [=](size_t t) {
+                const double* src = stg + t * nb;
+                double* dst = dsth + t * N;
+                for (size_t j = 0; j < nb; j++) dst[idx[j]] = src[j];
+            });
+        }
+    }
+    if (out->state_end) {
+        LANE_TRY(hipMemcpy(L.hsmall.data(), state, 5 * nb * 8, hipMemcpyDeviceToHost));
+        for (int kk = 0; kk < 5; kk++)
+            for (size_t j = 0; j < nb; j++) out->state_end[(size_t)kk * N + idx[j]] = L.hsmall[(size_t)kk * nb + j];
+    }
+    if (out->aux) {
+        LANE_TRY(hipMemcpy(L.hsmall.data(), Tt, nb * 8, hipMemcpyDeviceToHost));
+        LANE_TRY(hipMemcpy(L.hsmall.data() + nb, par + (size_t)15 * nb, nb * 8, hipMemcpyDeviceToHost));
+        LANE_TRY(hipMemcpy(L.hpass.data(), L.d_pass.p, 2 * nb * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < nb; j++) {
+            out->aux[idx[j]] = L.hsmall[j];
+            out->aux[N + idx[j]] = L.hsmall[nb + j];
+            out->aux[2 * N + idx[j]] = L.hpass[j];
+            out->aux[3 * N + idx[j]] = L.hpass[nb + j];
+        }
+    }
+    const double t_e = now_s();
+    if (res[1] < res[2]) // the pool cannot take this block's stragglers: they are finished here, the old way
+        if (int rc = late_fallback(L, b0, nb, dout, res[2])) return rc;
+    if (trace)
+        fprintf(stderr, "[splash] device %d block %zu (%zu cells): host->device %.3f s, queue+prefault %.3f s, "
+                        "kernels (rest) %.3f s, device->host %.3f s, %u stragglers (%u to the pool)%s %.3f s\n",
+                device, k, nb, t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, res[2], res[1],
+                res[1] < res[2] ? ", finished in place" : "", now_s() - t_e);
+    return SPLASH_OK;
+}
+
+// Pool overflow: the block's own tail phase and its late cells in list mode, on the lane's stream
+// (what every block did before the pool existed).  Everything of the block is still on the device.
+int Worker::late_fallback(Lane& L, size_t b0, size_t nb, const splash_dev_out& dout, uint32_t n_late)
+{
+    const splash_grid_out* out = P.out;
+    const size_t N = P.N;
+    const int nt = P.nt, nt_out = P.nt_out, n_out = P.n_out;
+    const size_t* idx = P.idx + b0;
+    hipStream_t s = L.st.s;
+    double* F = L.d_force.as<double>();
+    double *dsw = F, *dtc = F + (size_t)nt * nb, *dpn = F + (size_t)2 * nt * nb;
+    double* par = L.d_par.as<double>();
+    double* state = L.d_state.as<double>();
+    double* Tt = L.d_tt.as<double>();
+    int* dpass = out->aux ? L.d_pass.as<int>() : nullptr;
+    LANE_RC(splash_dev_spin_up_finish(cal, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, dpass, L.d_swork.p, s));
+    const uint32_t* d_cells = nullptr;
+    (void)splash_dev_spin_up_pending(L.d_swork.p, nb, nullptr, &d_cells, nullptr);
+    std::vector<uint32_t> late(n_late);
+    LANE_TRY(hipMemcpyAsync(late.data(), d_cells, (size_t)n_late * 4, hipMemcpyDeviceToHost, s));
+    const size_t late_cap = std::min<size_t>(n_late, 1 << 16);
+    LANE_TRY(L.d_late.alloc((size_t)nt_out * std::max(n_out, 1) * late_cap * 8));
+    std::vector<double> patch((size_t)nt_out * late_cap);
+    for (size_t k0 = 0; k0 < n_late; k0 += late_cap) {
+        const size_t nl = std::min(late_cap, (size_t)n_late - k0);
+        splash_dev_out dl = dout;
+        int ql = 0;
+        for (int k = 0; k < SPLASH_NOUT; k++)
+            dl.out[k] = out->out[k] ? L.d_late.as<double>() + (size_t)(ql++) * nt_out * late_cap : nullptr;
+        dl.ldo = late_cap;
+        dl.skip = nullptr;
+        dl.cells = d_cells + k0;
+        LANE_RC(splash_dev_run_all(cal, 0, nt, nl, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, &dl, s));
+        LANE_TRY(hipStreamSynchronize(s));
+        for (int k = 0; k < SPLASH_NOUT; k++) {
+            if (!out->out[k]) continue;
+            LANE_TRY(hipMemcpy2D(patch.data(), nl * 8, dl.out[k], late_cap * 8, nl * 8, (size_t)nt_out,
+                                 hipMemcpyDeviceToHost));
+            for (int t = 0; t < nt_out; t++)
+                for (size_t j = 0; j < nl; j++)
+                    out->out[k][(size_t)t * N + idx[late[k0 + j]]] = patch[(size_t)t * nl + j];
+        }
+    }
+    // state, threshold, aridity index and pass counts of the late cells
+    if (out->state_end) {
+        LANE_TRY(hipMemcpy(L.hsmall.data(), state, 5 * nb * 8, hipMemcpyDeviceToHost));
+        for (uint32_t c : late)
+            for (int k = 0; k < 5; k++) out->state_end[(size_t)k * N + idx[c]] = L.hsmall[(size_t)k * nb + c];
+    }
+    if (out->aux) {
+        LANE_TRY(hipMemcpy(L.hsmall.data() + nb, par + (size_t)15 * nb, nb * 8, hipMemcpyDeviceToHost));
+        LANE_TRY(hipMemcpy(L.hpass.data(), L.d_pass.p, 2 * nb * sizeof(int), hipMemcpyDeviceToHost));
+        for (uint32_t c : late) {
+            out->aux[N + idx[c]] = L.hsmall[nb + c];
+            out->aux[2 * N + idx[c]] = L.hpass[c];
+            out->aux[3 * N + idx[c]] = L.hpass[nb + c];
+        }
+    }
+    return SPLASH_OK;
+}
+
+// The tail of the whole call: the last spin-up phase over the pool, then the transient run of its
+// cells, patched into the results once the lanes have delivered theirs.
+int Worker::finish_pool(char* err, size_t errlen)
+{
+    const splash_grid_out* out = P.out;
+    const size_t cap = pool.cap;
+    const int nt = P.nt, nt_out = P.nt_out, n_out = P.n_out;
+    Stream st;
+    HIP_TRY(st.create(), err, errlen);
+    hipStream_t s = st.s;
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return lanes_gathered == (int)lanes.size(); });
+    }
+    if (abort) return SPLASH_OK; // the lanes report their own failure
+    const double t0 = now_s();
+    for (auto& L : lanes) HIP_TRY(hipStreamWaitEvent(s, L.ev_gather.e, 0), err, errlen);
+    size_t p_cnt;
+    spin_work_layout(cap, nullptr, nullptr, nullptr, &p_cnt);
+    HIP_TRY(hipMemcpyAsync(&n_pool, (const uint32_t*)((char*)pool.work.p + p_cnt) + (kSpinPhases - 2),
+                           sizeof n_pool, hipMemcpyDeviceToHost, s), err, errlen);
+    HIP_TRY(hipStreamSynchronize(s), err, errlen); // every block's early phases and gather are done
+    const double t1 = now_s();
+    origin.assign(n_pool, 0);
+    if (n_pool) {
+        double *psw = pool.sw(), *ptc = psw + (size_t)nt * cap, *ppn = psw + (size_t)2 * nt * cap;
+        int* ppass = out->aux ? pool.pass.as<int>() : nullptr;
+        int rc = spin_phases(cal, cap, psw, ptc, ppn, cap, pool.tt.as<double>(), pool.par.as<double>(), cap,
+                             pool.state.as<double>(), cap, ppass, pool.work.p, s, kSpinPhases - 1, kSpinPhases);
         if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
-        rc = splash_dev_snow_threshold(nb, nt, dtc, nb, par, nb, Tt, s1);
-        if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
-        // The spin-up's tail (a few cells per thousand, over a second of sequential day steps) runs
-        // on a second stream while the first one already computes the transient run of all other
-        // cells and their results travel to the host; the late cells follow in list mode.
-        int* dpass = out->aux ? d_pass.as<int>() : nullptr;
-        rc = splash_dev_spin_up_begin(cal, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, dpass,
-                                      d_swork.p, s1);
-        if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
-        HIP_TRY(hipEventRecord(ev.e, s1), err, errlen);
-        const unsigned char* d_mask = nullptr;
-        const uint32_t *d_cells = nullptr, *d_ncells = nullptr;
-        (void)splash_dev_spin_up_pending(d_swork.p, nb, &d_mask, &d_cells, &d_ncells);
         splash_dev_out dout{};
         int q = 0;
         for (int k = 0; k < SPLASH_NOUT; k++)
-            dout.out[k] = out->out[k] ? d_out.as<double>() + (size_t)(q++) * nt_out * nb : nullptr;
-        dout.ldo = nb;
+            dout.out[k] = out->out[k] ? pool.out.as<double>() + (size_t)(q++) * nt_out * cap : nullptr;
+        dout.ldo = cap;
         dout.monthly = P.monthly;
         if (P.want_diag) {
             dout.diag_acc = d_acc.as<int64_t>();
-            dout.basin = in->basin ? d_basin.as<int32_t>() : nullptr;
+            dout.basin = P.in->basin ? pool.basin.as<int32_t>() : nullptr;
             dout.n_basin = P.n_basin;
         }
-        dout.skip = d_mask;
-        rc = splash_dev_run_all(cal, 0, nt, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, &dout, s1);
+        rc = splash_dev_run_all(cal, 0, nt, n_pool, psw, ptc, ppn, cap, pool.tt.as<double>(), pool.par.as<double>(),
+                                cap, pool.state.as<double>(), cap, &dout, s);
         if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
-        HIP_TRY(hipStreamWaitEvent(s2, ev.e, 0), err, errlen);
-        rc = splash_dev_spin_up_finish(cal, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, dpass,
-                                       d_swork.p, s2);
-        if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
-        // The kernels of this block are queued; while they run, map the caller's (typically
-        // freshly allocated) output arrays: the first touch of tens of GB is otherwise paid page
-        // by page inside the device-to-host copies.
-        if (P.dense && !prefaulted) {
-            prefault_outputs(out->out, SPLASH_NOUT, N, c0, v1 - b0, (size_t)nt_out);
-            prefaulted = true;
-        }
-        double t_c = now();
-        HIP_TRY(hipStreamSynchronize(s1), err, errlen);
-        double t_d = now();
-
-        for (int k = 0; k < SPLASH_NOUT; k++) {
-            if (!out->out[k]) continue;
-            if (P.dense) {
-                HIP_TRY(hipMemcpy2D(out->out[k] + c0, N * 8, dout.out[k], nb * 8, nb * 8,
-                                    (size_t)nt_out, hipMemcpyDeviceToHost), err, errlen);
-            } else {
-                HIP_TRY(hipMemcpy(stage.data(), dout.out[k], (size_t)nt_out * nb * 8,
-                                  hipMemcpyDeviceToHost), err, errlen);
-                for (int t = 0; t < nt_out; t++)
-                    for (size_t j = 0; j < nb; j++)
-                        out->out[k][(size_t)t * N + idx[j]] = stage[(size_t)t * nb + j];
-            }
-        }
-        double t_e = now();
-        // the late cells: transient run in list mode into compact arrays, patched into the results
-        HIP_TRY(hipStreamSynchronize(s2), err, errlen);
-        double t_f = now();
-        uint32_t n_late = 0;
-        HIP_TRY(hipMemcpy(&n_late, d_ncells, sizeof n_late, hipMemcpyDeviceToHost), err, errlen);
-        if (n_late) {
-            std::vector<uint32_t> late(n_late);
-            HIP_TRY(hipMemcpy(late.data(), d_cells, (size_t)n_late * 4, hipMemcpyDeviceToHost), err, errlen);
-            std::vector<double> patch((size_t)nt_out * late_cap);
-            for (size_t k0 = 0; k0 < n_late; k0 += late_cap) {
-                const size_t nl = std::min(late_cap, (size_t)n_late - k0);
-                splash_dev_out dl = dout;
-                int ql = 0;
-                for (int k = 0; k < SPLASH_NOUT; k++)
-                    dl.out[k] = out->out[k] ? d_late.as<double>() + (size_t)(ql++) * nt_out * late_cap : nullptr;
-                dl.ldo = late_cap;
-                dl.skip = nullptr;
-                dl.cells = d_cells + k0;
-                rc = splash_dev_run_all(cal, 0, nt, nl, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, &dl, s2);
-                if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
-                HIP_TRY(hipStreamSynchronize(s2), err, errlen);
-                for (int k = 0; k < SPLASH_NOUT; k++) {
-                    if (!out->out[k]) continue;
-                    HIP_TRY(hipMemcpy2D(patch.data(), nl * 8, dl.out[k], late_cap * 8, nl * 8,
-                                        (size_t)nt_out, hipMemcpyDeviceToHost), err, errlen);
-                    for (int t = 0; t < nt_out; t++)
-                        for (size_t j = 0; j < nl; j++)
-                            out->out[k][(size_t)t * N + idx[late[k0 + j]]] = patch[(size_t)t * nl + j];
-                }
-            }
-        }
+        HIP_TRY(hipMemcpyAsync(origin.data(), pool.origin.p, (size_t)n_pool * 8, hipMemcpyDeviceToHost, s), err, errlen);
+        patch.resize((size_t)std::max(n_out, 1) * nt_out * n_pool);
+        q = 0;
+        for (int k = 0; k < SPLASH_NOUT; k++)
+            if (out->out[k])
+                HIP_TRY(hipMemcpy2DAsync(patch.data() + (size_t)(q++) * nt_out * n_pool, (size_t)n_pool * 8, dout.out[k],
+                                         cap * 8, (size_t)n_pool * 8, (size_t)nt_out, hipMemcpyDeviceToHost, s),
+                        err, errlen);
         if (out->state_end) {
-            HIP_TRY(hipMemcpy(hsmall.data(), state, 5 * nb * 8, hipMemcpyDeviceToHost), err, errlen);
-            for (int k = 0; k < 5; k++)
-                for (size_t j = 0; j < nb; j++)
-                    out->state_end[(size_t)k * N + idx[j]] = hsmall[(size_t)k * nb + j];
+            pstate.resize((size_t)5 * n_pool);
+            HIP_TRY(hipMemcpy2DAsync(pstate.data(), (size_t)n_pool * 8, pool.state.p, cap * 8, (size_t)n_pool * 8, 5,
+                                     hipMemcpyDeviceToHost, s), err, errlen);
         }
         if (out->aux) {
-            HIP_TRY(hipMemcpy(hsmall.data(), Tt, nb * 8, hipMemcpyDeviceToHost), err, errlen);
-            HIP_TRY(hipMemcpy(hsmall.data() + nb, par + (size_t)15 * nb, nb * 8,
-                              hipMemcpyDeviceToHost), err, errlen);
-            HIP_TRY(hipMemcpy(hpass.data(), d_pass.p, 2 * nb * sizeof(int), hipMemcpyDeviceToHost),
-                    err, errlen);
-            for (size_t j = 0; j < nb; j++) {
-                out->aux[idx[j]] = hsmall[j];
-                out->aux[N + idx[j]] = hsmall[nb + j];
-                out->aux[2 * N + idx[j]] = hpass[j];
-                out->aux[3 * N + idx[j]] = hpass[nb + j];
+            paux.resize((size_t)n_pool);
+            ppass_h.resize((size_t)2 * n_pool);
+            HIP_TRY(hipMemcpyAsync(paux.data(), pool.par.as<double>() + (size_t)15 * cap, (size_t)n_pool * 8,
+                                   hipMemcpyDeviceToHost, s), err, errlen);
+            HIP_TRY(hipMemcpy2DAsync(ppass_h.data(), (size_t)n_pool * 4, pool.pass.p, cap * 4, (size_t)n_pool * 4, 2,
+                                     hipMemcpyDeviceToHost, s), err, errlen);
+        }
+        HIP_TRY(hipStreamSynchronize(s), err, errlen);
+    }
+    t_pool[0] = t1 - t0;
+    t_pool[1] = now_s() - t1;
+    return SPLASH_OK;
+}
+
+// after the lanes have delivered their blocks: the pool's cells overwrite their columns
+void Worker::patch_pool()
+{
+    if (!n_pool) return;
+    const double t0 = now_s();
+    const splash_grid_out* out = P.out;
+    const size_t N = P.N, np = n_pool;
+    const int nt_out = P.nt_out;
+    const size_t* idx = P.idx + v0;
+    const uint64_t* org = origin.data();
+    int q = 0;
+    for (int k = 0; k < SPLASH_NOUT; k++) {
+        if (!out->out[k]) continue;
+        const double* src = patch.data() + (size_t)(q++) * nt_out * np;
+        double* dst = out->out[k];
+        parallel_rows((size_t)nt_out, np * 16, [=](size_t t) {
+            for (size_t j = 0; j < np; j++) dst[t * N + idx[org[j]]] = src[t * np + j];
+        });
+    }
+    for (size_t j = 0; j < np; j++) {
+        const size_t c = idx[org[j]];
+        if (out->state_end)
+            for (int k = 0; k < 5; k++) out->state_end[(size_t)k * N + c] = pstate[(size_t)k * np + j];
+        if (out->aux) {
+            out->aux[N + c] = paux[j];
+            out->aux[2 * N + c] = ppass_h[j];
+            out->aux[3 * N + c] = ppass_h[np + j];
+        }
+    }
+    t_pool[2] = now_s() - t0;
+}
+
+// Valid cells [v0, v1) on `device`, in HBM-sized blocks dealt to the lanes.  `share` = workers using
+// this device (they split its free memory).  acc: this worker's host copy of the exact diagnostic
+// limbs (summed by the caller).
+int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, int64_t* acc,
+                char* err, size_t errlen)
+{
+    const splash_grid_in* in = P.in;
+    const int nt = P.nt, nt_out = P.nt_out, n_out = P.n_out;
+    HIP_TRY(hipSetDevice(device), err, errlen);
+    if (v1 <= v0) return SPLASH_OK;
+    Worker W(P, device, v0, v1);
+    if (int rc = splash_calendar_create(nt, in->doy, in->year, in->month, &W.cal, err, errlen)) return rc;
+    const bool f32 = W.f32;
+    const double t_w0 = now_s();
+    const size_t want = v1 - v0;
+    int n_lanes = 2;
+    if (const char* e = getenv("SPLASH_HIP_LANES")) n_lanes = std::max(1, std::min(4, atoi(e)));
+    const size_t acc_bytes = splash_dev_diag_acc_size(P.n_basin, P.nmonth);
+    {
+        // Sizing and allocation happen under the device's allocation lock: a second job on the same
+        // device (splash_grid_submit) plans with what this one has left.
+        std::lock_guard<std::recursive_mutex> alloc_lock(device_alloc_mutex(device));
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b), err, errlen);
+        free_b += pool_idle_bytes(device); // buffers kept from earlier calls are ours to reuse or release
+        // the straggler pool: room for 1/128 of the worker's cells (0.08 % of the synthetic grids' cells
+        // are stragglers); a block whose stragglers do not fit finishes them in place (late_fallback)
+        size_t pcap = std::min<size_t>(std::max<size_t>(want / 128, 16384), (size_t)1 << 18);
+        pcap = std::min(pcap, (want + 255) & ~(size_t)255);
+        pcap = (pcap + 255) & ~(size_t)255;
+        if (const char* e = getenv("SPLASH_HIP_POOL_CAP")) pcap = std::max<size_t>(1, (size_t)atol(e)); // tests: force the overflow path
+        const size_t pool_per_slot = (size_t)nt * 3 * 8 + (size_t)nt_out * std::max(n_out, 1) * 8 +
+                                     (SPLASH_NPAR + SPLASH_NSTATE + 1) * 8 + 8 + 2 * 4 + 4;
+        const double pool_bytes = (double)pcap * (double)pool_per_slot + (double)splash_dev_spin_up_work_size(pcap);
+        const size_t per_cell = (size_t)nt * 3 * 8 + (f32 ? (size_t)nt * 4 : 0) + (size_t)nt_out * std::max(n_out, 1) * 8 +
+                                (SPLASH_NPAR + SPLASH_NSTATE + 14 + 1) * 8 + 2 * 4 + 4 + 64;
+        const double frac = P.mem_fraction > 0 ? P.mem_fraction : 0.85;
+        const double budget = (double)free_b * frac / (double)std::max(share, 1) - pool_bytes - (double)acc_bytes;
+        // blocks: at least two per lane once a grid is big enough for the pipeline to pay
+        size_t nb_max = want;
+        if (want > ((size_t)1 << 20)) nb_max = std::max<size_t>((size_t)1 << 19, (want + 2 * n_lanes - 1) / (2 * n_lanes));
+        if (P.max_cells) nb_max = std::min(nb_max, P.max_cells);
+        auto lanes_for = [&](size_t nb) { return (int)std::min<size_t>((size_t)n_lanes, (want + nb - 1) / nb); };
+        auto need = [&](size_t nb) {
+            return (double)lanes_for(nb) * ((double)nb * (double)per_cell + (double)splash_dev_spin_up_work_size(nb));
+        };
+        if (need(nb_max) > budget) { // largest block that fits (bisection; need() grows with nb once the
+            size_t lo = 0, hi = nb_max;  // lane count has reached its cap, which it has wherever it matters)
+            while (hi - lo > 256) {
+                const size_t mid = lo + (hi - lo) / 2;
+                if (need(mid) > budget) hi = mid; else lo = mid;
+            }
+            nb_max = lo;
+        }
+        if (nb_max == 0) return fail(SPLASH_ENOMEM, err, errlen, "grid_run: not enough device memory");
+        nb_max = std::min(nb_max, kMaxCellsPerLaunch);
+        if (nb_max > 256) nb_max -= nb_max % 256;
+        W.nb_max = nb_max;
+        n_lanes = lanes_for(nb_max);
+        W.lanes = std::vector<Lane>(n_lanes);
+
+        Pool& pl = W.pool;
+        pl.cap = pcap;
+        HIP_TRY(pl.force.alloc((size_t)nt * 3 * pcap * 8), err, errlen);
+        HIP_TRY(pl.par.alloc((size_t)SPLASH_NPAR * pcap * 8), err, errlen);
+        HIP_TRY(pl.state.alloc((size_t)SPLASH_NSTATE * pcap * 8), err, errlen);
+        HIP_TRY(pl.tt.alloc(pcap * 8), err, errlen);
+        HIP_TRY(pl.origin.alloc(pcap * 8), err, errlen);
+        HIP_TRY(pl.pass.alloc(2 * pcap * sizeof(int)), err, errlen);
+        HIP_TRY(pl.basin.alloc(pcap * sizeof(int32_t)), err, errlen);
+        HIP_TRY(pl.work.alloc(splash_dev_spin_up_work_size(pcap)), err, errlen);
+        HIP_TRY(pl.out.alloc((size_t)nt_out * std::max(n_out, 1) * pcap * 8), err, errlen);
+        {   // the pool's counters start at zero (what phase 0 does for a block's workspace)
+            size_t p_cnt;
+            spin_work_layout(pcap, nullptr, nullptr, nullptr, &p_cnt);
+            HIP_TRY(hipMemset((char*)pl.work.p + p_cnt, 0, 64), err, errlen);
+        }
+        if (P.want_diag) {
+            HIP_TRY(W.d_acc.alloc(acc_bytes), err, errlen);
+            HIP_TRY(hipMemset(W.d_acc.p, 0, acc_bytes), err, errlen);
+        }
+        for (Lane& L : W.lanes) {
+            HIP_TRY(L.st.create(), err, errlen);
+            HIP_TRY(L.ev_gather.create(), err, errlen);
+            HIP_TRY(L.d_force.alloc((size_t)nt * 3 * nb_max * 8), err, errlen);
+            if (f32) HIP_TRY(L.d_f32.alloc((size_t)nt * nb_max * 4), err, errlen);
+            HIP_TRY(L.d_out.alloc((size_t)nt_out * std::max(n_out, 1) * nb_max * 8), err, errlen);
+            HIP_TRY(L.d_par.alloc((size_t)SPLASH_NPAR * nb_max * 8), err, errlen);
+            HIP_TRY(L.d_state.alloc((size_t)SPLASH_NSTATE * nb_max * 8), err, errlen);
+            HIP_TRY(L.d_stat.alloc((size_t)14 * nb_max * 8), err, errlen);
+            HIP_TRY(L.d_tt.alloc(nb_max * 8), err, errlen);
+            HIP_TRY(L.d_pass.alloc(2 * nb_max * sizeof(int)), err, errlen);
+            HIP_TRY(L.d_swork.alloc(splash_dev_spin_up_work_size(nb_max)), err, errlen);
+            HIP_TRY(L.d_res.alloc(64), err, errlen);
+            if (P.want_diag && in->basin) HIP_TRY(L.d_basin.alloc(nb_max * sizeof(int32_t)), err, errlen);
+            L.hstat.resize((size_t)14 * nb_max);
+            L.hsmall.resize(5 * nb_max);
+            L.hpass.resize(2 * nb_max);
+            if (in->basin && P.want_diag) L.hbasin.resize(nb_max);
+            if (!P.dense) {
+                L.stage.resize((size_t)std::max(f32 ? 0 : nt, nt_out) * nb_max);
+                if (f32) L.stage32.resize((size_t)nt * nb_max);
             }
         }
-        if (trace)
-            fprintf(stderr, "[splash] device %d block %zu cells: host->device %.3f s, queue+prefault %.3f s, "
-                            "main kernels (rest) %.3f s, device->host %.3f s, tail (rest) %.3f s, %u late cells + "
-                            "small copies %.3f s\n",
-                    device, nb, t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e, n_late, now() - t_f);
     }
-    if (P.want_diag)
-        HIP_TRY(hipMemcpy(acc, d_acc.p, acc_bytes, hipMemcpyDeviceToHost), err, errlen);
+    if (W.trace)
+        fprintf(stderr, "[splash] device %d: %zu cells in %zu blocks of <= %zu on %zu lanes, pool of %zu slots; calendar + "
+                        "allocations %.3f s\n", device, want, W.nblocks(), W.nb_max, W.lanes.size(), W.pool.cap, now_s() - t_w0);
+
+    std::vector<std::thread> threads;
+    for (size_t l = 0; l < W.lanes.size(); l++) threads.emplace_back([&W, l] { W.run_lane((int)l); });
+    const int rc_pool = W.finish_pool(err, errlen); // waits for the lanes' last gathers, then runs the tail
+    for (auto& t : threads) t.join();
+    for (Lane& L : W.lanes)
+        if (L.rc) return fail(L.rc, err, errlen, "%s", L.msg);
+    if (rc_pool) return rc_pool;
+    W.patch_pool();
+    if (W.trace)
+        fprintf(stderr, "[splash] device %d: %u stragglers in the pool: waited %.3f s for the last block's early phases, "
+                        "tail + their transient run + copy %.3f s, patch %.3f s\n", device, W.n_pool, W.t_pool[0],
+                W.t_pool[1], W.t_pool[2]);
+    if (P.want_diag) HIP_TRY(hipMemcpy(acc, W.d_acc.p, acc_bytes, hipMemcpyDeviceToHost), err, errlen);
     return SPLASH_OK;
 }
 
@@ -1249,6 +1620,7 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
     P.nt = in->nt;
     P.monthly = opt ? opt->monthly_out : 0;
     P.max_cells = opt ? opt->max_cells_per_launch : 0;
+    P.mem_fraction = (opt && opt->mem_fraction > 0 && opt->mem_fraction <= 1) ? opt->mem_fraction : 0.0;
     P.n_basin = in->basin ? in->n_basin : 1;
     P.want_diag = out->diag || out->diag_acc;
     // month count without touching a device: same rule as splash_calendar_create
@@ -1338,6 +1710,53 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
                 t_end - t_scan, t_end - t_enter);
     }
     return SPLASH_OK;
+}
+
+struct splash_grid_job {
+    splash_grid_in in;
+    splash_opts opt;
+    splash_grid_out out;
+    std::vector<int> devices;
+    bool has_opt = false;
+    std::thread th;
+    int rc = SPLASH_OK;
+    char msg[512] = "";
+};
+
+extern "C" int splash_grid_submit(const splash_grid_in* in, const splash_opts* opt, const splash_grid_out* out,
+                                  splash_grid_job** job, char* err, size_t errlen)
+{
+    if (!in || !out || !job) return fail(SPLASH_EINVAL, err, errlen, "grid_submit: NULL in/out/job");
+    if (int rc = need_device(err, errlen)) return rc;
+    auto* j = new splash_grid_job;
+    j->in = *in;
+    j->out = *out;
+    if (opt) {
+        j->opt = *opt;
+        j->has_opt = true;
+        if (opt->devices && opt->n_devices > 0) { // the list is copied: the caller's may be a temporary
+            j->devices.assign(opt->devices, opt->devices + opt->n_devices);
+            j->opt.devices = j->devices.data();
+        }
+    }
+    try {
+        j->th = std::thread([j] { j->rc = splash_grid_run(&j->in, j->has_opt ? &j->opt : nullptr, &j->out, j->msg, sizeof j->msg); });
+    } catch (...) {
+        delete j;
+        return fail(SPLASH_ENOMEM, err, errlen, "grid_submit: could not start a host thread");
+    }
+    *job = j;
+    return SPLASH_OK;
+}
+
+extern "C" int splash_grid_wait(splash_grid_job* job, char* err, size_t errlen)
+{
+    if (!job) return fail(SPLASH_EINVAL, err, errlen, "grid_wait: NULL job");
+    if (job->th.joinable()) job->th.join();
+    const int rc = job->rc;
+    if (rc) (void)fail(rc, err, errlen, "%s", job->msg);
+    delete job;
+    return rc;
 }
 
 extern "C" int splash_point_run(int nt, const int* doy, const int* year, const int* month,

@@ -551,6 +551,52 @@ __global__ __launch_bounds__(64) void k_spin_up_mod(SpinArgs a, double* const* s
     if (a.passes) a.passes[0] = count;
 }
 
+// ================================================================ straggler pool ===============
+// One workgroup reserves the block's slots in the pool; then one workgroup per job copies its columns.
+__global__ __launch_bounds__(64) void k_pool_reserve(PoolGatherArgs a)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t n = *a.n_cells;
+    const uint32_t base = atomicAdd(a.p_n, n);
+    // all or nothing: a block whose stragglers do not all fit keeps them (the caller finishes them in
+    // place).  A reservation that overflows leaves the counter above the capacity until it is taken
+    // back, so nothing reserved in between can fit either: the slots handed out stay contiguous.
+    const uint32_t fit = ((size_t)base + n <= a.cap) ? n : 0;
+    if (fit < n) atomicSub(a.p_n, n);
+    a.res[0] = base;
+    a.res[1] = fit;
+    a.res[2] = n;
+}
+
+__global__ __launch_bounds__(kBlock) void k_pool_gather(PoolGatherArgs a)
+{
+    const uint32_t fit = a.res[1], base = a.res[0];
+    for (uint32_t j = blockIdx.x; j < fit; j += gridDim.x) {
+        const size_t c = a.cells[j], slot = (size_t)base + j;
+        for (int t = threadIdx.x; t < a.nt; t += kBlock) {
+            const size_t k = (size_t)t * a.ldf + c, q = (size_t)t * a.cap + slot;
+            a.p_sw[q] = a.sw[k];
+            a.p_tc[q] = a.tc[k];
+            a.p_pn[q] = a.pn[k];
+        }
+        if (threadIdx.x < P_NPAR) a.p_par[(size_t)threadIdx.x * a.cap + slot] = a.par[(size_t)threadIdx.x * a.ldp + c];
+        if (threadIdx.x >= 32 && threadIdx.x < 37)
+            a.p_state[(size_t)(threadIdx.x - 32) * a.cap + slot] = a.state[(size_t)(threadIdx.x - 32) * a.lds + c];
+        if (threadIdx.x == 64) {
+            a.p_Tt[slot] = a.Tt[c];
+            a.p_meta[slot] = a.meta[c];
+            a.p_ai[slot] = a.ai[c];
+            a.p_origin[slot] = a.origin0 + c;
+            a.p_wl[slot] = (uint32_t)slot;
+            if (a.p_passes) {
+                a.p_passes[slot] = a.passes ? a.passes[c] : 0;
+                a.p_passes[a.cap + slot] = a.passes ? a.passes[a.ntotal + c] : 0;
+            }
+            if (a.p_basin) a.p_basin[slot] = a.basin ? a.basin[c] : 0;
+        }
+    }
+}
+
 // ================================================================ K5 run_all ===================
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -1565,6 +1611,13 @@ hipError_t launch_spin_phase(const SpinPhaseArgs& a, hipStream_t s)
         hipLaunchKernelGGL(k_spin_phase<true>, dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
     else
         hipLaunchKernelGGL(k_spin_phase<false>, dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool_gather(const PoolGatherArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pool_reserve, dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_pool_gather, dim3(2048), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

@@ -114,6 +114,45 @@ struct RunArgs {
     const unsigned char* skip;
 };
 
+// Straggler pool of the host-buffer pipeline (splash_capi.hip): the jobs a block's spin-up left for
+// its tail phase are copied -- forcing columns, parameters, threshold, parked state, job record -- to
+// compact arrays shared by all blocks of the call, so that the block's buffers can be reused at
+// once and the tail runs ONCE per call, over all blocks' stragglers together.
+struct PoolGatherArgs {
+    // the block (source)
+    const uint32_t* cells;   // worklist of the block's pending jobs (cell ids in the block)
+    const uint32_t* n_cells; // its device-side length
+    int nt;
+    const double *sw, *tc, *pn; // [nt][ldf]
+    size_t ldf;
+    const double* par;       // [P_NPAR][ldp]
+    size_t ldp;
+    const double* state;     // [5][lds]
+    size_t lds;
+    const double* Tt;
+    const int* meta;
+    const double* ai;
+    const int* passes;       // [2][ntotal] or NULL
+    size_t ntotal;
+    const int* basin;        // or NULL
+    uint64_t origin0;        // position of the block's cell 0 in the worker's list of valid cells
+    // the pool (destination), capacity cap; slot = *res_base + j
+    size_t cap;
+    double *p_sw, *p_tc, *p_pn; // [nt][cap]
+    double* p_par;           // [P_NPAR][cap]
+    double* p_state;         // [5][cap]
+    double* p_Tt;
+    int* p_meta;
+    double* p_ai;
+    int* p_passes;           // [2][cap] or NULL
+    int* p_basin;            // or NULL
+    uint64_t* p_origin;
+    uint32_t* p_wl;          // worklist of the pool's tail phase: identity
+    uint32_t* p_n;           // jobs in the pool (atomic counter; the tail phase's input count)
+    uint32_t* res;           // [3] per block, written by the reservation: base slot, jobs that fit, jobs of the block
+};
+hipError_t launch_pool_gather(const PoolGatherArgs& a, hipStream_t s);
+
 hipError_t launch_soil_hydro(size_t ncell, const double* lat, const double* elev,
                              const double* slop, const double* asp, const double* resolution,
                              const double* soil, const double* au, double* par, hipStream_t s);

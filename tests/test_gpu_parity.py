@@ -1320,3 +1320,68 @@ def test_overlapped_spin_up_gives_the_same_bits(api, oracle):
     assert torch.equal(a_state.view(torch.int64), b_state.view(torch.int64))
     assert torch.equal(a_acc, b_acc) and torch.equal(a_par.view(torch.int64), b_par.view(torch.int64))
     cal.close()
+
+
+@pytest.mark.gpu
+def test_host_path_pipeline_lanes_pool_and_jobs_give_the_same_bits(api, oracle):
+    """splash_grid_run pipelines its blocks over two lanes (host thread + stream + buffers each) and
+    finishes the stragglers of ALL blocks once, from a pool (splash_capi.hip).  Whatever the blocking,
+    the number of lanes, a pool too small for a block's stragglers (they are then finished in place),
+    a masked grid, or two calls in flight at once (splash_grid_submit/_wait): the same bits as the
+    one-block call -- results, end state, aridity index, pass counts and the exact totals."""
+    import os
+    H, W, nt = 48, 128, 400
+    n = H * W
+    doy, year, month, mid, nm = oracle.calendar(2001, nt)
+    st = oracle.synth_statics(777000, H, W, 0, n, 1)
+    sw, tc, pn = oracle.synth_forcing(777000, H, W, 0, n, 0, doy, st["lat"], st["elev"])
+    dates = np.datetime64("2001-01-01") + np.arange(nt)
+    basin = (np.arange(n) // (n // 5)).astype(np.int32).clip(0, 4)
+
+    def call(elev=None, **kw):
+        return api.splash_grid(sw, tc, pn, st["elev"] if elev is None else elev, st["soil"], st["lat"], st["slop"],
+                               st["asp"], st["au"], st["resolution"], time_index=dates,
+                               sim_control=dict(monthly_out=False), want_aux=True, want_diag=True,
+                               basin=basin, n_basin=5, **kw)
+
+    def same(a, b, what):
+        for k in ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "sm_lim", "state_end"):
+            assert np.array_equal(a[k].view(np.int64), b[k].view(np.int64)), (what, k)
+        for k in ("Tt", "AI", "passes1", "passes2"):
+            assert np.array_equal(a["aux"][k].view(np.int64), b["aux"][k].view(np.int64)), (what, k)
+        assert np.array_equal(a["diag_acc"], b["diag_acc"]), what
+
+    ref = call()
+    n_late = int((ref["aux"]["passes2"] > 28).sum())   # jobs the first seven phases (28 passes) leave
+    assert n_late >= 3, n_late
+    env0 = {k: os.environ.get(k) for k in ("SPLASH_HIP_LANES", "SPLASH_HIP_POOL_CAP")}
+    try:
+        same(ref, call(max_cells_per_launch=1024), "6 blocks on 2 lanes")
+        os.environ["SPLASH_HIP_LANES"] = "1"
+        same(ref, call(max_cells_per_launch=1024), "6 blocks on 1 lane")
+        os.environ["SPLASH_HIP_LANES"] = "3"
+        same(ref, call(max_cells_per_launch=700), "9 ragged blocks on 3 lanes")
+        os.environ["SPLASH_HIP_LANES"] = "2"
+        os.environ["SPLASH_HIP_POOL_CAP"] = "2"       # fewer slots than stragglers: the fallback path
+        same(ref, call(max_cells_per_launch=1024), "pool overflow")
+        same(ref, call(), "pool overflow, one block")
+        os.environ.pop("SPLASH_HIP_POOL_CAP")
+        # two calls in flight on the same device, each with its share of the memory
+        j1 = call(max_cells_per_launch=2048, submit=True, mem_fraction=0.4)
+        j2 = call(max_cells_per_launch=1500, submit=True, mem_fraction=0.4)
+        same(ref, j2.wait(), "second job in flight")
+        same(ref, j1.wait(), "first job in flight")
+        # a masked grid (NA cells are compacted on the host by several threads): valid cells unchanged
+        elev = st["elev"].copy()
+        elev[::7] = np.nan
+        m = call(elev=elev, max_cells_per_launch=900)
+        ok = ~np.isnan(elev)
+        for k in ("wn", "ro", "aet", "snow", "sm_lim"):
+            assert np.array_equal(m[k][:, ok].view(np.int64), ref[k][:, ok].view(np.int64)), k
+            assert np.isnan(m[k][:, ~ok]).all(), k
+    finally:
+        for k, v in env0.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

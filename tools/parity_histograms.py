@@ -44,11 +44,14 @@ def main():
     a = ap.parse_args()
     o = Oracle()
     L = ["# Error histograms of the HIP path against the oracle -- `tools/parity_histograms.py`", "",
-         "Counts of cell-days by decade of |x - ref|/|ref| over ALL cell-days (nothing set aside); `bit-equal` "
-         "includes matching NaN and 0 == 0; `ref=0` = cell-days whose reference value is exactly 0 (not in the "
-         "decades), of which `|x|>1e-12` have a product value beyond 1e-12; `only atol 1e-9` = pass the tolerance "
-         "1e-5|ref| + 1e-9 but not 1e-5|ref| + 1e-12; `only floor` = pass only through the series' floor "
-         "(aet: 1e-7 pet, ro: 1e-10 wn).", ""]
+         "Counts of cell-days over ALL cell-days (nothing set aside): `bit-equal` (includes matching NaN and "
+         "0 == 0), `|d|<=1e-12` (a non-zero difference below the survey's absolute tolerance for exact zeros: "
+         "transmittances of 1e-30 mm/day live here), then the rest by decade of |x - ref|/|ref|.  `beyond r` = "
+         "|x - ref| > r|ref| + 1e-12 (the levels `assert_bulk` holds); `ref=0` = cell-days whose reference value "
+         "is exactly 0, of which `|x|>1e-12` have a product value beyond 1e-12; `only atol 1e-9` = pass the "
+         "tolerance 1e-5|ref| + 1e-9 but not 1e-5|ref| + 1e-12; `only floor` = pass only through the series' "
+         "floor (aet: 1e-7 pet, ro: 1e-10 wn); `out of tol.` = fail 1e-5|ref| + 1e-9 + floor (cells set aside by "
+         "the tests are INCLUDED here).", ""]
     one, tra = {}, {}
     for case, (seed, Htot, W, cell0, n, nt, terrain, start) in CASES.items():
         p = device_pipeline(api, seed, Htot, W, cell0, n, nt, terrain, start=start)
