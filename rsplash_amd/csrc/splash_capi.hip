@@ -1005,8 +1005,10 @@ struct Pool {
 // overlap (the SOCK cluster of R/splash.grid.R:359-400 overlapped its workers the same way).
 struct Lane {
     DevBuf d_force, d_f32, d_out, d_par, d_state, d_stat, d_tt, d_pass, d_swork, d_basin, d_res, d_late;
-    std::vector<double> stage, hstat, hsmall;
+    std::vector<double> stage, stage_out, hstat, hsmall;
     std::vector<float> stage32;
+    std::thread d2h;      // delivers the previous block's results while the lane loads the next one
+    int d2h_rc = SPLASH_OK;
     std::vector<int> hpass;
     std::vector<int32_t> hbasin;
     int rc = SPLASH_OK;
@@ -1026,7 +1028,10 @@ struct Worker {
     std::vector<Lane> lanes;
     std::mutex mu;
     std::condition_variable cv;
-    int lanes_gathered = 0;     // lanes whose last block's gather is enqueued (or that gave up)
+    size_t next_block = 0;      // blocks are handed out in order, one host->device load at a time
+    bool loading = false;
+    size_t blocks_gathered = 0; // blocks whose early phases and gather are enqueued
+    int lanes_done = 0;
     std::atomic<bool> abort{false};
     std::atomic<bool> prefaulted{false};
     bool trace;
@@ -1052,14 +1057,15 @@ struct Worker {
         abort = true;
         return code;
     }
-    void lane_gathered()
+    void note(size_t& counter_or_null, bool lane_exit)
     {
         std::lock_guard<std::mutex> lk(mu);
-        lanes_gathered++;
+        if (lane_exit) lanes_done++; else counter_or_null++;
         cv.notify_all();
     }
     int run_lane(int li);
-    int run_block(Lane& L, size_t k, bool last_of_lane, bool& signalled);
+    int run_block(Lane& L, size_t k);
+    int deliver(Lane& L, size_t b0, size_t nb, splash_dev_out dout);
     int late_fallback(Lane& L, size_t b0, size_t nb, const splash_dev_out& dout, uint32_t n_late);
     int finish_pool(char* err, size_t errlen);
     void patch_pool();
@@ -1080,23 +1086,38 @@ struct Worker {
 int Worker::run_lane(int li)
 {
     Lane& L = lanes[li];
-    bool signalled = false;
     if (hipSetDevice(device) != hipSuccess) {
         lane_fail(L, SPLASH_ENODEV, "hipSetDevice", hipErrorInvalidDevice);
     } else {
-        const size_t nblk = nblocks(), nl = lanes.size();
-        size_t last = nblk; // this lane's last block
-        for (size_t k = li; k < nblk; k += nl) last = k;
-        for (size_t k = li; k < nblk && !abort; k += nl)
-            if (run_block(L, k, k == last, signalled)) break;
+        const size_t nblk = nblocks();
+        for (;;) {
+            size_t k;
+            {   // the next block, once nobody else is loading: host->device copies of two lanes at once
+                // only share the link (measured: 52 GB/s for one or for two), and lanes that load in
+                // lockstep compute in lockstep -- one at a time, copies and kernels interleave
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !loading || abort; });
+                if (abort || next_block >= nblk) break;
+                k = next_block++;
+                loading = true;
+            }
+            if (run_block(L, k)) break;
+        }
+        if (L.d2h.joinable()) L.d2h.join();
+        if (L.d2h_rc && !L.rc) L.rc = L.d2h_rc;
     }
-    if (!signalled) lane_gathered();
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        loading = false; // (a lane that failed while loading)
+    }
+    size_t dummy = 0;
+    note(dummy, true);
     return L.rc;
 }
 
 // Valid cells [b0, b0+nb) of the worker's range: what clFun does for a row block
 // (R/splash.grid.R:277-308).
-int Worker::run_block(Lane& L, size_t k, bool last_of_lane, bool& signalled)
+int Worker::run_block(Lane& L, size_t k)
 {
     const splash_grid_in* in = P.in;
     const splash_grid_out* out = P.out;
@@ -1163,6 +1184,11 @@ int Worker::run_block(Lane& L, size_t k, bool last_of_lane, bool& signalled)
         for (size_t j = 0; j < nb; j++) L.hbasin[j] = in->basin[idx[j]];
         LANE_TRY(hipMemcpyAsync(L.d_basin.p, L.hbasin.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice, s));
     }
+    {   // the copies have left the host buffers: the next lane may load
+        std::lock_guard<std::mutex> lk(mu);
+        loading = false;
+        cv.notify_all();
+    }
     const double t_b = now_s();
 
     // ---- kernels
@@ -1216,10 +1242,10 @@ int Worker::run_block(Lane& L, size_t k, bool last_of_lane, bool& signalled)
         LANE_TRY(launch_pool_gather(g, s));
         LANE_TRY(hipEventRecord(L.ev_gather.e, s));
     }
-    if (last_of_lane) { // the worker's thread may start the tail once every lane is here
-        lane_gathered();
-        signalled = true;
-    }
+    note(blocks_gathered, false); // the worker's thread starts the tail once every block is here
+    // the previous block's results must have left d_out before run_all writes it again
+    if (L.d2h.joinable()) L.d2h.join();
+    if (L.d2h_rc) return lane_fail(L, L.d2h_rc, "device->host copy of the previous block", hipSuccess);
     splash_dev_out dout{};
     int q = 0;
     for (int kk = 0; kk < SPLASH_NOUT; kk++)
@@ -1242,25 +1268,10 @@ int Worker::run_block(Lane& L, size_t k, bool last_of_lane, bool& signalled)
     LANE_TRY(hipStreamSynchronize(s));
     const double t_d = now_s();
 
-    // ---- device -> host
+    // ---- device -> host: the small arrays now (the next block overwrites them), the result series
+    // by a helper thread while this lane loads its next block
     uint32_t res[3] = {0, 0, 0};
     LANE_TRY(hipMemcpy(res, L.d_res.p, sizeof res, hipMemcpyDeviceToHost));
-    for (int kk = 0; kk < SPLASH_NOUT; kk++) {
-        if (!out->out[kk]) continue;
-        if (P.dense) {
-            LANE_TRY(hipMemcpy2D(out->out[kk] + c0, N * 8, dout.out[kk], nb * 8, nb * 8, (size_t)nt_out,
-                                 hipMemcpyDeviceToHost));
-        } else {
-            double* stg = L.stage.data();
-            LANE_TRY(hipMemcpy(stg, dout.out[kk], (size_t)nt_out * nb * 8, hipMemcpyDeviceToHost));
-            double* dsth = out->out[kk];
-            parallel_rows((size_t)nt_out, nb * 8, [=](size_t t) {
-                const double* src = stg + t * nb;
-                double* dst = dsth + t * N;
-                for (size_t j = 0; j < nb; j++) dst[idx[j]] = src[j];
-            });
-        }
-    }
     if (out->state_end) {
         LANE_TRY(hipMemcpy(L.hsmall.data(), state, 5 * nb * 8, hipMemcpyDeviceToHost));
         for (int kk = 0; kk < 5; kk++)
@@ -1277,14 +1288,57 @@ int Worker::run_block(Lane& L, size_t k, bool last_of_lane, bool& signalled)
             out->aux[3 * N + idx[j]] = L.hpass[nb + j];
         }
     }
+    const bool in_place = res[1] < res[2]; // the pool cannot take this block's stragglers
+    if (in_place) {
+        if (int rc = deliver(L, b0, nb, dout)) return lane_fail(L, rc, "device->host copy", hipSuccess);
+    } else {
+        L.d2h_rc = SPLASH_OK;
+        L.d2h = std::thread([this, &L, b0, nb, dout] {
+            (void)hipSetDevice(device);
+            L.d2h_rc = deliver(L, b0, nb, dout);
+        });
+    }
     const double t_e = now_s();
-    if (res[1] < res[2]) // the pool cannot take this block's stragglers: they are finished here, the old way
+    if (in_place) // ... they are finished here, the old way (after the block's own results are out)
         if (int rc = late_fallback(L, b0, nb, dout, res[2])) return rc;
     if (trace)
         fprintf(stderr, "[splash] device %d block %zu (%zu cells): host->device %.3f s, queue+prefault %.3f s, "
-                        "kernels (rest) %.3f s, device->host %.3f s, %u stragglers (%u to the pool)%s %.3f s\n",
+                        "kernels (rest) %.3f s, small copies %.3f s (results follow in the background), %u stragglers "
+                        "(%u to the pool)%s %.3f s\n",
                 device, k, nb, t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, res[2], res[1],
-                res[1] < res[2] ? ", finished in place" : "", now_s() - t_e);
+                in_place ? ", finished in place" : "", now_s() - t_e);
+    return SPLASH_OK;
+}
+
+// the result series of a block: device -> the caller's arrays
+int Worker::deliver(Lane& L, size_t b0, size_t nb, splash_dev_out dout)
+{
+    const splash_grid_out* out = P.out;
+    const size_t N = P.N;
+    const int nt_out = P.nt_out;
+    const size_t* idx = P.idx + b0;
+    const size_t c0 = idx[0];
+    const double t0 = now_s();
+    for (int kk = 0; kk < SPLASH_NOUT; kk++) {
+        if (!out->out[kk]) continue;
+        hipError_t e;
+        if (P.dense) {
+            e = hipMemcpy2D(out->out[kk] + c0, N * 8, dout.out[kk], nb * 8, nb * 8, (size_t)nt_out, hipMemcpyDeviceToHost);
+        } else {
+            double* stg = L.stage_out.data();
+            e = hipMemcpy(stg, dout.out[kk], (size_t)nt_out * nb * 8, hipMemcpyDeviceToHost);
+            double* dsth = out->out[kk];
+            if (e == hipSuccess)
+                parallel_rows((size_t)nt_out, nb * 8, [=](size_t t) {
+                    const double* src = stg + t * nb;
+                    double* dst = dsth + t * N;
+                    for (size_t j = 0; j < nb; j++) dst[idx[j]] = src[j];
+                });
+        }
+        if (e != hipSuccess) return SPLASH_EHIP;
+    }
+    if (trace)
+        fprintf(stderr, "[splash] device %d: results of block at valid cell %zu delivered in %.3f s\n", device, b0, now_s() - t0);
     return SPLASH_OK;
 }
 
@@ -1361,7 +1415,7 @@ int Worker::finish_pool(char* err, size_t errlen)
     hipStream_t s = st.s;
     {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return lanes_gathered == (int)lanes.size(); });
+        cv.wait(lk, [&] { return blocks_gathered == nblocks() || lanes_done == (int)lanes.size(); });
     }
     if (abort) return SPLASH_OK; // the lanes report their own failure
     const double t0 = now_s();
@@ -1491,9 +1545,10 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
                                 (SPLASH_NPAR + SPLASH_NSTATE + 14 + 1) * 8 + 2 * 4 + 4 + 64;
         const double frac = P.mem_fraction > 0 ? P.mem_fraction : 0.85;
         const double budget = (double)free_b * frac / (double)std::max(share, 1) - pool_bytes - (double)acc_bytes;
-        // blocks: at least two per lane once a grid is big enough for the pipeline to pay
+        // blocks: four per lane once a grid is big enough for the pipeline to pay, of a million cells at
+        // least (a block's later spin-up phases are short worklists, i.e. latency: ~30 ms per block)
         size_t nb_max = want;
-        if (want > ((size_t)1 << 20)) nb_max = std::max<size_t>((size_t)1 << 19, (want + 2 * n_lanes - 1) / (2 * n_lanes));
+        if (want > ((size_t)1 << 20)) nb_max = std::max<size_t>((size_t)1 << 20, (want + 4 * n_lanes - 1) / (4 * n_lanes));
         if (P.max_cells) nb_max = std::min(nb_max, P.max_cells);
         auto lanes_for = [&](size_t nb) { return (int)std::min<size_t>((size_t)n_lanes, (want + nb - 1) / nb); };
         auto need = [&](size_t nb) {
@@ -1553,7 +1608,8 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
             L.hpass.resize(2 * nb_max);
             if (in->basin && P.want_diag) L.hbasin.resize(nb_max);
             if (!P.dense) {
-                L.stage.resize((size_t)std::max(f32 ? 0 : nt, nt_out) * nb_max);
+                if (!f32) L.stage.resize((size_t)nt * nb_max);
+                L.stage_out.resize((size_t)nt_out * nb_max);
                 if (f32) L.stage32.resize((size_t)nt * nb_max);
             }
         }

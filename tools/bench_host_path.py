@@ -1,13 +1,16 @@
 """PCIe-inclusive rate of the host-buffer entry point (splash_grid_run): the whole splash.grid block
 call -- NA scan, H2D forcing, soil_hydro, snow threshold, both spin-ups, run_all, D2H outputs --
 on a synthetic terrain grid held in host memory.  Not the bench metric (bench.py keeps rasters
-resident); recorded in DESIGN.md.
+resident); recorded in DESIGN.md and profiles/.
 
-    python tools/bench_host_path.py [rows] [cols] [daily|monthly] [n_outputs] [f64|f32]
+    python tools/bench_host_path.py [rows] [cols] [daily|monthly] [n_outputs] [f64|f32] [reps] [cells per block]
 
 The output arrays are allocated and touched once before the timed calls (what the caller of a C ABI
 does: R's allocMatrix, or a reused buffer); f32 hands the forcing over in single precision (the
 reference's rasters are FLT4S), which halves the host->device bytes and changes no result.
+The grid is generated on the device in row chunks and copied to the host arrays chunk by chunk, so
+that the full 4096 x 4096 x 365 grid (73 GB of f32 forcing) fits the box's host memory.
+SPLASH_TRACE=1 prints the stage times of every block; SPLASH_HIP_LANES sets the pipeline's lanes.
 """
 import json
 import os
@@ -25,39 +28,58 @@ W = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 monthly = len(sys.argv) > 3 and sys.argv[3] == "monthly"
 nout = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 f32 = len(sys.argv) > 5 and sys.argv[5] == "f32"
+reps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+max_cells = int(sys.argv[7]) if len(sys.argv) > 7 else 0  # cells per block (0: the library's choice)
 n, nt, SEED = H * W, 365, 20221130
 dev = torch.device("cuda:0")
 f64 = dict(dtype=torch.float64, device=dev)
 time_index = np.arange("2001-01-01", "2002-01-01", dtype="datetime64[D]")
 doy, year, month = api.time_fields(time_index)
 cal = api.Calendar(doy, year, month)
-lat, elev, slop, asp, res = (torch.empty(n, **f64) for _ in range(5))
-soil, au = torch.empty(6, n, **f64), torch.empty(3, n, **f64)
-api.dev_synth_statics(SEED, H, W, 0, n, 1, lat, elev, slop, asp, res, soil, au)
-sw, tc, pn = (torch.empty(nt, n, **f64) for _ in range(3))
-api.dev_synth_forcing(SEED, cal, 0, nt, 0, n, lat, elev, sw, tc, pn, n)
-torch.cuda.synchronize()
-host = {k: v.cpu().numpy() for k, v in dict(lat=lat, elev=elev, slop=slop, asp=asp, res=res, soil=soil,
-                                            au=au, sw=sw, tc=tc, pn=pn).items()}
-del lat, elev, slop, asp, res, soil, au, sw, tc, pn
+fdt = np.float32 if f32 else np.float64
+t_gen = time.perf_counter()
+host = dict(lat=np.empty(n), elev=np.empty(n), slop=np.empty(n), asp=np.empty(n), res=np.empty(n),
+            soil=np.empty((6, n)), au=np.empty((3, n)),
+            sw=np.empty((nt, n), fdt), tc=np.empty((nt, n), fdt), pn=np.empty((nt, n), fdt))
+rows_chunk = max(1, min(H, (1 << 21) // W))
+for r0 in range(0, H, rows_chunk):
+    nr = min(rows_chunk, H - r0)
+    nc, c0 = nr * W, r0 * W
+    lat, elev, slop, asp, res = (torch.empty(nc, **f64) for _ in range(5))
+    soil, au = torch.empty(6, nc, **f64), torch.empty(3, nc, **f64)
+    api.dev_synth_statics(SEED, H, W, c0, nc, 1, lat, elev, slop, asp, res, soil, au)
+    sw, tc, pn = (torch.empty(nt, nc, **f64) for _ in range(3))
+    api.dev_synth_forcing(SEED, cal, 0, nt, c0, nc, lat, elev, sw, tc, pn, nc)
+    torch.cuda.synchronize()
+    for k, v in dict(lat=lat, elev=elev, slop=slop, asp=asp, res=res).items():
+        host[k][c0:c0 + nc] = v.cpu().numpy()
+    host["soil"][:, c0:c0 + nc] = soil.cpu().numpy()
+    host["au"][:, c0:c0 + nc] = au.cpu().numpy()
+    for k, v in dict(sw=sw, tc=tc, pn=pn).items():
+        host[k][:, c0:c0 + nc] = (v.float() if f32 else v).cpu().numpy()
+    del lat, elev, slop, asp, res, soil, au, sw, tc, pn
 torch.cuda.empty_cache()
+print(f"grid generated and copied to the host in {time.perf_counter() - t_gen:.1f} s", file=sys.stderr, flush=True)
 names = ("wn", "snow", "ro", "aet", "pet", "cond", "bflow", "netr", "sm_lim")[:nout]
-if f32:
-    for k in ("sw", "tc", "pn"):
-        host[k] = host[k].astype(np.float32)
 bufs = {k: np.zeros(((12 if monthly else nt), n)) for k in names}
 best = None
-for rep in range(3):
+times = []
+for rep in range(reps):
     t0 = time.perf_counter()
     out = api.splash_grid(host["sw"], host["tc"], host["pn"], host["elev"], host["soil"], host["lat"],
                           host["slop"], host["asp"], Au=host["au"], resolution=host["res"],
                           time_index=time_index, sim_control=dict(monthly_out=monthly), outputs=names,
-                          out=bufs, want_state=False)
+                          out=bufs, want_state=False, max_cells_per_launch=max_cells)
     dt = time.perf_counter() - t0
-    print(f"call {rep}: {dt:.3f} s", file=sys.stderr)
+    print(f"call {rep}: {dt:.3f} s", file=sys.stderr, flush=True)
+    times.append(dt)
     best = dt if best is None else min(best, dt)
-bytes_moved = n * nt * (12 if f32 else 24) + n * (12 if monthly else nt) * 8 * nout
-print(json.dumps({"entry": "splash_grid_run (host buffers)", "forcing": "f32" if f32 else "f64", "cells": n, "days": nt, "outputs": list(names),
-                  "monthly": monthly, "seconds": best, "cell_days_per_s": n * nt / best,
-                  "pcie_bytes": bytes_moved, "pcie_GBps_equivalent": bytes_moved / best / 1e9,
+bytes_in = n * nt * (12 if f32 else 24)
+bytes_out = n * (12 if monthly else nt) * 8 * nout
+print(json.dumps({"entry": "splash_grid_run (host buffers)", "forcing": "f32" if f32 else "f64", "rows": H, "cols": W,
+                  "cells": n, "days": nt, "outputs": list(names), "monthly": monthly, "seconds": best,
+                  "seconds_all_calls": [round(t, 3) for t in times], "cell_days_per_s": n * nt / best,
+                  "pcie_bytes_in": bytes_in, "pcie_bytes_out": bytes_out,
+                  "pcie_GBps_equivalent": (bytes_in + bytes_out) / best / 1e9,
+                  "lanes": os.environ.get("SPLASH_HIP_LANES", "2 (default)"), "max_cells_per_block": max_cells,
                   "wn_mean": float(np.nanmean(out["wn"]))}))
