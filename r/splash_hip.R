@@ -33,20 +33,23 @@ splash.point <- function(sw_in, tc, pn, lat, elev, slop = 0, asp = 0, soil_data,
 # `bs` is raster::blockSize(sw_in, ...) as in the reference; the static rasters (lat, terraines,
 # resolution, Au) are prepared exactly as R/splash.grid.R:76-110 does.  `devices`: HIP ordinals the
 # block is split over inside the call (this is what stands where the SOCK cluster stood).
-.splash_grid_block <- function(i, bs, sw_in, tc, pn, elev, lat, terraines, soil, resolution, Au,
-                               ztime, monthly_out, devices = 0L) {
+# .splash_grid_submit starts the block's call and returns a handle at once; .splash_grid_collect
+# waits for it and returns
+#   list(wn, ro, pet, aet, snow, cond, bflow, netr, sm_lim) of [ncell_blk x nl] matrices, which
+#   writeValues(brick, m, bs$row[i]) / matXX[startind[i]:endind[i], ] <- m consume unchanged
+#   (R/splash.grid.R:370-392)
+.splash_grid_submit <- function(i, bs, sw_in, tc, pn, elev, lat, terraines, soil, resolution, Au,
+                                ztime, monthly_out, devices = 0L, mem_fraction = 0) {
   gv <- function(x) raster::getValues(x, bs$row[i], bs$nrows[i])
   tf <- .time_fields(ztime)
   stat <- cbind(gv(lat), gv(elev), gv(terraines[[1]]), gv(terraines[[2]]), gv(resolution))
-  .Call("C_splash_grid_run", gv(sw_in), gv(tc), gv(pn), stat, gv(soil), gv(Au),
-        tf$doy, tf$year, tf$month, monthly_out, as.integer(devices))
-  # -> list(wn, ro, pet, aet, snow, cond, bflow, netr, sm_lim) of [ncell_blk x nl] matrices, which
-  #    writeValues(brick, m, bs$row[i]) / matXX[startind[i]:endind[i], ] <- m consume unchanged
-  #    (R/splash.grid.R:370-392)
+  .Call("C_splash_grid_submit", gv(sw_in), gv(tc), gv(pn), stat, gv(soil), gv(Au),
+        tf$doy, tf$year, tf$month, monthly_out, as.integer(devices), as.numeric(mem_fraction))
 }
+.splash_grid_collect <- function(handle) .Call("C_splash_grid_wait", handle)
 
 # file stem, NetCDF variable, unit and long name of the nine result bricks, in the order
-# .splash_grid_block returns them (names as R/splash.grid.R:190-216 and :449)
+# .splash_grid_collect returns them (names as R/splash.grid.R:190-216 and :449)
 .splash_outputs <- data.frame(
   key  = c("wn",  "ro", "pet", "aet", "snow", "cond", "bflow", "netr",   "sm_lim"),
   stem = c("swc", "ro", "pet", "aet", "swe",  "cond", "bflow", "netrad", "sm_lim"),
@@ -63,13 +66,13 @@ splash.point <- function(sw_in, tc, pn, lat, elev, slop = 0, asp = 0, soil_data,
 # splash.grid with the reference's signature (R/splash.grid.R:28).  Static preparation (upslope
 # area, latitude, slope/aspect, resolution: R/splash.grid.R:76-110) and the output time axis
 # (:145-181) are the package's own code and are reused through `prep`; what changes is the middle:
-# no cluster, no per-cell mapply -- every row block goes through ONE .Call into the HIP library,
-# which splits it over `devices` itself.  Blocks are sized by raster::blockSize as before, so
-# memory use on the R side is unchanged.
+# no cluster, no per-cell mapply -- every row block goes through ONE call of the HIP library, which
+# splits it over `devices` itself; `inflight` of them are in the library at a time.  Blocks are
+# sized by raster::blockSize as before, so memory use on the R side is `inflight` blocks.
 splash.grid <- function(sw_in, tc, pn, elev, soil, outdir = getwd(),
                         tmpdir = dirname(raster::rasterTmpFile()),
                         sim.control = list(monthly_out = TRUE, inmem = FALSE), devices = 0L,
-                        prep = splash.grid.statics(elev, tmpdir)) {
+                        inflight = 2L, prep = splash.grid.statics(elev, tmpdir)) {
   raster::rasterOptions(tolerance = 0.5)
   raster::compareRaster(sw_in, tc, pn, elev, soil, extent = TRUE, crs = TRUE, res = TRUE,
                         orig = FALSE, rotation = FALSE, values = FALSE, stopiffalse = FALSE,
@@ -98,9 +101,20 @@ splash.grid <- function(sw_in, tc, pn, elev, soil, outdir = getwd(),
   mats <- if (inmem) lapply(1:9, function(k) matrix(NA_real_, raster::ncell(elev), nl)) else NULL
   bs <- raster::blockSize(sw_in, minblocks = 2)
   pb <- utils::txtProgressBar(min = 0, max = bs$n, style = 3)
+  # The receive loop of R/splash.grid.R:359-400 with the GPU where the cluster was: `inflight` blocks
+  # are in the library at any time (each on its own host thread and streams, with its share of the
+  # device memory), so reading block i+1 from disk, the device work of block i and writing block i-1
+  # overlap, and the long tails of the blocks' spin-ups run side by side instead of one after another.
+  inflight <- max(1L, min(as.integer(inflight), bs$n))
+  submit <- function(i) .splash_grid_submit(i, bs, sw_in, tc, pn, elev, prep$lat, prep$terraines, soil,
+                                            prep$resolution, prep$Au, ztime, monthly, devices,
+                                            mem_fraction = 0.8 / inflight)
+  handles <- vector("list", bs$n)
+  for (i in seq_len(inflight)) handles[[i]] <- submit(i)
   for (i in seq_len(bs$n)) {
-    res <- .splash_grid_block(i, bs, sw_in, tc, pn, elev, prep$lat, prep$terraines, soil,
-                              prep$resolution, prep$Au, ztime, monthly, devices)
+    res <- .splash_grid_collect(handles[[i]])
+    handles[i] <- list(NULL)
+    if (i + inflight <= bs$n) handles[[i + inflight]] <- submit(i + inflight)   # :395-399: next block to the free slot
     for (k in 1:9) {
       if (inmem) {
         rows <- raster::cellFromRow(elev, bs$row[i]:(bs$row[i] + bs$nrows[i] - 1))

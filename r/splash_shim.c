@@ -23,9 +23,11 @@
 /* sw_in, tc, pn: numeric matrices [ncell x nt] exactly as raster::getValues(brick, row, nrows)
  * returns them (R/splash.grid.R:278-280): column-major => time-major [nt][ncell], zero-copy.
  * stat: numeric matrix [ncell x 5] = lat, elev, slop, asp, resolution; soil [ncell x 6];
- * au [ncell x 3] or NULL; doy/year/month: integer(nt); monthly: logical(1). */
-SEXP C_splash_grid_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP stat, SEXP soil, SEXP au, SEXP doy,
-                       SEXP year, SEXP month, SEXP monthly, SEXP devices)
+ * au [ncell x 3] or NULL; doy/year/month: integer(nt); monthly: logical(1).
+ * Fills in/opt/out for one block and returns the (protected) list of result matrices. */
+static SEXP grid_call_setup(SEXP sw_in, SEXP tc, SEXP pn, SEXP stat, SEXP soil, SEXP au, SEXP doy,
+                            SEXP year, SEXP month, SEXP monthly, SEXP devices, splash_grid_in* in,
+                            splash_opts* opt, splash_grid_out* out)
 {
     SEXP dim = getAttrib(sw_in, R_DimSymbol);
     if (isNull(dim) || LENGTH(dim) != 2) error("sw_in must be a [ncell x nt] matrix");
@@ -41,57 +43,117 @@ SEXP C_splash_grid_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP stat, SEXP soil, SEXP 
     if (!isNull(au) && (size_t)XLENGTH(au) != 3 * ncell) error("Au must be a [ncell x 3] matrix");
     if (!isInteger(devices) || LENGTH(devices) < 1) error("devices must be integer(>= 1)");
 
-    splash_grid_in in;
-    memset(&in, 0, sizeof in);
-    in.ncell = ncell;
-    in.nt = nt;
-    in.doy = INTEGER(doy);
-    in.year = INTEGER(year);
-    in.month = INTEGER(month);
-    in.sw_in = REAL(sw_in);
-    in.tc = REAL(tc);
-    in.pn = REAL(pn);
+    memset(in, 0, sizeof *in);
+    in->ncell = ncell;
+    in->nt = nt;
+    in->doy = INTEGER(doy);
+    in->year = INTEGER(year);
+    in->month = INTEGER(month);
+    in->sw_in = REAL(sw_in);
+    in->tc = REAL(tc);
+    in->pn = REAL(pn);
     const double* st = REAL(stat); /* column-major [ncell x 5] == [5][ncell] */
-    in.lat = st;
-    in.elev = st + ncell;
-    in.slop = st + 2 * ncell;
-    in.asp = st + 3 * ncell;
-    in.resolution = st + 4 * ncell;
-    in.soil = REAL(soil);          /* [ncell x 6] == [6][ncell] */
-    in.au = isNull(au) ? NULL : REAL(au);
+    in->lat = st;
+    in->elev = st + ncell;
+    in->slop = st + 2 * ncell;
+    in->asp = st + 3 * ncell;
+    in->resolution = st + 4 * ncell;
+    in->soil = REAL(soil);          /* [ncell x 6] == [6][ncell] */
+    in->au = isNull(au) ? NULL : REAL(au);
 
-    splash_opts opt;
-    memset(&opt, 0, sizeof opt);
-    opt.monthly_out = asLogical(monthly);
-    opt.device = INTEGER(devices)[0];
-    opt.n_devices = LENGTH(devices);   /* > 1: the block is split over these GPUs inside the call */
-    opt.devices = INTEGER(devices);
+    memset(opt, 0, sizeof *opt);
+    opt->monthly_out = asLogical(monthly);
+    opt->device = INTEGER(devices)[0];
+    opt->n_devices = LENGTH(devices);   /* > 1: the block is split over these GPUs inside the call */
+    opt->devices = INTEGER(devices);
 
     /* number of output steps: months present in the calendar, or days */
     int nmonth = 1;
     for (int t = 1; t < nt; t++)
-        if (in.month[t] != in.month[t - 1] || in.year[t] != in.year[t - 1]) nmonth++;
-    const int nt_out = opt.monthly_out ? nmonth : nt;
+        if (in->month[t] != in->month[t - 1] || in->year[t] != in->year[t - 1]) nmonth++;
+    const int nt_out = opt->monthly_out ? nmonth : nt;
 
     static const char* names[] = {"wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr",
                                   "sm_lim", ""};
     SEXP res = PROTECT(mkNamed(VECSXP, names));
-    splash_grid_out out;
-    memset(&out, 0, sizeof out); /* no state_end / diag / aux */
+    memset(out, 0, sizeof *out); /* no state_end / diag / aux */
     for (int k = 0; k < SPLASH_NOUT; k++) {
         SEXP m = PROTECT(allocMatrix(REALSXP, (int)ncell, nt_out)); /* [ncell x nt_out] */
-        out.out[k] = REAL(m);
+        out->out[k] = REAL(m);
         SET_VECTOR_ELT(res, k, m);
         UNPROTECT(1);
     }
+    return res; /* still protected: the caller unprotects */
+}
 
+SEXP C_splash_grid_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP stat, SEXP soil, SEXP au, SEXP doy,
+                       SEXP year, SEXP month, SEXP monthly, SEXP devices)
+{
+    splash_grid_in in;
+    splash_opts opt;
+    splash_grid_out out;
+    SEXP res = grid_call_setup(sw_in, tc, pn, stat, soil, au, doy, year, month, monthly, devices, &in, &opt, &out);
     char err[512];
     int rc = splash_grid_run(&in, &opt, &out, err, sizeof err);
-    if (rc != SPLASH_OK) {
-        UNPROTECT(1);
-        error("splash_grid_run failed (%d): %s", rc, err);
-    }
     UNPROTECT(1);
+    if (rc != SPLASH_OK) error("splash_grid_run failed (%d): %s", rc, err);
+    return res;
+}
+
+/* The same call in two halves (splash_grid_submit / splash_grid_wait), so that splash.grid's loop
+ * over row blocks keeps several blocks in flight, as the reference's receive loop keeps its cluster
+ * busy (R/splash.grid.R:359-400).  _submit returns an external pointer; everything the running call
+ * reads or writes (the argument matrices and the result list) hangs off that pointer's protected
+ * slot, so R's collector leaves it alone until _wait has returned the results.
+ * mem_fraction: this call's share of the device's free memory (0 = the library's default). */
+typedef struct {
+    splash_grid_job* job;
+} grid_handle;
+
+static void grid_handle_finalizer(SEXP ptr)
+{
+    grid_handle* h = (grid_handle*)R_ExternalPtrAddr(ptr);
+    if (!h) return;
+    if (h->job) { /* dropped without wait(): let the call finish before its buffers can go */
+        char err[256];
+        (void)splash_grid_wait(h->job, err, sizeof err);
+    }
+    R_Free(h);
+    R_ClearExternalPtr(ptr);
+}
+
+SEXP C_splash_grid_submit(SEXP sw_in, SEXP tc, SEXP pn, SEXP stat, SEXP soil, SEXP au, SEXP doy,
+                          SEXP year, SEXP month, SEXP monthly, SEXP devices, SEXP mem_fraction)
+{
+    splash_grid_in in;
+    splash_opts opt;
+    splash_grid_out out;
+    SEXP res = grid_call_setup(sw_in, tc, pn, stat, soil, au, doy, year, month, monthly, devices, &in, &opt, &out);
+    opt.mem_fraction = asReal(mem_fraction);
+    /* keep-alive list: results + every argument the call reads */
+    SEXP keep = PROTECT(allocVector(VECSXP, 11));
+    SEXP args[10] = {sw_in, tc, pn, stat, soil, au, doy, year, month, devices};
+    SET_VECTOR_ELT(keep, 0, res);
+    for (int k = 0; k < 10; k++) SET_VECTOR_ELT(keep, k + 1, args[k]);
+    grid_handle* h = R_Calloc(1, grid_handle);
+    SEXP ptr = PROTECT(R_MakeExternalPtr(h, R_NilValue, keep));
+    R_RegisterCFinalizerEx(ptr, grid_handle_finalizer, TRUE);
+    char err[512];
+    int rc = splash_grid_submit(&in, &opt, &out, &h->job, err, sizeof err);
+    UNPROTECT(3);
+    if (rc != SPLASH_OK) error("splash_grid_submit failed (%d): %s", rc, err);
+    return ptr;
+}
+
+SEXP C_splash_grid_wait(SEXP ptr)
+{
+    grid_handle* h = (grid_handle*)R_ExternalPtrAddr(ptr);
+    if (!h || !h->job) error("splash.grid: this block has been collected already");
+    char err[512];
+    int rc = splash_grid_wait(h->job, err, sizeof err);
+    h->job = NULL;
+    SEXP res = VECTOR_ELT(R_ExternalPtrProtected(ptr), 0);
+    if (rc != SPLASH_OK) error("splash_grid_run failed (%d): %s", rc, err);
     return res;
 }
 
@@ -192,6 +254,8 @@ SEXP C_splash_static_rasters(SEXP elev, SEXP ymax, SEXP yres, SEXP xres, SEXP de
 
 static const R_CallMethodDef CallEntries[] = {
     {"C_splash_grid_run", (DL_FUNC)&C_splash_grid_run, 11},
+    {"C_splash_grid_submit", (DL_FUNC)&C_splash_grid_submit, 12},
+    {"C_splash_grid_wait", (DL_FUNC)&C_splash_grid_wait, 1},
     {"C_splash_point_run", (DL_FUNC)&C_splash_point_run, 14},
     {"C_splash_unswc_run", (DL_FUNC)&C_splash_unswc_run, 3},
     {"C_splash_static_rasters", (DL_FUNC)&C_splash_static_rasters, 5},
