@@ -504,8 +504,11 @@ static int spin_phases(const splash_calendar* cal, size_t ncell, const double* s
         a.wl_out = wl[ph & 1];
         a.n_out = cnt + ph;
         a.pending = (ph == kSpinPhases - 2) ? (unsigned char*)(w + o_pend) : nullptr;
-        // the cache of day terms pays from the second pass of a launch on
+        // the cache of day terms pays from the second pass of a launch on; phase 0 streams compact
+        // records, the short worklists of the later phases keep rich ones (splash_kernels.hip)
         a.cache = budget[ph] >= 2 ? cache_all : nullptr;
+        a.rich = ph > 0 ? 1 : 0;
+        a.cache_cap = ph > 0 ? spin_cache_rich_cap(spin_cache_cap(ncell)) : spin_cache_cap(ncell);
         if (ph == 0) { // every cell, in blocks the size of the cache
             // per block: one pass of the general kernel (spin-up #1's pass: it stores the block's
             // records), then the other passes of the phase by the read-back kernel, which is the

@@ -688,8 +688,8 @@ __device__ __forceinline__ void hour_angle2(double cos1, double cos2, double& h1
 // day_terms():  everything that depends only on the cell, the calendar day and the day's forcing
 //   -- the slope geometry and the sunset angle, the cloud factor and net longwave, the water
 //   properties (saturation slope, latent heat, density, psychrometric constant, viscosity) and
-//   what follows from them -- 17 numbers.  They do not depend on the state (soil water, snow pack),
-//   so a spin-up pass after the first finds the same 17 numbers for every day of the year: the
+//   what follows from them -- 14 numbers and a flag.  They do not depend on the state (soil water, snow pack),
+//   so a spin-up pass after the first finds the same numbers for every day of the year: the
 //   tail of the spin-up (cells that run hundreds of passes, alone on their SIMD, paying the full
 //   instruction latency of every day step) stores them once and reads them back (k_spin_phase).
 // evap_update(): the state-dependent rest (albedo, net radiation and its cross-over angle, the
@@ -700,25 +700,49 @@ __device__ __forceinline__ void hour_angle2(double cos1, double cos2, double& h1
 // sw is the supply fraction (src/SPLASH.cpp:1042-1048), snow already includes today's snowfall.
 // Angles are kept in radians (the reference converts to degrees and back at every use).
 struct DayTerms {
-    double ru, rv, ruv;   // slope-corrected geometry, ru/rv (src/SOLAR.cpp:139-140)
+    double ru, rv, ruv;   // slope-corrected geometry, ru/rv (src/SOLAR.cpp:139-140); rv = cos(delta)*kb
     double hs, sin_hs;    // sunset angle on the slope and its sine (:149-159)
     double xrw;           // rw = (1 - albedo) * xrw (:220-224)
     double rnl;           // net longwave (:203)
     double s, g;          // saturation slope, psychrometric constant (src/EVAP.cpp:111, 115)
     double econ, inv_econ, eetc; // :117, its reciprocal, 1e3*s/(lv*pw*(s+0.24g)) (:129)
-    double pw, ipk;       // water density, 1/(pw*kfus) when tc >= 3 (:113, :233-236)
-    double kv, ikv24;     // Ksat_visc and 1/(24*Ksat_visc) (src/SPLASH.cpp:1260-1261, :1281)
-    double tc;
+    double pw;            // water density (:113)
+    double visc;          // viscosity: a FLOAT by construction (:405-462), held in a double
+    bool warm;            // tc >= 3.0: snow melts (:233)
 };
-constexpr int kNTerms = 17;
+// what the spin-up's cache keeps of them per cell-day: 13 doubles (rv is cos(delta) of the day times a
+// cell constant: recomputed) and one word holding the viscosity's 32 bits and the flag
+constexpr int kNTermWords = 13;
 
 __device__ __forceinline__ void terms_fence(DayTerms& T)
 {
 #define SPL_PIN(x) asm volatile("" : "+v"(x))
     SPL_PIN(T.ru); SPL_PIN(T.rv); SPL_PIN(T.ruv); SPL_PIN(T.hs); SPL_PIN(T.sin_hs); SPL_PIN(T.xrw);
     SPL_PIN(T.rnl); SPL_PIN(T.s); SPL_PIN(T.g); SPL_PIN(T.econ); SPL_PIN(T.inv_econ); SPL_PIN(T.eetc);
-    SPL_PIN(T.pw); SPL_PIN(T.ipk); SPL_PIN(T.kv); SPL_PIN(T.ikv24); SPL_PIN(T.tc);
+    SPL_PIN(T.pw); SPL_PIN(T.visc);
 #undef SPL_PIN
+}
+
+// What the water balance takes from the day's viscosity and density: 1/(pw*kfus) when snow can melt
+// (src/EVAP.cpp:233-236), Ksat_visc (src/SPLASH.cpp:1260-1261) and 1/(24*Ksat_visc) (:1281), from ONE
+// reciprocal of visc*pw.  Evaluated by the update (not kept among the terms: three doubles of the
+// spin-up's cached record for ten instructions), so run_all and every spin-up variant execute the
+// same operations on the same two finished numbers.
+struct ViscTerms {
+    double ipk, kv, ikv24;
+};
+__device__ __forceinline__ ViscTerms visc_terms(const CellConst& c, const DayTerms& T)
+{
+    ViscTerms v;
+    const double r_v = frcp(T.visc * T.pw);
+    const double inv_pw = r_v * T.visc;
+    v.ipk = T.warm ? inv_pw * (1.0 / kKfus) : 0.0;
+    v.kv = c.int_perm * ((T.pw * kG) * (r_v * T.pw)) * 3.6;
+    v.ikv24 = (T.visc * inv_pw) * c.inv_kv24c;
+    // finished doubles, as when they come back from the tail's cache (a product that is later an
+    // addend -- r - Ksat in inf_GA -- could otherwise be contracted into an FMA in one variant only)
+    asm volatile("" : "+v"(v.ipk), "+v"(v.kv), "+v"(v.ikv24));
+    return v;
 }
 
 __device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d, const DayPre& pre,
@@ -799,19 +823,12 @@ __device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d,
     T.s = s;
     T.g = g;
     T.pw = pw;
-    // 1/visc (Ksat_visc, src/SPLASH.cpp:1260-1261), 1/(24*Ksat_visc) (:1281) and 1/(pw*kfus)
-    // (:233-236) from the reciprocal of visc*pw
-    const double visc = day_viscosity(c, pre, tc);                    // :100-105, :120
-    const double r_v = frcp(visc * pw);
-    const double inv_pw = r_v * visc;
-    T.ipk = (tc >= 3.0) ? inv_pw * (1.0 / kKfus) : 0.0;
-    T.kv = c.int_perm * ((pw * kG) * (r_v * pw)) * 3.6;
-    T.ikv24 = (visc * inv_pw) * c.inv_kv24c;
-    T.tc = tc;
+    T.visc = day_viscosity(c, pre, tc);                               // :100-105, :120 (see visc_terms)
+    T.warm = (tc >= 3.0);
 }
 
-__device__ __forceinline__ void evap_update(const CellConst& c, const DayTerms& T, double sw,
-                                            double snow, double nd, Etr& o)
+__device__ __forceinline__ void evap_update(const CellConst& c, const DayTerms& T, const ViscTerms& V,
+                                            double sw, double snow, double nd, Etr& o)
 {
     const double ru = T.ru, rv = T.rv, rnl = T.rnl, s = T.s, g = T.g, econ = T.econ;
     const double sw_s = sw > 1.0 ? 1.0 : sw; // :92
@@ -852,8 +869,8 @@ __device__ __forceinline__ void evap_update(const CellConst& c, const DayTerms& 
     const double eet_d = T.eetc * rn_d;                               // :129
 
     double snowmelt = 0.0, sublimation = 0.0, melt_enrg = 0.0; // :233-249
-    if (T.tc >= 3.0) {
-        const double m = (rn_d * T.ipk) * 1000.0;
+    if (T.warm) {
+        const double m = (rn_d * V.ipk) * 1000.0;
         snowmelt = SPL_MIN(snow, m);
         melt_enrg = (snowmelt * 1.0e-3) * T.pw * kKfus;
     }
@@ -880,7 +897,7 @@ __device__ __forceinline__ void evap_update(const CellConst& c, const DayTerms& 
     o.sublimation = sublimation;
     o.pw = T.pw;
     o.rn_d = rn_d;
-    o.visc = 0.0; // filled by evap_day() for the test hook; the water balance uses T.kv
+    o.visc = T.visc;
     o.econ = econ;
     o.pet_max = pet_max;
 }
@@ -893,8 +910,7 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
     DayTerms T;
     day_terms(c, d, pre, sw_in, tc, T);
     terms_fence(T);
-    evap_update(c, T, sw, snow, nd, o);
-    o.visc = day_viscosity(c, pre, tc);
+    evap_update(c, T, visc_terms(c, T), sw, snow, nd, o);
 }
 
 // ---- SPLASH helpers ---------------------------------------------------------------------------
@@ -1044,9 +1060,10 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
 
 // ---- the day step: src/SPLASH.cpp:920-1588 (== quick_run :150-918) ----------------------------
 // day_update(): the water balance given the day's state-independent terms (computed by day_terms()
-// or read back from the spin-up's cache) and the day's rain and snowfall.
-__device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K, double pn,
-                                           double snowfall, State& st, DayOut& o)
+// or read back from the spin-up's cache), what follows from the day's viscosity (visc_terms()) and
+// the day's rain and snowfall.
+__device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K, const ViscTerms& V,
+                                           double pn, double snowfall, State& st, DayOut& o)
 {
     const double wn = st.wn;
     double snow = st.snow, qin = st.qin, td = st.td, nd = st.nd;
@@ -1067,12 +1084,12 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
     snow += snowfall;
 
     Etr ev;
-    evap_update(c, K, sw, snow, nd, ev);          // :1235
+    evap_update(c, K, V, sw, snow, nd, ev);       // :1235
     snow -= ev.snowmelt;                          // :1240
     const double snowmelt = ev.snowmelt - ev.sublimation; // :1243
 
     // :1260-1272
-    const double Ksat_visc = K.kv;
+    const double Ksat_visc = V.kv;
     const double inflow = pn + ev.cond + snowmelt;
     const double infi = inf_GA(c, wn, Ksat_visc, inflow);
     const double ro_h_arg = inflow - infi;
@@ -1080,7 +1097,7 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
     double R = infi - ev.aet;
 
     // :1275-1284
-    const double hyd_grad_z = (infi * K.ikv24) - 1.0;
+    const double hyd_grad_z = (infi * V.ikv24) - 1.0;
     const double hyd_grad_out = fsqrt_nn(hyd_grad_z * hyd_grad_z + c.tan2_slop);
 
     // :1291-1326 (cell-static part folded into kb_coef); Kb and log(Kb) keep the reference's
@@ -1233,7 +1250,7 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     DayTerms T;
     day_terms(c, d, pre, sw_in, tc, T);
     if (FENCE) terms_fence(T);
-    day_update(c, T, pn, snowfall, st, o);
+    day_update(c, T, visc_terms(c, T), pn, snowfall, st, o);
 }
 
 // ---- rain / snow split: R/splash.point.R:120-128, 521-578 -------------------------------------

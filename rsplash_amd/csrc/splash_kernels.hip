@@ -228,37 +228,84 @@ __device__ __forceinline__ bool same_bits(double a, double b)
 // list, so the long-running cells end up packed into few dense waves.
 //   job stage 1: spin-up #1 (cellout as given); its first pass also yields the aridity index
 //   job stage 2: spin-up #2 with cellout := AI (R/splash.point.R:150)
-// One cached record: the 17 state-independent terms of a cell-day (DayTerms) + the day's rain and
-// snowfall; the cache is [365][kNRec][cap] doubles, slot = position of the job in the worklist, so
-// that the 64 lanes of a wavefront read 512 contiguous bytes per field.
-constexpr int kNRec = kNTerms + 2;
+// One cached record: the state-independent terms of a cell-day (DayTerms) + the day's rain and
+// snowfall, 15 words; the cache is [365][kNRec][cap] doubles, slot = position of the job in the
+// worklist, so that the 64 lanes of a wavefront read 512 contiguous bytes per field.
+// Two layouts.  Compact (15 words = 120 B): what phase 0 streams for every cell of the grid -- its
+// fill pass is bound by the bytes it stores.  Rich (19 words): the compact record plus rv and the
+// three numbers visc_terms() derives, for the later phases -- short worklists and, at the end, lone
+// wavefronts whose every instruction is latency: there the twenty instructions (one reciprocal) and
+// the scalar load saved per day step are worth far more than the bytes (measured on the tail:
+// 1 272 ms with compact records, 1 160 ms with rich ones).
+constexpr int kNRecCompact = kNTermWords + 2;
+constexpr int kNRecRich = kNRecCompact + 4;
 struct DayRecord {
     DayTerms T;
+    ViscTerms V;
     double rain, snf;
 };
+template <bool RICH>
 __device__ __forceinline__ void rec_store(double* __restrict__ base, size_t cap, int day, size_t slot,
                                           const DayRecord& r)
 {
-    double* p = base + ((size_t)day * kNRec) * cap + slot;
-    const double v[kNRec] = {r.T.ru, r.T.rv, r.T.ruv, r.T.hs, r.T.sin_hs, r.T.xrw, r.T.rnl, r.T.s, r.T.g,
-                             r.T.econ, r.T.inv_econ, r.T.eetc, r.T.pw, r.T.ipk, r.T.kv, r.T.ikv24,
-                             r.T.tc, r.rain, r.snf};
+    constexpr int NR = RICH ? kNRecRich : kNRecCompact;
+    double* p = base + ((size_t)day * NR) * cap + slot;
+    // the viscosity is a float: its 32 bits and the melt flag share one word, exactly
+    const unsigned long long vw = (unsigned long long)__float_as_uint((float)r.T.visc) |
+                                  ((unsigned long long)(r.T.warm ? 1u : 0u) << 32);
+    const double v[kNRecRich] = {r.T.ru, r.T.ruv, r.T.hs, r.T.sin_hs, r.T.xrw, r.T.rnl, r.T.s, r.T.g,
+                                 r.T.econ, r.T.inv_econ, r.T.eetc, r.T.pw, __longlong_as_double((long long)vw),
+                                 r.rain, r.snf, r.T.rv, r.V.ipk, r.V.kv, r.V.ikv24};
 #pragma unroll
-    for (int k = 0; k < kNRec; k++) p[(size_t)k * cap] = v[k];
+    for (int k = 0; k < NR; k++) p[(size_t)k * cap] = v[k];
 }
-__device__ __forceinline__ DayRecord rec_load(const double* __restrict__ base, size_t cap, int day,
-                                              size_t slot)
+// Loading is split from decoding: the words of tomorrow's record are requested a day ahead and must
+// not be touched before tomorrow (anything computed from them at the point of the load -- the
+// viscosity's conversion, rv, visc_terms() -- makes the wavefront wait for the load right there, a
+// full memory round trip per day: +17 % on the tail when this was one function).
+template <bool RICH>
+struct RawRecord {
+    double v[RICH ? kNRecRich : kNRecCompact];
+};
+template <bool RICH>
+__device__ __forceinline__ RawRecord<RICH> rec_load(const double* __restrict__ base, size_t cap, int day, size_t slot)
 {
-    const double* p = base + ((size_t)day * kNRec) * cap + slot;
-    double v[kNRec];
+    constexpr int NR = RICH ? kNRecRich : kNRecCompact;
+    const double* p = base + ((size_t)day * NR) * cap + slot;
+    RawRecord<RICH> w;
 #pragma unroll
-    for (int k = 0; k < kNRec; k++) v[k] = p[(size_t)k * cap];
+    for (int k = 0; k < NR; k++) w.v[k] = p[(size_t)k * cap];
+    return w;
+}
+// Compact: rv = cos(delta) * kb of the record's day (one multiplication of a per-day scalar and a cell
+// constant, the same one day_terms() does, pinned like the loaded terms) and visc_terms() are redone.
+template <bool RICH>
+__device__ __forceinline__ DayRecord rec_decode(const CellConst& c, const RawRecord<RICH>& w, double cd)
+{
+    const double* v = w.v;
     DayRecord r;
-    r.T.ru = v[0]; r.T.rv = v[1]; r.T.ruv = v[2]; r.T.hs = v[3]; r.T.sin_hs = v[4]; r.T.xrw = v[5];
-    r.T.rnl = v[6]; r.T.s = v[7]; r.T.g = v[8]; r.T.econ = v[9]; r.T.inv_econ = v[10]; r.T.eetc = v[11];
-    r.T.pw = v[12]; r.T.ipk = v[13]; r.T.kv = v[14]; r.T.ikv24 = v[15]; r.T.tc = v[16];
-    r.rain = v[17];
-    r.snf = v[18];
+    r.T.ru = v[0]; r.T.ruv = v[1]; r.T.hs = v[2]; r.T.sin_hs = v[3]; r.T.xrw = v[4]; r.T.rnl = v[5];
+    r.T.s = v[6]; r.T.g = v[7]; r.T.econ = v[8]; r.T.inv_econ = v[9]; r.T.eetc = v[10]; r.T.pw = v[11];
+    r.rain = v[13];
+    r.snf = v[14];
+    if constexpr (!RICH) {
+        const unsigned long long vw = (unsigned long long)__double_as_longlong(v[12]);
+        r.T.visc = (double)__uint_as_float((unsigned)vw);
+        r.T.warm = ((vw >> 32) & 1ull) != 0;
+    }
+    if constexpr (RICH) {
+        r.T.visc = 0.0;            // (its three derived terms are in the record)
+        r.T.warm = (v[16] != 0.0); // ipk = 1/(pw*kfus) > 0 exactly when tc >= 3
+        r.T.rv = v[15];
+        r.V.ipk = v[16];
+        r.V.kv = v[17];
+        r.V.ikv24 = v[18];
+    } else {
+        double rv = cd * c.kb;
+        asm volatile("" : "+v"(rv));
+        r.T.rv = rv;
+        r.V = visc_terms(c, r.T);
+    }
     return r;
 }
 
@@ -277,7 +324,7 @@ __device__ __forceinline__ DayRecord rec_load(const double* __restrict__ base, s
 // tail is ~1000 passes x 365 sequential day steps of lone wavefronts, every instruction of which is
 // latency; compiled together with the general loop its day step carried ~100 v_readlane (scalar
 // registers spilled to vector lanes) and ~300 s_mov per day that the smaller kernel does not need.
-template <bool CACHED, bool READBACK = false>
+template <bool CACHED, bool READBACK = false, bool RICH = false>
 __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPhaseArgs a)
 {
     const size_t nin = a.n_in ? (size_t)*a.n_in : a.ncell;
@@ -327,7 +374,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     auto day_one = [&](State& st_, DayOut& o_, double* p_day) {
         DayRecord r;
         if (READBACK || (CACHED && cached && p_day == nullptr)) {
-            r = rec_load(a.cache, a.cache_cap, 0, sl);
+            r = rec_decode<RICH>(c, rec_load<RICH>(a.cache, a.cache_cap, 0, sl), d0.cd);
         } else if constexpr (!READBACK) {
             double sw0, tc0, pn0;
             f.raw(0, sw0, tc0, pn0);
@@ -335,10 +382,11 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             asm volatile("" : "+v"(r.rain), "+v"(r.snf)); // finished doubles, like the terms below
             day_terms(c, day_const(d0), day_prefetch(c, tc0), sw0, tc0, r.T);
             terms_fence(r.T);
-            if (CACHED && cached) rec_store(a.cache, a.cache_cap, 0, sl, r);
+            r.V = visc_terms(c, r.T);
+            if (CACHED && cached) rec_store<RICH>(a.cache, a.cache_cap, 0, sl, r);
         }
         if (p_day) *p_day = r.rain + r.snf;
-        day_update(c, r.T, r.rain, r.snf, st_, o_);
+        day_update(c, r.T, r.V, r.rain, r.snf, st_, o_);
     };
     State cur;
     double e_wn;
@@ -378,15 +426,18 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     bool done = !valid || finished_before || (READBACK && !cached);
     for (int it = 0; it < a.budget; it++) {
         const bool acc = !READBACK && a.fresh && it == 0; // first pass of spin-up #1 (uniform)
+        // (Finished lanes keep stepping along with the wavefront.  Masking them out of the pass -- so that
+        // only the branches of the jobs still running are executed -- was measured in round 3: the
+        // tail's longest job takes those branches itself, and the extra execution mask held across the
+        // day loop cost 76 more scalar instructions per day step: 1 174 -> 1 235 ms.)
         // cur = state after day 1 of this pass (== the parked start-of-pass state)
         if (READBACK || (CACHED && cached && it > 0)) {
             // read-back pass: next day's record is requested a day ahead
-            DayRecord r = rec_load(a.cache, a.cache_cap, 1, sl);
+            RawRecord<RICH> w = rec_load<RICH>(a.cache, a.cache_cap, 1, sl);
             for (int i = 1; i < a.n; i++) {
-                DayRecord rn = r;
-                if (i + 1 < a.n) rn = rec_load(a.cache, a.cache_cap, i + 1, sl);
-                day_update(c, r.T, r.rain, r.snf, cur, o);
-                r = rn;
+                const DayRecord r = rec_decode<RICH>(c, w, RICH ? 0.0 : days[i].cd);
+                if (i + 1 < a.n) w = rec_load<RICH>(a.cache, a.cache_cap, i + 1, sl); // tomorrow's, untouched until tomorrow
+                day_update(c, r.T, r.V, r.rain, r.snf, cur, o);
             }
         } else if constexpr (!READBACK) {
             // order of the day's vector-memory traffic as in k_run_all: gathers at the top; once
@@ -406,12 +457,13 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 asm volatile("" : "+v"(r.rain), "+v"(r.snf));
                 day_terms(c, day_const(d), pre, swv, tcv, r.T);
                 terms_fence(r.T);
+                r.V = visc_terms(c, r.T);
                 asm volatile("" : : : "memory");
                 const int in_ = i + 1 < a.n ? i + 1 : i; // the last day reads its own row again
                 double swn, tcn, pnn;
                 f.raw(in_, swn, tcn, pnn);
-                if (CACHED && cached) rec_store(a.cache, a.cache_cap, i, sl, r);
-                day_update(c, r.T, r.rain, r.snf, cur, o);
+                if (CACHED && cached) rec_store<RICH>(a.cache, a.cache_cap, i, sl, r);
+                day_update(c, r.T, r.V, r.rain, r.snf, cur, o);
                 if (acc) { // pet_vec is only filled in the first pass (:1667), Pinit = rain + snow
                     const double pday = r.rain + r.snf;
                     pet_sum += (o.pet == o.pet) ? o.pet : 0.0; // na.rm = T
@@ -807,12 +859,12 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
         DayOut o;
         DayTerms T;
         day_terms(c, day_const(d), pre, swv, tcv, T);
-        asm volatile("" : "+v"(T.kv) : : "memory"); // the viscosity (gathers) is finished here
+        asm volatile("" : "+v"(T.visc) : : "memory"); // the viscosity (gathers) is finished here
         const int tn = t + 1 < a.nt ? t + 1 : t;    // the last day reads its own row again
         double swn, tcn, pnn;
         f.raw(tn, swn, tcn, pnn);
         double sfn = f.raw_snowfall(tn);
-        day_update(c, T, rain, snf, st, o);
+        day_update(c, T, visc_terms(c, T), rain, snf, st, o);
         asm volatile("" : "+v"(swn), "+v"(tcn), "+v"(pnn), "+v"(sfn) : : "memory"); // forcing has landed
 
         double lim = 0.0;
@@ -1605,8 +1657,12 @@ hipError_t launch_snow_threshold(size_t ncell, int nt, const double* tc, size_t 
 hipError_t launch_spin_phase(const SpinPhaseArgs& a, hipStream_t s)
 {
     if (a.ncell == 0) return hipSuccess;
-    if (a.readback)
-        hipLaunchKernelGGL((k_spin_phase<true, true>), dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
+    if (a.readback && a.rich)
+        hipLaunchKernelGGL((k_spin_phase<true, true, true>), dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
+    else if (a.readback)
+        hipLaunchKernelGGL((k_spin_phase<true, true, false>), dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
+    else if (a.cache && a.rich)
+        hipLaunchKernelGGL((k_spin_phase<true, false, true>), dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
     else if (a.cache)
         hipLaunchKernelGGL(k_spin_phase<true>, dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
     else
@@ -1819,7 +1875,8 @@ hipError_t launch_diag_finalize(const long long* acc, int n_rec, double* diag, d
     return hipGetLastError();
 }
 
-size_t spin_cache_bytes_per_slot() { return (size_t)365 * kNRec * sizeof(double); }
+size_t spin_cache_bytes_per_slot() { return (size_t)365 * kNRecCompact * sizeof(double); }
+size_t spin_cache_rich_cap(size_t cap) { return (cap * kNRecCompact / kNRecRich) & ~(size_t)63; }
 size_t visc_table_floats_r() { return (size_t)kViscNR * 8; }
 hipError_t launch_visc_tables(float* rtab, hipStream_t s)
 {

@@ -78,8 +78,11 @@ struct SpinPhaseArgs {
     int readback;           // 1: the read-back kernel (every job's records are in the cache already)
     int no_queue;           // 1: park unfinished jobs without queueing them (a launch over the same
                             //    cells follows and does the queueing)
+    int rich;               // 1: the cache holds 19-word records (cache_cap = spin_cache_rich_cap of the
+                            //    workspace's capacity), see splash_kernels.hip "Two layouts"
 };
-size_t spin_cache_bytes_per_slot();
+size_t spin_cache_bytes_per_slot(); // compact records
+size_t spin_cache_rich_cap(size_t cap); // slots of rich records the same bytes hold
 
 struct RunArgs {
     const DayRec* days; // day t0 onwards
