@@ -240,8 +240,9 @@ def roofline(avg_launch_s, units_per_launch, key, kernel):
             traffic = None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": "profiles/traffic.json: separate rocprofv3 --pmc passes of this command on an "
-                              "earlier run (tools/pmc_fetch.sh), not measured in this run; so is valu_busy_frac",
+            "traffic_source": None if traffic is None else
+            "profiles/traffic.json: separate rocprofv3 --pmc passes of this command on an earlier run "
+            "(tools/pmc_fetch.sh), not measured in this run; so is valu_busy_frac",
             "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS, "kernel": kernel,
             "avg_launch_ms": avg_launch_s * 1e3, "units_per_launch": units_per_launch,
             "alg_bytes_per_unit": ALG_BYTES_PER_CELL_DAY, "valu_busy_frac": valu_busy,
@@ -262,11 +263,10 @@ def run_resident(ctx):
     strong = args.scaling == "strong" and world > 1
     if strong:
         # THE H x W grid, cut into row blocks of chunk_rows rows that are dealt round-robin
+        from rsplash_amd.dist import row_blocks_round_robin
         Htot = H
-        cr = max(1, min(args.chunk_rows, H))
-        starts = list(range(0, H, cr))
-        chunks = [(r0, min(cr, H - r0)) for k, r0 in enumerate(starts) if k % world == rank]
-        cr_eff = cr
+        cr_eff = max(1, min(args.chunk_rows, H))
+        chunks = row_blocks_round_robin(H, cr_eff, world, rank)
     else:
         Htot = H * world
         chunks = [(rank * H, H)]

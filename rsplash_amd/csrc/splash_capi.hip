@@ -120,6 +120,16 @@ size_t pool_idle_bytes(int dev)
     return n;
 }
 
+// all bytes of device `dev` the pool holds, in use or idle
+size_t pool_held_bytes(int dev)
+{
+    if (dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::recursive_mutex> lk(g_dev_mu[dev]);
+    size_t n = 0;
+    for (auto& s : g_ctx[dev].pool) n += s.bytes;
+    return n;
+}
+
 hipError_t pool_alloc(void** out, size_t bytes)
 {
     int dev = 0;
@@ -1534,6 +1544,10 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
         std::lock_guard<std::recursive_mutex> alloc_lock(device_alloc_mutex(device));
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b), err, errlen);
+        if (const char* e = getenv("SPLASH_HIP_FAKE_DEVICE_BYTES")) { // test aid: a device of that many bytes, of
+            const size_t fake = (size_t)atoll(e), held = pool_held_bytes(device); // which the pool's buffers are taken
+            free_b = std::min(free_b, fake > held ? fake - held : 0);
+        }
         free_b += pool_idle_bytes(device); // buffers kept from earlier calls are ours to reuse or release
         // the straggler pool: room for 1/128 of the worker's cells (0.08 % of the synthetic grids' cells
         // are stragglers); a block whose stragglers do not fit finishes them in place (late_fallback)

@@ -801,6 +801,9 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
     const double lim_den = wmax_r - c.RES;
     State st{a.state[ci], a.state[a.lds + ci], a.state[2 * a.lds + ci], a.state[3 * a.lds + ci],
              a.state[4 * a.lds + ci]};
+    if (SUBSET && in_range && !valid)           // a cell still spinning up on another stream: its state is being
+        st = State{c.RES, 0.0, 0.0, 0.0, 0.0}; // written there; the lane runs on a fixed one, its results count for
+                                               // nothing (lanes past the last cell keep mirroring that cell)
 
     // which outputs are requested: known at compile time for the two common sets (OUTMASK != 0),
     // otherwise tested at run time (nine uniform booleans that the compiler keeps as 64-bit lane
@@ -919,7 +922,8 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
                 size_t k = (size_t)m * a.ldo + co;
 #pragma unroll
                 for (int q = 0; q < 9; q++) {
-                    if ((omask & (1u << q)) && in_range) {
+                    if ((omask & (1u << q)) && (SUBSET ? valid : in_range)) { // (a skipped cell's months are written
+                                                                               //  by the later call in list mode)
                         double x = (q == 0 || q == 4 || q == 8) ? acc[q] * inv_n : acc[q];
                         if (partial_head) x += a.out[q][k];
                         a.out[q][k] = x;

@@ -29,6 +29,17 @@ def row_block_partition(n_rows, n_cols, world, rank, valid_per_row=None):
     return dict(row0=r0, row1=r1, cell0=r0 * n_cols, ncell=(r1 - r0) * n_cols)
 
 
+def row_blocks_round_robin(n_rows, chunk_rows, world, rank):
+    """Strong scaling of ONE grid: its rows in blocks of `chunk_rows`, dealt round-robin -- rank r owns
+    blocks r, r + world, ...  Every rank gets every latitude band (the day step costs more at low
+    latitudes: a contiguous split leaves the equatorial rank ~5 % behind), still a row-block
+    partition with no data-path exchange.  Returns [(row0, nrows), ...] in ascending order."""
+    if world < 1 or not (0 <= rank < world) or chunk_rows < 1:
+        raise ValueError("bad world/rank/chunk_rows")
+    starts = range(0, n_rows, chunk_rows)
+    return [(r0, min(chunk_rows, n_rows - r0)) for k, r0 in enumerate(starts) if k % world == rank]
+
+
 def all_reduce_(t, op="sum", group=None):
     """In-place all-reduce of a tensor over the ranks of torch.distributed: directly on the device
     with the nccl (= RCCL) backend, through a host copy with gloo (CPU rehearsals, CPU tensors).

@@ -34,6 +34,25 @@ def test_row_block_partition_covers_grid_once():
     assert sum(cnt) == 360 and max(loads) - min(loads) <= 2 * 300  # within two rows of the ideal
 
 
+def test_strong_scaling_row_blocks_tile_the_grid_once():
+    """bench.py --scaling strong: THE grid's rows in blocks dealt round-robin to the ranks"""
+    from rsplash_amd.dist import row_blocks_round_robin
+    for H, chunk, world in ((4096, 64, 8), (4096, 64, 1), (4096, 64, 3), (139, 16, 4), (5, 64, 2), (256, 1, 7)):
+        seen = np.zeros(H, int)
+        per_rank = []
+        for r in range(world):
+            blocks = row_blocks_round_robin(H, chunk, world, r)
+            assert blocks == sorted(blocks)
+            for r0, nr in blocks:
+                seen[r0:r0 + nr] += 1
+            per_rank.append(sum(nr for _, nr in blocks))
+        assert (seen == 1).all()
+        assert max(per_rank) - min(per_rank) <= chunk
+    # 8 ranks of the benchmark grid: 512 rows each, every rank from the first to the last band
+    b = row_blocks_round_robin(4096, 64, 8, 3)
+    assert sum(nr for _, nr in b) == 512 and b[0] == (192, 64) and b[-1] == (3776, 64)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

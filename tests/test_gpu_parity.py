@@ -1385,3 +1385,47 @@ def test_host_path_pipeline_lanes_pool_and_jobs_give_the_same_bits(api, oracle):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+@pytest.mark.gpu
+def test_repeated_multi_block_calls_keep_their_block_size(api, oracle):
+    """The host-buffer entry points keep their device buffers between calls.  Those idle buffers are
+    not 'free' for hipMemGetInfo: a call that sized its blocks from the free figure alone shrank with
+    every call after the first multi-block one until it ran out of memory.  Idle pooled bytes count
+    as free now: the same call repeated under a tight memory share plans the same blocks each time
+    (SPLASH_TRACE prints the plan) and returns the same bits."""
+    import os
+    import re
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import os, sys, numpy as np
+        sys.path.insert(0, %r)
+        from rsplash_amd import api
+        from oracle.binding import Oracle
+        o = Oracle()
+        H, W, nt = 32, 128, 365
+        doy, year, month, mid, nm = o.calendar(2001, nt)
+        st = o.synth_statics(777000, H, W, 0, H * W, 1)
+        sw, tc, pn = o.synth_forcing(777000, H, W, 0, H * W, 0, doy, st["lat"], st["elev"])
+        dates = np.datetime64("2001-01-01") + np.arange(nt)
+        ref = None
+        for rep in range(4):
+            g = api.splash_grid(sw, tc, pn, st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"],
+                                st["resolution"], time_index=dates, sim_control=dict(monthly_out=False),
+                                mem_fraction=float(os.environ["FRAC"]))
+            if ref is None:
+                ref = g
+            assert np.array_equal(ref["wn"].view(np.int64), g["wn"].view(np.int64))
+        print("done")
+    """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # a pretend device of 0.7 GB (SPLASH_HIP_FAKE_DEVICE_BYTES: free = that minus what the pool holds): the
+    # 4096-cell grid needs ~0.33 GB for the straggler pool and ~0.65 GB per lane in one block
+    env = dict(os.environ, SPLASH_TRACE="1", FRAC="0.85", SPLASH_HIP_FAKE_DEVICE_BYTES=str(700 * 1000 * 1000))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "done" in r.stdout, r.stderr[-3000:]
+    plans = re.findall(r"(\d+) cells in (\d+) blocks of <= (\d+) on", r.stderr)
+    assert len(plans) == 4, r.stderr[-2000:]
+    assert len(set(plans)) == 1, plans          # the same plan every time
+    assert int(plans[0][1]) >= 2, plans         # and it is a multi-block plan
