@@ -1429,3 +1429,29 @@ def test_repeated_multi_block_calls_keep_their_block_size(api, oracle):
     assert len(plans) == 4, r.stderr[-2000:]
     assert len(set(plans)) == 1, plans          # the same plan every time
     assert int(plans[0][1]) >= 2, plans         # and it is a multi-block plan
+
+
+@pytest.mark.gpu
+def test_host_path_out_of_memory_is_an_error_not_a_hang(api, oracle):
+    """A device too small for the call (a pretend one: SPLASH_HIP_FAKE_DEVICE_BYTES) makes splash_grid_run
+    return SPLASH_ENOMEM with a message -- from the blocking call and from submit/wait alike -- and the
+    next call on the real device works."""
+    import os
+    from rsplash_amd._lib import SplashError
+    H, W, nt = 8, 64, 365
+    doy, year, month, mid, nm = oracle.calendar(2001, nt)
+    st = oracle.synth_statics(777000, H, W, 0, H * W, 1)
+    sw, tc, pn = oracle.synth_forcing(777000, H, W, 0, H * W, 0, doy, st["lat"], st["elev"])
+    dates = np.datetime64("2001-01-01") + np.arange(nt)
+    args = (sw, tc, pn, st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"], st["resolution"])
+    os.environ["SPLASH_HIP_FAKE_DEVICE_BYTES"] = str(20 * 1000 * 1000)
+    try:
+        with pytest.raises(SplashError, match="memory"):
+            api.splash_grid(*args, time_index=dates)
+        job = api.splash_grid(*args, time_index=dates, submit=True)
+        with pytest.raises(SplashError, match="memory"):
+            job.wait()
+    finally:
+        os.environ.pop("SPLASH_HIP_FAKE_DEVICE_BYTES")
+    g = api.splash_grid(*args, time_index=dates)
+    assert np.isfinite(g["wn"]).all()

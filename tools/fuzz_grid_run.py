@@ -1,6 +1,8 @@
 """Randomised invariants of the host-buffer entry point (splash_grid_run through api.splash_grid), GPU box:
-for random grid shapes, NA masks, launch blockings, device lists {0,0}/{0,0,0}, single-precision
-transport, monthly/daily outputs and basin maps, the results must equal the plain call BITWISE on
+for random grid shapes, NA masks, launch blockings, device lists {0,0}/{0,0,0}, pipeline lanes (1-4),
+straggler pools too small for a block (finished in place), calls in flight side by side
+(splash_grid_submit/_wait), single-precision transport, monthly/daily outputs and basin maps, the
+results must equal the plain call BITWISE on
 every valid cell, NA cells must come back NaN, and the per-basin totals must be identical limbs.
     python tools/fuzz_grid_run.py [n_cases=12]"""
 import os, sys
@@ -41,8 +43,31 @@ for case in range(n_cases):
     for k in names:
         if not (np.isnan(ref[k][:, mask]).all() and np.isfinite(ref[k][:, ~mask]).all()):
             msgs.append(f"NaN pattern of {k}")
+    lanes = int(rng.integers(1, 5))
+    variants[f"{lanes} lanes, blocked"] = dict(max_cells_per_launch=int(rng.integers(64, 400)), _env=dict(SPLASH_HIP_LANES=str(lanes)))
+    variants["tiny pool, blocked"] = dict(max_cells_per_launch=int(rng.integers(64, 400)),
+                                          _env=dict(SPLASH_HIP_POOL_CAP=str(int(rng.integers(1, 4)))))
+    variants["in flight (a)"] = dict(max_cells_per_launch=int(rng.integers(64, 400)), submit=True, mem_fraction=0.3)
+    variants["in flight (b)"] = dict(devices=[0, 0], submit=True, mem_fraction=0.3)
+    jobs = {}
     for tag, extra in variants.items():
+        extra = dict(extra)
+        env = extra.pop("_env", {})
+        os.environ.update(env)
         g = api.splash_grid(swm, tcm, pnm, *args, **kw, **extra)
+        for e in env:
+            os.environ.pop(e)
+        if extra.get("submit"):
+            jobs[tag] = g
+            continue
+        for k in names:
+            if not np.array_equal(g[k][:, ~mask].view(np.int64), ref[k][:, ~mask].view(np.int64)):
+                msgs.append(f"{tag}: {k} differs")
+        for k in g["diag"]:
+            if not np.array_equal(np.asarray(g["diag"][k]).view(np.int64), np.asarray(ref["diag"][k]).view(np.int64)):
+                msgs.append(f"{tag}: basin totals of {k} differ")
+    for tag, job in jobs.items():  # both were in the library at the same time
+        g = job.wait()
         for k in names:
             if not np.array_equal(g[k][:, ~mask].view(np.int64), ref[k][:, ~mask].view(np.int64)):
                 msgs.append(f"{tag}: {k} differs")
