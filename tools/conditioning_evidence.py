@@ -60,7 +60,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cells", type=int, default=8192)
     ap.add_argument("--days", type=int, default=730)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_conditioning.md"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_conditioning.md"))
     ap.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
 

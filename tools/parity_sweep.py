@@ -59,12 +59,12 @@ for g in range(ngrid):
         # the reference's own builds count differently too (oracle/parity.py)
         from oracle.parity import reference_disagrees_with_itself
         mm = np.where(ok & ((got["aux"]["passes2"] != aux["passes2"]) | (got["aux"]["passes1"] != aux["passes1"])))[0]
-        exc = reference_disagrees_with_itself(mm[:16], ref, aux, st, (doy, year, month, mid, nm, sw, tc, pn),
+        exc = reference_disagrees_with_itself(mm[:4], ref, aux, st, (doy, year, month, mid, nm, sw, tc, pn),
                                               ["wn", "ro", "aet", "pet", "snow"])
         print("PASSES", g, [(int(c), int(got["aux"]["passes1"][c]), int(aux["passes1"][c]),
                              int(got["aux"]["passes2"][c]), int(aux["passes2"][c]), bool(e))
                             for c, e in zip(mm[:16], exc)], flush=True)
-        passes_equal = bool(len(mm) <= 16 and exc.all())
+        passes_equal = bool(len(mm) <= 4 and exc.all())
     bad_total += nbad + (0 if passes_equal else 1)
     print(json.dumps({"grid": g, "seed": seed, "terrain": terrain, "cells": H * W, "days": nt,
                       "critical_event_cells": r["critical_event_cells"], "set_aside": r["set_aside"],
