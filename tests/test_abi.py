@@ -115,6 +115,13 @@ def test_r_wrapper_labels_results_positionally():
     assert stem == [{"wn": "swc", "snow": "swe", "netr": "netrad"}.get(k, k) for k in key]
     # the order of the reference's return value (R/splash.grid.R:449) is restored BY NAME
     assert 'out[c("wn", "ro", "pet", "aet", "snow", "bflow", "cond", "netrad", "sm_lim")]' in txt
+    # the pipelined loop: blocks are submitted ahead and collected in order; the shim registers both halves
+    assert '.Call("C_splash_grid_submit"' in txt and '.Call("C_splash_grid_wait"' in txt and "inflight" in txt
+    shim_txt = open(os.path.join(ROOT, "r", "splash_shim.c")).read()
+    assert '{"C_splash_grid_submit", (DL_FUNC)&C_splash_grid_submit, 12}' in shim_txt
+    assert '{"C_splash_grid_wait", (DL_FUNC)&C_splash_grid_wait, 1}' in shim_txt
+    n_args = len(re.search(r'\.Call\("C_splash_grid_submit",(.*?)\)\n\}', txt, re.S).group(1).split(","))
+    assert n_args >= 12
     hdr = open(os.path.join(ROOT, "include", "splash_hip.h")).read()
     m = re.search(r"#define SPLASH_NOUT 9\s*/\*\s*([a-z_, ]+?)\s*\(", hdr)
     assert [x.strip() for x in m.group(1).split(",")] == key
