@@ -1802,6 +1802,48 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
         rcs[w] = grid_worker(P, devs[w], share, v0, v1, acc[w].data(), buf, sizeof buf);
         msgs[w] = buf;
     };
+    // Large result arrays (daily outputs: tens of GB) are page-locked while the first blocks load and
+    // compute: device->host copies into registered memory run beside the host->device copies of the
+    // next block (measured, tools/ubench/pcie_probe.py: 90 GB/s in both directions against 52 GB/s
+    // shared from pageable memory) and registering costs 9 ms per GB on a helper thread.  A failed
+    // registration (limits, memory that is already registered) just leaves that array pageable.
+    struct Registered {
+        std::vector<void*> done;
+        std::thread th;
+        std::atomic<bool> stop{false};
+        ~Registered()
+        {
+            stop = true;
+            if (th.joinable()) th.join();
+            for (void* p : done) (void)hipHostUnregister(p);
+        }
+    } reg;
+    {
+        const size_t bytes_each = (size_t)P.nt_out * N * 8;
+        size_t total = 0;
+        for (int k = 0; k < SPLASH_NOUT; k++) total += out->out[k] ? bytes_each : 0;
+        static const bool off = getenv("SPLASH_HIP_NO_REGISTER") != nullptr;
+        if (!off && P.dense && total >= ((size_t)8 << 30)) {
+            const int dev0 = devs[0];
+            // the forcing too (both directions must be page-locked for the copies to overlap), first:
+            // its copies start at once
+            const size_t fbytes = (size_t)P.nt * N * (f64 ? 8 : 4);
+            void* fptr[3] = {f64 ? (void*)in->sw_in : (void*)in->sw_in_f32, f64 ? (void*)in->tc : (void*)in->tc_f32,
+                             f64 ? (void*)in->pn : (void*)in->pn_f32};
+            reg.th = std::thread([&reg, out, bytes_each, dev0, fbytes, fptr] {
+                (void)hipSetDevice(dev0);
+                auto lock = [&](void* p, size_t n) {
+                    if (hipHostRegister(p, n, hipHostRegisterPortable) == hipSuccess)
+                        reg.done.push_back(p);
+                    else
+                        (void)hipGetLastError();
+                };
+                for (int v = 0; v < 3 && !reg.stop; v++) lock(fptr[v], fbytes);
+                for (int k = 0; k < SPLASH_NOUT && !reg.stop; k++)
+                    if (out->out[k]) lock(out->out[k], bytes_each);
+            });
+        }
+    }
     if (nw == 1) {
         run(0);
     } else {
