@@ -824,6 +824,10 @@ namespace {
 
 struct DevBuf {
     void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p) { o.p = nullptr; }
     ~DevBuf() { pool_free(p); }
     hipError_t alloc(size_t bytes) { return pool_alloc(&p, bytes ? bytes : 8); }
     template <class T>
@@ -984,6 +988,9 @@ void parallel_rows(size_t n, size_t bytes_per_row, F fn)
 
 struct Stream {
     hipStream_t s = nullptr;
+    Stream() = default;
+    Stream(const Stream&) = delete;
+    Stream(Stream&& o) noexcept : s(o.s) { o.s = nullptr; }
     ~Stream()
     {
         if (s) {
@@ -995,6 +1002,9 @@ struct Stream {
 };
 struct Event {
     hipEvent_t e = nullptr;
+    Event() = default;
+    Event(const Event&) = delete;
+    Event(Event&& o) noexcept : e(o.e) { o.e = nullptr; }
     ~Event()
     {
         if (e) (void)hipEventDestroy(e);
@@ -1013,10 +1023,6 @@ struct Pool {
     double* sw() const { return force.as<double>(); }
 };
 
-// One lane of the pipeline: a host thread with its own stream, block buffers and spin-up workspace.
-// Lanes take the blocks in turn; while one lane's thread sits in a host<->device copy the other
-// lane's kernels have the GPU, so H2D of block k+1, the kernels of block k and D2H of block k-1
-// overlap (the SOCK cluster of R/splash.grid.R:359-400 overlapped its workers the same way).
 // host staging without the value-initialisation of std::vector (zero-filling ~0.5 GB per call is
 // 0.1 s of page faults on the calling thread; the gather threads touch the pages anyway)
 template <class T>
@@ -1033,6 +1039,10 @@ struct HostBuf {
     T& operator[](size_t i) const { return p[i]; }
 };
 
+// One lane of the pipeline: a host thread with its own stream, block buffers and spin-up workspace.
+// Lanes take the blocks in turn; while one lane's thread sits in a host<->device copy the other
+// lane's kernels have the GPU, so H2D of block k+1, the kernels of block k and D2H of block k-1
+// overlap (the SOCK cluster of R/splash.grid.R:359-400 overlapped its workers the same way).
 struct Lane {
     DevBuf d_force, d_f32, d_out, d_par, d_state, d_stat, d_tt, d_pass, d_swork, d_basin, d_res, d_late;
     HostBuf<double> stage, stage_out, hstat, hsmall;
@@ -1134,7 +1144,11 @@ int Worker::run_lane(int li)
             if (run_block(L, k)) break;
         }
         if (L.d2h.joinable()) L.d2h.join();
-        if (L.d2h_rc && !L.rc) L.rc = L.d2h_rc;
+        if (L.d2h_rc && !L.rc) {
+            L.rc = L.d2h_rc;
+            snprintf(L.msg, sizeof L.msg, "device->host copy of a block's results failed");
+            abort = true;
+        }
     }
     {
         std::lock_guard<std::mutex> lk(mu);
