@@ -359,7 +359,7 @@ def run_resident(ctx):
     kind = 'flat' if flat else 'slope/aspect + lateral flow'
     if world == 1:
         split = "one GPU"
-        mode = "weak"
+        mode = args.scaling  # what --gpus N would do with the same flags: the label is the same at every N
     elif strong:
         split = (f"split over {world} GPUs: row blocks of {cr_eff} rows dealt round-robin, {n // W} rows "
                  f"({n} cells) per GPU")

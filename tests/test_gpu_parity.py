@@ -1071,7 +1071,8 @@ def test_bench_line_keeps_the_contract():
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["unit"] == "cell-days/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
-    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    # the default splits THE grid over the ranks of --gpus N (total work fixed): the label says so at every N
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["scaling"] == "strong" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
