@@ -26,9 +26,14 @@ for g in range(ng):
     r2 = trajectory_summary(o, p)
     msg += ["trajectory: " + v[:300] for v in r2["violations"]]
     bad += len(msg)
-    print(json.dumps({"grid": g, "seed": seed, "one_step": {k: v for k, v in r1.items() if not hasattr(v, "shape")},
+    def bulk(prof):  # worst share of a series' cell-days beyond 1e-9 / 1e-7 (the levels assert_bulk holds)
+        return {} if not prof else {"beyond_1e-9": max(v["beyond_1e_9"] / v["n"] for v in prof.values()),
+                                    "beyond_1e-7": max(v["beyond_1e_7"] / v["n"] for v in prof.values())}
+    b1, b2 = bulk(r1.pop("profile", None)), bulk(r2.get("profile"))
+    print(json.dumps({"grid": g, "seed": seed, "bulk_one_step": b1, "bulk_trajectory": b2,
+                      "one_step": {k: v for k, v in r1.items() if not hasattr(v, "shape")},
                       "trajectory": {k: r2[k] for k in ("set_aside_cell_days", "critical_event_cells",
                                                          "critical_event_cells_that_differ", "max_abs_dwn_mm")},
-                      "problems": msg}, default=str)[:900], flush=True)
+                      "problems": msg}, default=str)[:1400], flush=True)
 print(json.dumps({"grids": ng, "problems": bad}))
 sys.exit(1 if bad else 0)
