@@ -237,8 +237,16 @@ __device__ __forceinline__ bool same_bits(double a, double b)
 // wavefronts whose every instruction is latency: there the twenty instructions (one reciprocal) and
 // the scalar load saved per day step are worth far more than the bytes (measured on the tail:
 // 1 272 ms with compact records, 1 160 ms with rich ones).
+// Compact records are laid out field by field ([day][field][slot]: the 64 lanes of a wavefront read
+// 512 contiguous bytes per field -- phase 0 is a stream over every cell).  Rich records are laid out
+// record by record ([day][slot][20 words], the 20th is padding): a lane reads its 160 contiguous bytes
+// with ten 16-byte loads off ONE address instead of nineteen 8-byte loads off nineteen -- 57 fewer
+// instructions per day step (the address arithmetic was 34 scalar and 17 vector instructions), which
+// is what counts where a lone wavefront pays for every instruction; coalescing is no concern there.
 constexpr int kNRecCompact = kNTermWords + 2;
-constexpr int kNRecRich = kNRecCompact + 4;
+constexpr int kNRecRich = kNRecCompact + 4; // (words that carry data; kRichStride in memory)
+static_assert(kNRecRich <= 20, "rich record");
+constexpr int kRichStride = 20; // words per rich record in memory (16-byte aligned pairs)
 struct DayRecord {
     DayTerms T;
     ViscTerms V;
@@ -248,16 +256,21 @@ template <bool RICH>
 __device__ __forceinline__ void rec_store(double* __restrict__ base, size_t cap, int day, size_t slot,
                                           const DayRecord& r)
 {
-    constexpr int NR = RICH ? kNRecRich : kNRecCompact;
-    double* p = base + ((size_t)day * NR) * cap + slot;
     // the viscosity is a float: its 32 bits and the melt flag share one word, exactly
     const unsigned long long vw = (unsigned long long)__float_as_uint((float)r.T.visc) |
                                   ((unsigned long long)(r.T.warm ? 1u : 0u) << 32);
-    const double v[kNRecRich] = {r.T.ru, r.T.ruv, r.T.hs, r.T.sin_hs, r.T.xrw, r.T.rnl, r.T.s, r.T.g,
-                                 r.T.econ, r.T.inv_econ, r.T.eetc, r.T.pw, __longlong_as_double((long long)vw),
-                                 r.rain, r.snf, r.T.rv, r.V.ipk, r.V.kv, r.V.ikv24};
+    const double v[kRichStride] = {r.T.ru, r.T.ruv, r.T.hs, r.T.sin_hs, r.T.xrw, r.T.rnl, r.T.s, r.T.g,
+                                   r.T.econ, r.T.inv_econ, r.T.eetc, r.T.pw, __longlong_as_double((long long)vw),
+                                   r.rain, r.snf, r.T.rv, r.V.ipk, r.V.kv, r.V.ikv24, 0.0};
+    if constexpr (RICH) {
+        double2* p = reinterpret_cast<double2*>(base + ((size_t)day * cap + slot) * kRichStride);
 #pragma unroll
-    for (int k = 0; k < NR; k++) p[(size_t)k * cap] = v[k];
+        for (int k = 0; k < kRichStride / 2; k++) p[k] = double2{v[2 * k], v[2 * k + 1]};
+    } else {
+        double* p = base + ((size_t)day * kNRecCompact) * cap + slot;
+#pragma unroll
+        for (int k = 0; k < kNRecCompact; k++) p[(size_t)k * cap] = v[k];
+    }
 }
 // Loading is split from decoding: the words of tomorrow's record are requested a day ahead and must
 // not be touched before tomorrow (anything computed from them at the point of the load -- the
@@ -265,16 +278,25 @@ __device__ __forceinline__ void rec_store(double* __restrict__ base, size_t cap,
 // full memory round trip per day: +17 % on the tail when this was one function).
 template <bool RICH>
 struct RawRecord {
-    double v[RICH ? kNRecRich : kNRecCompact];
+    double v[RICH ? kRichStride : kNRecCompact];
 };
 template <bool RICH>
 __device__ __forceinline__ RawRecord<RICH> rec_load(const double* __restrict__ base, size_t cap, int day, size_t slot)
 {
-    constexpr int NR = RICH ? kNRecRich : kNRecCompact;
-    const double* p = base + ((size_t)day * NR) * cap + slot;
     RawRecord<RICH> w;
+    if constexpr (RICH) {
+        const double2* p = reinterpret_cast<const double2*>(base + ((size_t)day * cap + slot) * kRichStride);
 #pragma unroll
-    for (int k = 0; k < NR; k++) w.v[k] = p[(size_t)k * cap];
+        for (int k = 0; k < kRichStride / 2; k++) {
+            const double2 x = p[k];
+            w.v[2 * k] = x.x;
+            w.v[2 * k + 1] = x.y;
+        }
+    } else {
+        const double* p = base + ((size_t)day * kNRecCompact) * cap + slot;
+#pragma unroll
+        for (int k = 0; k < kNRecCompact; k++) w.v[k] = p[(size_t)k * cap];
+    }
     return w;
 }
 // Compact: rv = cos(delta) * kb of the record's day (one multiplication of a per-day scalar and a cell
@@ -1880,7 +1902,7 @@ hipError_t launch_diag_finalize(const long long* acc, int n_rec, double* diag, d
 }
 
 size_t spin_cache_bytes_per_slot() { return (size_t)365 * kNRecCompact * sizeof(double); }
-size_t spin_cache_rich_cap(size_t cap) { return (cap * kNRecCompact / kNRecRich) & ~(size_t)63; }
+size_t spin_cache_rich_cap(size_t cap) { return (cap * kNRecCompact / kRichStride) & ~(size_t)63; }
 size_t visc_table_floats_r() { return (size_t)kViscNR * 8; }
 hipError_t launch_visc_tables(float* rtab, hipStream_t s)
 {

@@ -78,7 +78,7 @@ struct SpinPhaseArgs {
     int readback;           // 1: the read-back kernel (every job's records are in the cache already)
     int no_queue;           // 1: park unfinished jobs without queueing them (a launch over the same
                             //    cells follows and does the queueing)
-    int rich;               // 1: the cache holds 19-word records (cache_cap = spin_cache_rich_cap of the
+    int rich;               // 1: the cache holds rich records, 20 words each, record by record (cache_cap = spin_cache_rich_cap of the
                             //    workspace's capacity), see splash_kernels.hip "Two layouts"
 };
 size_t spin_cache_bytes_per_slot(); // compact records
