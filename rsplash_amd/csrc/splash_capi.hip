@@ -1073,7 +1073,6 @@ struct Worker {
     size_t blocks_gathered = 0; // blocks whose early phases and gather are enqueued
     int lanes_done = 0;
     std::atomic<bool> abort{false};
-    std::atomic<bool> prefaulted{false};
     bool trace;
     // what finish_pool brings back for patch_pool
     uint32_t n_pool = 0;
@@ -1306,8 +1305,10 @@ int Worker::run_block(Lane& L, size_t k)
     // The kernels of this block are queued; while they run, map the caller's (typically freshly
     // allocated) output arrays: the first touch of tens of GB is otherwise paid page by page inside
     // the device-to-host copies.
-    if (P.dense && !prefaulted.exchange(true))
-        prefault_outputs(out->out, SPLASH_NOUT, N, P.idx[v0], v1 - v0, (size_t)nt_out);
+    // Only THIS block's columns (the rows' segments [c0, c0 + nb)): the other lane may be delivering a
+    // neighbouring block's results at this moment, and a page-touching write outside the block's own
+    // columns would race with them.
+    if (P.dense) prefault_outputs(out->out, SPLASH_NOUT, N, c0, nb, (size_t)nt_out);
     const double t_c = now_s();
     LANE_TRY(hipStreamSynchronize(s));
     const double t_d = now_s();
