@@ -51,6 +51,13 @@ def test_no_gpu_means_loud_failure(bourne):
         api.SPLASH.moist_surf(1.0, 10.0, -800.0, 150.0, 250.0, 20.0, 0.37)
     with pytest.raises(api.SplashError):
         api.Calendar(b["doy"], b["year"], b["month"])
+    # the two halves of the grid call (ABI 3) refuse at submit time, before any thread is started
+    n, nt = 4, len(b["dates"])
+    tile = lambda x: np.repeat(np.asarray(x, dtype=np.float64)[:, None], n, axis=1)
+    with pytest.raises(api.SplashError, match="no HIP device"):
+        api.splash_grid(tile(b["sw_in"]), tile(b["Ta"]), tile(b["P"]), np.full(n, s["elev_m"]),
+                        np.repeat(np.asarray(b["soil"], dtype=np.float64)[:, None], n, axis=1),
+                        np.full(n, s["latitude"]), np.zeros(n), np.zeros(n), time_index=b["dates"], submit=True)
 
 
 def test_time_fields_and_month_ids(bourne):
