@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPLASH_ABI_VERSION 3
+#define SPLASH_ABI_VERSION 4
 
 enum {
     SPLASH_OK = 0,
@@ -69,6 +69,9 @@ const char* splash_hip_last_error(void);      /* thread-local text of the last f
  * costs seconds); this returns the idle ones to the runtime.  SPLASH_HIP_NO_POOL=1 in the
  * environment disables the retention altogether. */
 void splash_hip_release_cache(void);
+/* bytes of `device` the library's buffer cache holds (in use + idle) and the idle part alone; after a
+ * call has returned everything it held is idle again (tests check that no buffer is lost) */
+int splash_hip_cache_stats(int device, size_t* held_bytes, size_t* idle_bytes);
 
 /* ---------------------------------------------------------------- calendar ---------------- */
 /* Per-day tables shared by all cells: orbit terms (src/SOLAR.cpp:98-124, 291-374), the month
@@ -335,6 +338,13 @@ typedef struct {
     double* aux;              /* optional [4][ncell]: Tt, AI, passes1, passes2 */
     int64_t* diag_acc;        /* optional: the exact limbs behind diag, [n_basin][nmonth][SPLASH_NDIAG+1][2],
                                  for callers that sum over several calls or ranks */
+    /* (ABI 4) opt-in single-precision transport of the results: series k is delivered to out_f32[k]
+     * (caller-allocated [nt_out][ncell] float) instead of out[k], which must then be NULL.  The
+     * arithmetic stays FP64; each value is rounded to the nearest float on the device, i.e. the array
+     * holds exactly (float)x of what out[k] would have held -- what the reference's output bricks
+     * store anyway (datatype FLT4S, R/splash.grid.R:186-216).  Halves the device->host bytes, which
+     * bound a call with daily outputs.  All NULL = the default: double precision. */
+    float* out_f32[SPLASH_NOUT];
 } splash_grid_out;
 
 /* splash.grid's inner computation for a block of cells (R/splash.grid.R:277-308): every cell gets

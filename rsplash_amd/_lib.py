@@ -32,7 +32,7 @@ class Opts(C.Structure):
 
 class GridOut(C.Structure):
     _fields_ = [("out", _dp * NOUT), ("state_end", _dp), ("diag", _dp), ("aux", _dp),
-                ("diag_acc", _lp)]
+                ("diag_acc", _lp), ("out_f32", _fp * NOUT)]
 
 
 class DevOut(C.Structure):
@@ -68,6 +68,7 @@ def _load():
     L.splash_hip_device_count.restype = C.c_int
     L.splash_hip_last_error.restype = C.c_char_p
     L.splash_hip_release_cache.restype = None
+    L.splash_hip_cache_stats.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.splash_calendar_create.argtypes = [C.c_int, _ip, _ip, _ip, C.POINTER(_vp), C.c_char_p, C.c_size_t]
     L.splash_calendar_destroy.argtypes = [_vp]
     L.splash_calendar_destroy.restype = None
@@ -142,7 +143,7 @@ lib = _load()
 # every symbol include/splash_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
     "splash_hip_abi_version", "splash_hip_device_count", "splash_hip_last_error",
-    "splash_hip_release_cache",
+    "splash_hip_release_cache", "splash_hip_cache_stats",
     "splash_calendar_create", "splash_calendar_destroy", "splash_calendar_nt",
     "splash_calendar_nmonth", "splash_calendar_orbit", "splash_orbit_day", "splash_dev_soil_hydro",
     "splash_dev_snow_threshold", "splash_dev_spin_up_work_size", "splash_dev_spin_up",

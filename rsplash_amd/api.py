@@ -35,6 +35,13 @@ def device_count():
     return lib.splash_hip_device_count()
 
 
+def cache_stats(device=0):
+    """(held, idle) bytes of the library's device-buffer cache on `device`"""
+    held, idle = C.c_size_t(0), C.c_size_t(0)
+    check(lib.splash_hip_cache_stats(int(device), C.byref(held), C.byref(idle)), "splash_hip_cache_stats")
+    return held.value, idle.value
+
+
 def orbit_day(doy, year):
     """(dr, sin delta, cos delta) of one calendar day -- host-only, no GPU needed"""
     v = [C.c_double() for _ in range(3)]
@@ -106,7 +113,7 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
                 time_index=None, sim_control=None, outputs=OUT_NAMES, device=0,
                 max_cells_per_launch=0, want_aux=False, want_diag=False, outdir=None, lon=None,
                 basin=None, n_basin=0, devices=None, out=None, want_state=True, submit=False,
-                mem_fraction=0.0):
+                mem_fraction=0.0, out_dtype=np.float64):
     """R/splash.grid.R:28 on arrays.  sw_in/tc/pn: [nt, ncell] (or [nt, H, W]) daily rasters;
     elev/lat/slop/asp: [ncell]; soil: [6, ncell]; Au: [3, ncell] (area, ncellin, ncellout) or
     None.  The static rasters the reference derives with raster/GDAL/TauDEM (lat, slope, aspect,
@@ -122,8 +129,11 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     basin/n_basin: optional integer basin id per cell -> want_diag totals per basin
     ([n_basin, nmonth] per quantity).  devices: list of HIP ordinals to split the cells over inside
     the one call (one host thread per entry; the same ordinal may repeat).
-    out: dict name -> preallocated float64 array [nt_out, ...] to receive that series (what an R
+    out: dict name -> preallocated array [nt_out, ...] of `out_dtype` to receive that series (what an R
     caller's allocMatrix is); series not in `out` are allocated here.
+    out_dtype=np.float32: single-precision transport of the results (splash_grid_out.out_f32): every
+    value is rounded to the nearest float on the device -- what the reference's FLT4S bricks hold,
+    R/splash.grid.R:186-216 -- which halves the device->host bytes; the arithmetic is FP64 either way.
     submit=True: splash_grid_submit -- the call runs on its own host thread and streams; a GridJob
     comes back at once and its wait() returns what this function would have (a host loop over row
     blocks keeps two or more in flight, each with its mem_fraction of the device's free memory)."""
@@ -169,16 +179,22 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     nm = int(month_ids(year, month)[-1]) + 1
     nt_out = nm if monthly else nt
     res = {}
+    odt = np.dtype(out_dtype)
+    if odt not in (np.dtype(np.float64), np.dtype(np.float32)):
+        raise ValueError("out_dtype must be float64 or float32")
     for k in outputs:
         a = out.get(k) if out else None
         if a is None:
-            a = np.empty((nt_out,) + shp)
-        elif a.shape != (nt_out,) + shp or a.dtype != np.float64 or not a.flags.c_contiguous:
-            raise ValueError(f"out[{k!r}] must be a C-contiguous float64 array of shape {(nt_out,) + shp}")
+            a = np.empty((nt_out,) + shp, odt)
+        elif a.shape != (nt_out,) + shp or a.dtype != odt or not a.flags.c_contiguous:
+            raise ValueError(f"out[{k!r}] must be a C-contiguous {odt} array of shape {(nt_out,) + shp}")
         res[k] = a
     gout = _lib.GridOut()
     for i, k in enumerate(OUT_NAMES):
-        gout.out[i] = res[k].ctypes.data_as(_dp) if k in res else None
+        if odt == np.float64:
+            gout.out[i] = res[k].ctypes.data_as(_dp) if k in res else None
+        else:
+            gout.out_f32[i] = res[k].ctypes.data_as(C.POINTER(C.c_float)) if k in res else None
     state_end = None
     if want_state:
         state_end = np.empty((NSTATE,) + shp)
@@ -214,22 +230,56 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
 
 
 class GridJob:
-    """a splash_grid call in flight (splash_grid_submit); wait() -> the results dict"""
+    """a splash_grid call in flight (splash_grid_submit); wait() -> the results dict.
 
-    def __init__(self, job, keep, finish):
+    The library's thread reads the forcing arrays and writes the result arrays until splash_grid_wait
+    returns (include/splash_hip.h), so the job keeps them alive (`_keep`) and NEVER lets go of them
+    before it has waited: close() (also the context manager's exit and the finaliser) waits for a job
+    that was not waited for and discards its outcome -- e.g. the second of two jobs in flight when the
+    first one's wait() raised.  r/splash_shim.c's grid_handle_finalizer does the same for R."""
+
+    def __init__(self, job, keep, finish, wait_fn=None):
         self._job, self._keep, self._finish = job, keep, finish
+        self._wait_fn = wait_fn or lib.splash_grid_wait   # (injectable: the CPU test has no device)
 
     def wait(self):
         if self._job is None:
-            raise SplashError("GridJob.wait() called twice")
+            raise SplashError("GridJob.wait() called twice (or after close())")
         err = C.create_string_buffer(512)
-        rc = lib.splash_grid_wait(self._job, err, 512)
-        self._job = None
+        job, self._job = self._job, None
+        try:
+            rc = self._wait_fn(job, err, 512)
+        finally:
+            finish, self._finish = self._finish, None
         if rc:
+            self._keep = None   # the library is done with the arrays whatever the outcome
             raise SplashError(f"splash_grid_run failed ({rc}): {err.value.decode()}")
-        r = self._finish()
+        r = finish()
         self._keep = None
         return r
+
+    def close(self):
+        """wait for a job nobody waited for (its result is dropped), then release the arrays"""
+        job, self._job = self._job, None
+        if job is not None:
+            try:
+                self._wait_fn(job, None, 0)
+            finally:
+                self._finish = None
+        self._keep = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown: nothing left to report to
+            pass
 
 
 def _grid_results(res, shp, lat, lon, outdir, time_index, monthly, want_state, state_end, want_aux, aux,

@@ -1,0 +1,114 @@
+// splash_host.hpp -- what the translation units of the host side share: error reporting, the
+// per-device buffer pool, the calendar's layout and the spin-up's phase driver.
+//   splash_capi.hip       the C ABI's small entry points: calendar, device-resident stages, module
+//                         mirrors, static rasters, unSWC, the buffer pool
+//   splash_grid_host.hip  splash_grid_run / _submit / _wait: the pipelined host-buffer path
+//                         (Worker / Lane / Pool) that stands where R/splash.grid.R:260-314, 359-400 stand
+// Nothing here is part of the ABI (include/splash_hip.h is).
+#pragma once
+#include "../../include/splash_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "splash_kernels.hpp"
+
+namespace splash {
+namespace host {
+
+// text of the calling thread's last failure (splash_hip_last_error)
+extern thread_local std::string g_err;
+int fail(int code, char* err, size_t errlen, const char* fmt, ...) __attribute__((format(printf, 4, 5)));
+int need_device(char* err, size_t errlen);
+
+// device buffers of the host-buffer entry points are kept between calls (splash_capi.hip)
+hipError_t pool_alloc(void** out, size_t bytes);
+void pool_free(void* p);
+size_t pool_idle_bytes(int dev);
+size_t pool_held_bytes(int dev);
+std::recursive_mutex& device_alloc_mutex(int dev);
+int visc_tables(ViscTables& vt);
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes)
+    {
+        o.p = nullptr;
+        o.bytes = 0;
+    }
+    ~DevBuf() { pool_free(p); }
+    // a buffer that is already held is returned first: alloc() may be called again (a larger request,
+    // or once per block) without leaking the slot it held
+    hipError_t alloc(size_t n)
+    {
+        if (p) {
+            pool_free(p);
+            p = nullptr;
+            bytes = 0;
+        }
+        hipError_t e = pool_alloc(&p, n ? n : 8);
+        if (e == hipSuccess) bytes = n ? n : 8; else p = nullptr;
+        return e;
+    }
+    // keeps the buffer when it is large enough already
+    hipError_t reserve(size_t n) { return (p && bytes >= n) ? hipSuccess : alloc(n); }
+    template <class T>
+    T* as() const
+    {
+        return (T*)p;
+    }
+};
+
+inline bool isnan_d(double x) { return x != x; }
+
+// the kernels address a launch's cells with 32-bit byte offsets from uniform row bases
+constexpr size_t kMaxCellsPerLaunch = (1ull << 29) - 1;
+
+// phases of the spin-up (see k_spin_phase): all but the last finish all but a few cells per
+// thousand, the last is the long tail
+constexpr int kSpinPhases = 8;
+size_t spin_work_layout(size_t ncell, size_t* o_wl_b, size_t* o_meta, size_t* o_ai, size_t* o_cnt,
+                        size_t* o_cache = nullptr, size_t* o_pend = nullptr);
+int spin_phases(const splash_calendar* cal, size_t ncell, const double* sw_in, const double* tc,
+                const double* pn, size_t ldf, const double* Tt, double* cellpar, size_t ldp,
+                double* state, size_t lds, int* passes, void* work, void* stream, int ph0, int ph1);
+
+} // namespace host
+} // namespace splash
+
+struct splash_calendar {
+    int nt = 0, nmonth = 0, device = 0;
+    std::vector<splash::DayRec> host;
+    splash::DayRec* dev = nullptr;
+    // spin-up table (nt >= 365 only): the reference spins up on quick_run(i+1, y[1], ...) --
+    // day-of-year 1..365 of the FIRST year whatever date the series starts on (src/SPLASH.cpp:1658,
+    // 1674; R/splash.point.R:141-152) -- while the rain/snow split of those 365 records keeps the
+    // months of their real dates (R/splash.point.R:124-128 runs before the spin-up)
+    std::vector<splash::DayRec> spin_host;
+    splash::DayRec* spin_dev = nullptr;
+};
+
+#define HIP_TRY(expr, err, errlen)                                                          \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return fail(e__ == hipErrorOutOfMemory ? SPLASH_ENOMEM                          \
+                        : (e__ == hipErrorNoDevice || e__ == hipErrorInvalidDevice)         \
+                            ? SPLASH_ENODEV                                                 \
+                            : SPLASH_EHIP,                                                  \
+                        err, errlen, "%s: %s", #expr, hipGetErrorString(e__));              \
+    } while (0)
+
+#define REQ(cond, msg)                                                   \
+    do {                                                                 \
+        if (!(cond)) return fail(SPLASH_EINVAL, nullptr, 0, "%s", msg);  \
+    } while (0)

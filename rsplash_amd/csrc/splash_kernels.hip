@@ -631,12 +631,21 @@ __global__ __launch_bounds__(64) void k_pool_reserve(PoolGatherArgs a)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t n = *a.n_cells;
-    const uint32_t base = atomicAdd(a.p_n, n);
     // all or nothing: a block whose stragglers do not all fit keeps them (the caller finishes them in
-    // place).  A reservation that overflows leaves the counter above the capacity until it is taken
-    // back, so nothing reserved in between can fit either: the slots handed out stay contiguous.
-    const uint32_t fit = ((size_t)base + n <= a.cap) ? n : 0;
-    if (fit < n) atomicSub(a.p_n, n);
+    // place).  The counter only ever moves by a reservation that fits (compare-and-swap), so the slots
+    // handed out are contiguous below it whatever the number of lanes reserving at once (an add that is
+    // taken back on overflow is not: with three lanes a reservation made between another's add and its
+    // subtraction could end up above the counter).
+    uint32_t base = *(volatile uint32_t*)a.p_n, fit = 0;
+    for (;;) {
+        if ((size_t)base + n > a.cap) break;
+        const uint32_t seen = atomicCAS(a.p_n, base, base + n);
+        if (seen == base) {
+            fit = n;
+            break;
+        }
+        base = seen;
+    }
     a.res[0] = base;
     a.res[1] = fit;
     a.res[2] = n;
@@ -1262,6 +1271,23 @@ __global__ __launch_bounds__(kBlock) void k_widen_f32(const float* __restrict__ 
 {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
         dst[i] = (double)__builtin_nontemporal_load(&src[i]);
+}
+
+// single-precision transport of result series (opt-in: splash_grid_out.out_f32): round to nearest even
+// on the device, two values per lane (8-byte stores); what the reference's FLT4S bricks hold
+__global__ __launch_bounds__(kBlock) void k_narrow_f32(const double* __restrict__ src, size_t n,
+                                                      float* __restrict__ dst)
+{
+    const size_t n2 = n / 2;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (size_t)gridDim.x * kBlock) {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const d2_t v = __builtin_nontemporal_load((const d2_t*)src + i);
+        float2 f;
+        f.x = (float)v.x;
+        f.y = (float)v.y;
+        ((float2*)dst)[i] = f;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = (float)src[n - 1];
 }
 
 // ================================================================ synthetic inputs =============
@@ -1915,6 +1941,15 @@ hipError_t launch_widen_f32(const float* src, size_t n, double* dst, hipStream_t
     if (n == 0) return hipSuccess;
     const size_t nb = (n + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)(nb < 65536 ? nb : 65536)), dim3(kBlock), 0, s, src,
+                       n, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_narrow_f32(const double* src, size_t n, float* dst, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const size_t nb = (n / 2 + kBlock - 1) / kBlock + 1;
+    hipLaunchKernelGGL(k_narrow_f32, dim3((unsigned)(nb < 65536 ? nb : 65536)), dim3(kBlock), 0, s, src,
                        n, dst);
     return hipGetLastError();
 }

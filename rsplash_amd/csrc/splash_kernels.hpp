@@ -181,6 +181,8 @@ hipError_t launch_flow_accumulation(int H, int W, const double* fd, const double
                                     const double* resolution, double* ups_ncell, double* ups_area,
                                     int* levels_out, hipStream_t s);
 hipError_t launch_widen_f32(const float* src, size_t n, double* dst, hipStream_t s);
+// src and dst 16- and 8-byte aligned (whole series of a block buffer are)
+hipError_t launch_narrow_f32(const double* src, size_t n, float* dst, hipStream_t s);
 hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, const double* sw,
                              const double* dr, const double* sd, const double* cd,
                              const double* sw_in, const double* tc, const double* slop,

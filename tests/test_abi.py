@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in include/splash_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.lib.splash_hip_abi_version() == 3
+    assert _lib.lib.splash_hip_abi_version() == 4
 
 
 def test_product_never_touches_the_oracle():
@@ -137,3 +137,56 @@ def test_r_wrapper_labels_results_positionally():
         got = re.findall(r'"([^"]*)"', m.group(1))
         if got[0] == "wn":
             assert got[:9] == key
+
+
+def test_grid_job_waits_before_it_lets_go_of_the_arrays():
+    """A GridJob dropped without wait() -- e.g. the second of two jobs in flight when the first one's
+    wait() raised -- must wait for the library's thread BEFORE the arrays it reads and writes are
+    released (include/splash_hip.h: every array stays valid until _wait returns).  No
+    device here: the wait function is injected and records the order of events."""
+    import gc
+    import weakref
+    from rsplash_amd import api
+
+    class Arr:   # stands for the numpy arrays the job keeps alive
+        pass
+    events = []
+
+    def make():
+        a = Arr()
+        weakref.finalize(a, lambda: events.append("arrays released"))
+
+        def wait_fn(job, err, errlen):
+            events.append("waited")
+            return 0
+        return api.GridJob(object(), (a,), lambda: {"ok": True}, wait_fn=wait_fn)
+
+    j = make()
+    del j
+    gc.collect()
+    assert events == ["waited", "arrays released"], events          # dropped: waited first
+    del events[:]
+    with make() as j:
+        pass
+    gc.collect()
+    assert events[:1] == ["waited"] and events.count("waited") == 1, events   # context manager: once
+    del events[:]
+    j = make()
+    assert j.wait() == {"ok": True}
+    with pytest.raises(api.SplashError):
+        j.wait()
+    j.close()
+    del j
+    gc.collect()
+    assert events == ["waited", "arrays released"], events          # waited once, not again by close/del
+
+    def failing(job, err, errlen):
+        events.append("waited")
+        return -3
+    del events[:]
+    j = api.GridJob(object(), (Arr(),), lambda: {}, wait_fn=failing)
+    with pytest.raises(api.SplashError):
+        j.wait()
+    del j
+    gc.collect()
+    assert events == ["waited"], events

@@ -1355,9 +1355,36 @@ def test_host_path_pipeline_lanes_pool_and_jobs_give_the_same_bits(api, oracle):
     ref = call()
     n_late = int((ref["aux"]["passes2"] > 28).sum())   # jobs the first seven phases (28 passes) leave
     assert n_late >= 3, n_late
-    env0 = {k: os.environ.get(k) for k in ("SPLASH_HIP_LANES", "SPLASH_HIP_POOL_CAP")}
+    knobs = ("SPLASH_HIP_LANES", "SPLASH_HIP_POOL_CAP", "SPLASH_HIP_PREFAULT", "SPLASH_HIP_PREFAULT_MIN_BYTES",
+             "SPLASH_HIP_REGISTER_MIN_BYTES", "SPLASH_HIP_BLOCKS_PER_LANE", "SPLASH_HIP_MIN_BLOCK_CELLS")
+    env0 = {k: os.environ.get(k) for k in knobs}
+    for k in knobs:
+        os.environ.pop(k, None)
     try:
         same(ref, call(max_cells_per_launch=1024), "6 blocks on 2 lanes")
+        # The code that only runs for BIG calls, at test size: the result
+        # pages mapped per block while its kernels run (>= 64 MiB per block by default), caller arrays
+        # page-locked by a helper thread while the first blocks load and compute (>= 8 GiB of results by
+        # default), and the library's own plan of four blocks per lane (grids > 2^20 cells by default).
+        # Outputs are handed over filled with a sentinel: every value must have been delivered.
+        os.environ["SPLASH_HIP_PREFAULT_MIN_BYTES"] = "0"
+        os.environ["SPLASH_HIP_REGISTER_MIN_BYTES"] = "0"
+        os.environ["SPLASH_HIP_MIN_BLOCK_CELLS"] = "512"
+        nt_out = nt
+        for mode in ("populate", "touch"):
+            os.environ["SPLASH_HIP_PREFAULT"] = mode
+            bufs = {k: np.full((nt_out, n), -12345.678) for k in ("wn", "ro", "pet", "aet", "snow", "cond", "bflow",
+                                                                   "netr", "sm_lim")}
+            g = call(out=bufs)    # the library's own blocking: 2 lanes x 4 blocks of 768 cells
+            same(ref, g, f"prefault={mode} + registered arrays + 4 blocks per lane")
+            assert all(g[k] is bufs[k] for k in bufs)
+        os.environ["SPLASH_HIP_BLOCKS_PER_LANE"] = "6"
+        os.environ["SPLASH_HIP_LANES"] = "3"
+        same(ref, call(), "prefault + registered arrays, 3 lanes x 6 blocks")
+        for k in ("SPLASH_HIP_PREFAULT", "SPLASH_HIP_PREFAULT_MIN_BYTES", "SPLASH_HIP_REGISTER_MIN_BYTES",
+                  "SPLASH_HIP_BLOCKS_PER_LANE", "SPLASH_HIP_MIN_BLOCK_CELLS"):
+            os.environ.pop(k)
+        os.environ["SPLASH_HIP_LANES"] = "2"
         os.environ["SPLASH_HIP_LANES"] = "1"
         same(ref, call(max_cells_per_launch=1024), "6 blocks on 1 lane")
         os.environ["SPLASH_HIP_LANES"] = "3"
@@ -1366,6 +1393,15 @@ def test_host_path_pipeline_lanes_pool_and_jobs_give_the_same_bits(api, oracle):
         os.environ["SPLASH_HIP_POOL_CAP"] = "2"       # fewer slots than stragglers: the fallback path
         same(ref, call(max_cells_per_launch=1024), "pool overflow")
         same(ref, call(), "pool overflow, one block")
+        # several overflowing blocks per lane: the lane's buffer for late cells is allocated once and
+        # goes back to the cache with the rest (it was re-allocated per block and the earlier
+        # ones stayed busy for the life of the process) -- after the call everything held is idle
+        os.environ["SPLASH_HIP_LANES"] = "4"          # and four lanes reserve pool slots at once (CAS)
+        same(ref, call(max_cells_per_launch=256), "pool overflow, 24 blocks on 4 lanes")
+        os.environ["SPLASH_HIP_LANES"] = "2"
+        same(ref, call(max_cells_per_launch=512), "pool overflow, 6 blocks per lane")
+        held, idle = api.cache_stats(0)
+        assert held == idle and held > 0, (held, idle)
         os.environ.pop("SPLASH_HIP_POOL_CAP")
         # two calls in flight on the same device, each with its share of the memory
         j1 = call(max_cells_per_launch=2048, submit=True, mem_fraction=0.4)
@@ -1459,3 +1495,113 @@ def test_host_path_out_of_memory_is_an_error_not_a_hang(api, oracle):
         os.environ.pop("SPLASH_HIP_FAKE_DEVICE_BYTES")
     g = api.splash_grid(*args, time_index=dates)
     assert np.isfinite(g["wn"]).all()
+
+
+@pytest.mark.gpu
+def test_prefault_touches_only_its_own_columns(api, oracle):
+    """Regression test for the race fixed by inspection in ff89765 (round 3).  While a block's kernels
+    run, its lane maps the caller's result pages.  The first version did that ONCE, from the first lane
+    to arrive, over the whole worker range -- columns [idx[v0], idx[v0] + (v1 - v0)) of every row -- by
+    storing a zero every 4 KiB, while the other lane's helper thread was delivering ITS block into the
+    same arrays: a delivered value could be overwritten.  Now a block touches columns [c0, c0 + nb), its
+    own, which nothing else writes before its own delivery (and by default it stores nothing at all:
+    madvise(MADV_POPULATE_WRITE)).
+    By construction, not by luck of timing: SPLASH_HIP_PREFAULT=touch selects the storing variant,
+    SPLASH_HIP_PREFAULT_DELAY_MS makes every lane sleep before it touches, so that the blocks handed out
+    before have been delivered by then.  With the old range (kept as fault injection behind
+    SPLASH_HIP_TEST_PREFAULT_WHOLE_RANGE, nothing a caller would set) the same call MUST come back
+    with overwritten values: the negative control shows that this test can see the bug."""
+    import os
+    H, W, nt = 48, 128, 365
+    n = H * W
+    doy, year, month, mid, nm = oracle.calendar(2001, nt)
+    st = oracle.synth_statics(777000, H, W, 0, n, 1)
+    sw, tc, pn = oracle.synth_forcing(777000, H, W, 0, n, 0, doy, st["lat"], st["elev"])
+    dates = np.datetime64("2001-01-01") + np.arange(nt)
+    names = ("wn", "ro", "pet", "aet", "snow")
+
+    def call(**kw):
+        bufs = {k: np.full((nt, n), -12345.678) for k in names}
+        return api.splash_grid(sw, tc, pn, st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"],
+                               st["resolution"], time_index=dates, sim_control=dict(monthly_out=False),
+                               outputs=names, out=bufs, want_state=False, **kw)
+
+    knobs = ("SPLASH_HIP_PREFAULT", "SPLASH_HIP_PREFAULT_MIN_BYTES", "SPLASH_HIP_PREFAULT_DELAY_MS",
+             "SPLASH_HIP_TEST_PREFAULT_WHOLE_RANGE", "SPLASH_HIP_LANES")
+    env0 = {k: os.environ.get(k) for k in knobs}
+    for k in knobs:
+        os.environ.pop(k, None)
+    try:
+        ref = call()                                   # one block, nothing touched (6 144 cells: below 64 MiB)
+        os.environ.update(SPLASH_HIP_PREFAULT="touch", SPLASH_HIP_PREFAULT_MIN_BYTES="0",
+                          SPLASH_HIP_PREFAULT_DELAY_MS="150", SPLASH_HIP_LANES="2")
+        g = call(max_cells_per_launch=768)             # 8 blocks on 2 lanes
+        for k in names:
+            assert np.array_equal(g[k].view(np.int64), ref[k].view(np.int64)), k
+        os.environ["SPLASH_HIP_TEST_PREFAULT_WHOLE_RANGE"] = "1"
+        bad = call(max_cells_per_launch=768)
+        n_diff = sum(int((bad[k].view(np.int64) != ref[k].view(np.int64)).sum()) for k in names)
+        cols = np.unique(np.concatenate([np.nonzero((bad[k].view(np.int64) != ref[k].view(np.int64)).any(axis=0))[0]
+                                         for k in names]))
+        print("negative control: old range overwrote", n_diff, "delivered values, in columns", cols[:12], "...")
+        assert n_diff > 0, "the fault injection did not reproduce the overwrite: the test has no teeth"
+    finally:
+        for k, v in env0.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.gpu
+def test_single_precision_result_transport_is_the_rounded_double(api, oracle):
+    """splash_grid_out.out_f32 (ABI 4, opt-in): the series arrive as floats rounded on the device.  Bit
+    for bit (float) of what the double-precision call delivers -- dense and masked grids, daily and
+    monthly, several blocks, the straggler pool and its overflow path (late cells are rounded on the
+    host) -- and asking for one series in both precisions is refused."""
+    import os
+    H, W, nt = 24, 128, 400
+    n = H * W
+    doy, year, month, mid, nm = oracle.calendar(2001, nt)
+    st = oracle.synth_statics(777000, H, W, 0, n, 1)
+    sw, tc, pn = oracle.synth_forcing(777000, H, W, 0, n, 0, doy, st["lat"], st["elev"])
+    dates = np.datetime64("2001-01-01") + np.arange(nt)
+
+    def call(elev=None, monthly=False, **kw):
+        return api.splash_grid(sw, tc, pn, st["elev"] if elev is None else elev, st["soil"], st["lat"], st["slop"],
+                               st["asp"], st["au"], st["resolution"], time_index=dates,
+                               sim_control=dict(monthly_out=monthly), **kw)
+
+    def same32(a64, a32, what):
+        for k in api.OUT_NAMES:
+            assert a32[k].dtype == np.float32, k
+            want = a64[k].astype(np.float32)
+            assert np.array_equal(want.view(np.int32), a32[k].view(np.int32)), (what, k)
+        assert np.array_equal(a64["state_end"].view(np.int64), a32["state_end"].view(np.int64)), what
+
+    env0 = {k: os.environ.get(k) for k in ("SPLASH_HIP_POOL_CAP",)}
+    try:
+        for monthly in (False, True):
+            ref = call(monthly=monthly)
+            same32(ref, call(monthly=monthly, out_dtype=np.float32), f"one block, monthly={monthly}")
+            same32(ref, call(monthly=monthly, out_dtype=np.float32, max_cells_per_launch=700),
+                   f"ragged blocks, monthly={monthly}")
+        os.environ["SPLASH_HIP_POOL_CAP"] = "2"
+        same32(ref, call(monthly=True, out_dtype=np.float32, max_cells_per_launch=1024), "pool overflow")
+        os.environ.pop("SPLASH_HIP_POOL_CAP")
+        elev = st["elev"].copy()
+        elev[::5] = np.nan
+        m64, m32 = call(elev=elev, max_cells_per_launch=900), call(elev=elev, max_cells_per_launch=900,
+                                                                  out_dtype=np.float32)
+        ok = ~np.isnan(elev)
+        for k in api.OUT_NAMES:
+            assert np.array_equal(m64[k][:, ok].astype(np.float32).view(np.int32), m32[k][:, ok].view(np.int32)), k
+            assert np.isnan(m32[k][:, ~ok]).all(), k
+    finally:
+        for k, v in env0.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    with pytest.raises(ValueError):       # a caller's array must have the dtype asked for
+        call(out=dict(wn=np.empty((nt, n))), out_dtype=np.float32)
