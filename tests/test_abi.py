@@ -190,3 +190,33 @@ def test_grid_job_waits_before_it_lets_go_of_the_arrays():
     del j
     gc.collect()
     assert events == ["waited"], events
+
+
+def test_r_shim_syntax_and_registration():
+    """r/splash_shim.c has never met R's headers in this image (no R).  It is put through
+    `gcc -fsyntax-only -Wall -Wextra` against DECLARATIONS-ONLY headers of our own
+    (tests/csrc/r_decls: the ~30 functions of R's public C API the shim uses, with their documented
+    signatures) and the real include/splash_hip.h, so that a typo, a wrong arity or a wrong argument
+    type in the submit/_wait/finalizer code cannot ship; and the arities in its registration table must
+    be those of the definitions (R checks them at .Call time: src/RcppExports.cpp:9-25 is what the
+    table replaces).  Syntax-checked, not run."""
+    import subprocess
+    shim = os.path.join(ROOT, "r", "splash_shim.c")
+    r = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-cast-function-type",
+                        "-I" + os.path.join(ROOT, "tests", "csrc", "r_decls"), "-I" + os.path.join(ROOT, "include"), shim],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    txt = re.sub(r"/\*.*?\*/", "", open(shim).read(), flags=re.S)
+    defs = {m.group(1): m.group(2).count("SEXP") for m in re.finditer(r"^SEXP (C_\w+)\(([^)]*)\)\s*\{", txt, re.M)}
+    table = {m.group(1): int(m.group(2)) for m in re.finditer(r'\{"(C_\w+)", \(DL_FUNC\)&\1, (\d+)\}', txt)}
+    assert table and table == defs, (table, defs)
+    # every entry point the R wrapper calls is registered
+    wrapper = open(os.path.join(ROOT, "r", "splash_hip.R")).read()
+    for name in set(re.findall(r'\.Call\("(C_\w+)"', wrapper)):
+        assert name in table, name
+    # and the negative control: a wrong arity is caught
+    bad = txt.replace("R_ClearExternalPtr(ptr);", "R_ClearExternalPtr(ptr, 1);")
+    assert bad != txt
+    r = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", "-I" + os.path.join(ROOT, "tests", "csrc", "r_decls"),
+                        "-I" + os.path.join(ROOT, "include"), "-"], input=bad, capture_output=True, text=True)
+    assert r.returncode != 0
