@@ -144,12 +144,17 @@ def main():
         if world > 1:
             dist.init_process_group("gloo")
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        ctx_collective = None
         if world > 1:
             dist.all_reduce(t)
+            ctx_collective = collective_info(dist, t.numel() * t.element_size())
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"dryrun": True, "n_gpus": world, "sum_of_ranks": float(t.item())}))
+            line = {"dryrun": True, "n_gpus": world, "sum_of_ranks": float(t.item())}
+            if world > 1:
+                line["collective"] = ctx_collective
+            print(json.dumps(line))
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -179,6 +184,13 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def collective_info(dist, nbytes):
+    """what the process group itself says (the driver checks that the backend saw N ranks: `n_gpus` alone
+    is WORLD_SIZE from the environment)"""
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank0_of": dist.get_rank(),
+            "op": "all_reduce(sum) of the int64 water-balance limbs, once per step", "bytes": int(nbytes)}
 
 
 def allreduce_(ctx, t, op=None):
@@ -375,6 +387,8 @@ def run_resident(ctx):
                       "timed": "K2 snow threshold + K5 run_all + K7 monthly water-balance totals "
                                "(+ all-reduce), inputs resident in HBM"})
     line["config"].pop("scaling", None)
+    if world > 1:
+        line["collective"] = collective_info(ctx["dist"], acc.numel() * acc.element_size())
     line["roofline"] = roofline(avg_launch_s, units_per_launch, f"{brows}x{W}x{nt}", "k_run_all<daily,diag>")
     # both spin-ups of every cell + one transient pass: what a whole splash.grid call costs.
     # Measured as the library runs it for a host caller: the spin-up's long tail (a few cells per
@@ -401,8 +415,12 @@ def run_resident(ctx):
                         par_i[:, c0:], n, state[:, c0:], n, outb, bn, monthly=False, diag_acc=acc,
                         stream=sp, skip=mask_p + c0)
     s2.wait_event(e_begin)
+    e_t0, e_t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e_t0.record(s2)
     api.dev_spin_up_finish(cal, n, sw, tc, pn, n, Tt, par_i, n, state, n, work, stream=s2.cuda_stream)
+    e_t1.record(s2)
     torch.cuda.synchronize()
+    tail_s = e_t0.elapsed_time(e_t1) / 1e3
     n_late = api.dev_spin_up_pending_count(work, n, sp)
     for k0 in range(0, n_late, late_cap):
         nl = min(late_cap, n_late - k0)
@@ -422,7 +440,12 @@ def run_resident(ctx):
     allreduce_(ctx, sp_all, ctx["dist"].ReduceOp.MAX)
     spinup_max = float(sp_all.item())
     line["value_inclusive"] = cell_days_step / incl
-    line["inclusive"] = {"seconds": incl, "late_cells": n_late,
+    tail_t = torch.tensor([tail_s], dtype=torch.float64, device=dev)
+    allreduce_(ctx, tail_t, ctx["dist"].ReduceOp.MAX)
+    line["inclusive"] = {"seconds": incl, "late_cells": n_late, "tail_seconds": float(tail_t.item()),
+                         "tail_note": "the spin-up's last phase (splash_dev_spin_up_finish): one cell's chain of up to "
+                                      "1000 passes x 365 sequential day steps on a lone wavefront; constant PER RANK, "
+                                      "it does not shrink when the grid is split over more GPUs (DESIGN.md 7)",
                          "note": "spin-up + one transient pass of every cell with outputs, the spin-up's tail on "
                                  "a second stream overlapped with the transient pass (as splash_grid_run does it)"}
     line["spinup"] = {"seconds": spinup_max, "cells": n,
@@ -436,63 +459,125 @@ def run_resident(ctx):
     # rank 0 (at any N): CPU baseline on a bounded sample of ITS cells + the parity figures of the same
     # sample; the other ranks wait at the barrier so that the group is torn down together
     if rank == 0 and args.cpu_seconds > 0:
-        cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp)
+        cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp, W, chunks, Htot)
     if world > 1:
         ctx["dist"].barrier()
     cal.close()
     return line
 
 
-def cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp):
+def sample_bands(n, W, cells_wanted, nbands=8):
+    """[(first local cell, cells)] of `nbands` bands of whole grid rows spread evenly over the rank's rows
+    (first band = its first rows, last band = its last rows), cells_wanted cells in all"""
+    rows = n // W
+    rb = max(1, cells_wanted // (nbands * W))
+    if rows < 2 * nbands * rb or n % W:
+        return [(0, min(n, max(W, cells_wanted - cells_wanted % 64)))]
+    return [(int(round(i * (rows - rb) / (nbands - 1))) * W, rb * W) for i in range(nbands)]
+
+
+def cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp, W, chunks, Htot):
     """CPU baseline (the oracle's transient loop on the host cores) on a bounded sample of the same
-    workload, and the parity figures of the GPU results on that sample (rank 0, N = 1 only)."""
+    workload, and the parity figures of the GPU results on that sample (rank 0 only).  The sample is
+    eight bands of whole rows spread over the rank's rows -- every latitude band of the grid, not its
+    first rows (rows 0-127 of 4096 said nothing about the snow-free, ponding-prone low
+    latitudes) -- and the same cells serve the timing and the comparison."""
     api, torch, args = ctx["api"], ctx["torch"], ctx["args"]
     from oracle.binding import Oracle
-    from oracle.parity import SERIES11, trajectory_summary
+    from oracle.parity import SERIES11, merge_profiles, trajectory_summary
     o = Oracle()
     cores = host_cores()
     doy, year, month = api.time_fields(dates)
 
-    def cpu_run(ns, threads, store=True):
-        sl = slice(0, ns)
-        hsw, htc, hpn = (x[:, sl].contiguous().cpu().numpy() for x in (sw, tc, pn))
-        hp = par[:, sl].cpu().numpy()
+    def host(cells):   # cells: list of (c0, nc) local ranges -> numpy inputs of those cells, concatenated
+        cat = lambda x: torch.cat([x[..., c0:c0 + nc] for c0, nc in cells], dim=-1).contiguous().cpu().numpy()
+        return cat(sw), cat(tc), cat(pn), cat(par), cat(Tt), cat(state0)
+
+    def cpu_run(cells, threads, store=True):
+        hsw, htc, hpn, hp, hTt, hst = host(cells)
         t1 = time.perf_counter()
-        o.grid_transient(doy, year, month, hsw, htc, hpn, hp[0], hp[1], hp[2], hp[3], hp[4:16],
-                         Tt[sl].cpu().numpy(), state0[:, sl].cpu().numpy(), n_threads=threads, store=store)
+        o.grid_transient(doy, year, month, hsw, htc, hpn, hp[0], hp[1], hp[2], hp[3], hp[4:16], hTt, hst,
+                         n_threads=threads, store=store)
         return time.perf_counter() - t1
 
+    def global_row(c_local):   # grid row of a local cell (strong scaling deals row blocks round-robin)
+        r, acc_rows = c_local // W, 0
+        for r0, nr in chunks:
+            if r < acc_rows + nr:
+                return r0 + (r - acc_rows)
+            acc_rows += nr
+        return -1
+
     ns1 = min(1024, n)
-    t1 = cpu_run(ns1, 1)
+    t1 = cpu_run([(0, ns1)], 1)
     rate1 = ns1 * nt / t1
     nsn = min(n, max(ns1, 64 * cores))
-    tn = cpu_run(nsn, cores)
+    tn = cpu_run([(0, nsn)], cores)
     rate_n = nsn * nt / tn
-    ns2 = int(min(n, bn, max(nsn, rate_n * args.cpu_seconds / nt)))
-    ns2 -= ns2 % 64 if ns2 > 64 else 0
-    tcpu = cpu_run(ns2, cores)
+    # at most 2^19 cells, so that the sample -- and what it reports -- is the same on any host whose
+    # cores get that far in the time budget
+    want = int(min(n, 1 << 19, max(nsn, rate_n * args.cpu_seconds / nt)))
+    bands = sample_bands(n, W, want)
+    ns2 = sum(nc for _, nc in bands)
+    tcpu = cpu_run(bands, cores)
+    rows_txt = ", ".join(f"{global_row(c0)}-{global_row(c0 + nc - 1)}" for c0, nc in bands)
     line["cpu_baseline"] = {
         "value": ns2 * nt / tcpu, "unit": "cell-days/s", "cores": cores, "kind": "port",
         "single_thread_value": rate1, "threads_obtained": o.threads_obtained(cores), "omp_max_threads": o.max_threads(), "cpu_model": cpu_model(),
-        "sample": f"first {ns2} cells x {nt} days of the same grid (run_all + rain/snow split from the "
-                  f"GPU's spun-up state), OpenMP over cells with {cores} threads, {tcpu:.1f} s; one thread: "
-                  f"{ns1} cells in {t1:.1f} s",
+        "sample": f"{ns2} cells x {nt} days of the same grid in {len(bands)} bands of whole rows spread over the "
+                  f"latitudes (grid rows {rows_txt}; run_all + rain/snow split from the GPU's spun-up state), OpenMP "
+                  f"over cells with {cores} threads, {tcpu:.1f} s; one thread: {ns1} cells in {t1:.1f} s",
     }
-    # the same cells on the GPU, all 11 series, checked on EVERY cell-day (oracle/parity.py); at most
-    # the first 2^19 cells, so that the sample -- and what it reports -- is the same on any host
-    # whose cores get that far in the time budget
-    ns2 = min(ns2, 1 << 19)
+    # the same cells on the GPU, all 11 series, checked on EVERY cell-day (oracle/parity.py), band by band
     f64 = dict(dtype=torch.float64, device=ctx["dev"])
-    gs = {k: torch.empty(nt, ns2, **f64) for k in SERIES11}
-    st = state0[:, :ns2].clone()
-    api.dev_run_all(cal, 0, nt, ns2, sw, tc, pn, n, Tt, par, n, st, ns2, gs, ns2, stream=sp)
-    torch.cuda.synchronize()
-    p = dict(doy=doy, year=year, month=month, sw=sw[:, :ns2].cpu().numpy(), tc=tc[:, :ns2].cpu().numpy(),
-             pn=pn[:, :ns2].cpu().numpy(), par=par[:, :ns2].cpu().numpy(), Tt=Tt[:ns2].cpu().numpy(),
-             state0=state0[:, :ns2].cpu().numpy(), out={k: v.cpu().numpy() for k, v in gs.items()})
-    r = trajectory_summary(o, p, n_threads=cores)
-    r["cells"] = ns2
-    line["parity_sample"] = r
+    per_band, profs, viol, worst = [], [], [], []
+    tot = dict(cell_days=0, set_aside_cell_days=0, grazing_cell_days=0, cells_after_a_grazing_day=0,
+               critical_event_cells=0, critical_event_cells_that_differ=0,
+               cells_on_which_the_reference_disagrees_with_itself=0)
+    max_rel, max_dwn, oot = {}, 0.0, {}
+    frac_all = {}
+    for c0, nc in bands:
+        gs = {k: torch.empty(nt, nc, **f64) for k in SERIES11}
+        st = state0[:, c0:c0 + nc].clone()
+        api.dev_run_all(cal, 0, nt, nc, sw[:, c0:], tc[:, c0:], pn[:, c0:], n, Tt[c0:], par[:, c0:], n, st, nc, gs, nc,
+                        stream=sp)
+        torch.cuda.synchronize()
+        hsw, htc, hpn, hp, hTt, hst = host([(c0, nc)])
+        p = dict(doy=doy, year=year, month=month, sw=hsw, tc=htc, pn=hpn, par=hp, Tt=hTt, state0=hst,
+                 out={k: v.cpu().numpy() for k, v in gs.items()})
+        r = trajectory_summary(o, p, n_threads=cores, n_worst=5)
+        row0 = global_row(c0)
+        per_band.append({"row0": row0, "rows": nc // W, "lat_deg": round(60.0 - 120.0 * (row0 + 0.5 * (nc // W)) / Htot, 2),
+                         "cells": nc, "set_aside_cell_days": r["set_aside_cell_days"],
+                         "critical_event_cells": r["critical_event_cells"],
+                         "flips": r["critical_event_cells_that_differ"], "max_rel_err": r["max_rel_err"],
+                         "max_abs_dwn_mm": r["max_abs_dwn_mm"], "out_of_tolerance": r["out_of_tolerance"],
+                         "violations": r["violations"]})
+        for k in tot:
+            tot[k] += r[k]
+        for k, v in r["max_rel_err"].items():
+            max_rel[k] = max(max_rel.get(k, 0.0), v)
+        for k, v in r["out_of_tolerance"].items():
+            oot[k] = {q: oot.get(k, {}).get(q, 0) + v[q] for q in v}
+        for k, v in r["fraction_of_all_cell_days_within_tolerance"].items():
+            frac_all[k] = frac_all.get(k, 0.0) + v * nc / ns2
+        max_dwn = max(max_dwn, r["max_abs_dwn_mm"])
+        profs.append(r["profile"])
+        viol += [f"rows {row0}+: {v}" for v in r["violations"]]
+        for w in r["worst"]:
+            w = dict(w, grid_row=global_row(c0 + w["cell"]), grid_col=int((c0 + w["cell"]) % W))
+            worst.append(w)
+        excuse = r["excuse_builds"]
+        del gs, st
+    worst.sort(key=lambda w: -w["rel"])
+    res = dict(tot, cells=ns2, tolerance=1e-5, bands=per_band, max_rel_err=max_rel, max_abs_dwn_mm=max_dwn,
+               fraction_of_all_cell_days_within_tolerance=frac_all, out_of_tolerance=oot, violations=viol,
+               excuse_builds=excuse, worst=worst[:5],
+               profile={k: merge_profiles([pr[k] for pr in profs]) for k in profs[0]},
+               note="trajectory comparison (the oracle carries its own state from the GPU's spun-up state), every "
+                    "cell-day of every band; out_of_tolerance.inside_set_aside = cell-days after a grazing-sun day or a "
+                    "flipped critical event of their cell (oracle/parity.py), .kept must be 0 or excused")
+    line["parity_sample"] = res
 
 
 # ------------------------------------------------------------------------------------ configs 3, 4
@@ -657,6 +742,9 @@ def run_streamed(ctx):
                      {"days": nt, "years": years, "cells_per_gpu": n,
                       "timed": "per year: forcing generation (second stream, overlapped) + K5 run_all + K7; "
                                "one all-reduce of the totals at the end"})
+    if world > 1:
+        line["collective"] = collective_info(dist, acc.numel() * acc.element_size())
+        line["collective"]["op"] = "all_reduce(sum) of the int64 water-balance limbs, once per 30-year run"
     line["roofline"] = roofline(avg_launch_s, units_per_launch, f"stream{n}", "k_run_all (one calendar year)")
     # What the overlapped figure hides: the stand-in generator of the NEXT year's forcing runs on the
     # second stream beside every run_all launch and takes its share of the machine.  Measured apart,

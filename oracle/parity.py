@@ -285,9 +285,9 @@ def trajectory_summary(oracle, p, min_frac_all=1.0 - 1e-5, max_flip_frac=0.05, n
     Returns the figures plus 'violations' (list of messages)."""
     hp = p["par"]
     want = tuple(dict.fromkeys(tuple(names) + ("pet", "wn")))
-    ref, st1, ev, _ = oracle.grid_transient2(p["doy"], p["year"], p["month"], p["sw"], p["tc"], p["pn"],
-                                             hp[0], hp[1], hp[2], hp[3], hp[4:16], p["Tt"], p["state0"],
-                                             names=want, n_threads=n_threads)
+    ref, st1, ev, hs = oracle.grid_transient2(p["doy"], p["year"], p["month"], p["sw"], p["tc"], p["pn"],
+                                              hp[0], hp[1], hp[2], hp[3], hp[4:16], p["Tt"], p["state0"],
+                                              names=want, n_threads=n_threads, want_hs=bool(n_worst))
     graz_after = np.cumsum((ev & EV_GRAZING) != 0, axis=0) > 0
     crit_after = np.cumsum((ev & (EV_CRITICAL | EV_RESIDUAL)) != 0, axis=0) > 0
     flagged = crit_after.any(0)
@@ -341,7 +341,15 @@ def trajectory_summary(oracle, p, min_frac_all=1.0 - 1e-5, max_flip_frac=0.05, n
     if bulk:
         viol += bulk_violations(prof, bulk, "trajectory ")
     worst_rows = worst_cell_days({k: p["out"][k] for k in names}, ref, keep, n_worst, events=ev) if n_worst else []
+    for r in worst_rows:  # what the explanation of a worst row needs: the sun's height and the soil's pore-size index
+        r["hs_deg"] = float(hs[r["day"], r["cell"]])
+        r["lambda"] = float(hp[8, r["cell"]])
+        r["depth_m"] = float(hp[9, r["cell"]])
     set_aside = int((~keep).sum())
+    # of each series' cell-days out of tolerance, how many lie inside the set-aside mask (the rest would
+    # have raised a violation above unless another build of the reference excused their cell)
+    oot = {k: dict(all=int(bads[k].sum()), inside_set_aside=int((bads[k] & ~keep).sum()),
+                   kept=int((bads[k] & keep).sum())) for k in names}
     if set_aside > 5e-3 * ev.size:
         viol.append(f"{set_aside} of {ev.size} cell-days set aside")
     return dict(cell_days=int(ev.size), tolerance=RTOL, set_aside_cell_days=set_aside,
@@ -353,7 +361,7 @@ def trajectory_summary(oracle, p, min_frac_all=1.0 - 1e-5, max_flip_frac=0.05, n
                 fraction_of_all_cell_days_within_tolerance=frac_all,
                 fraction_within_tolerance_without_flipped_cells=frac_kept, max_rel_err=worst,
                 max_abs_dwn_mm=float(np.abs(p["out"]["wn"] - ref["wn"])[keep].max()), violations=viol,
-                profile=prof, worst=worst_rows)
+                out_of_tolerance=oot, excuse_builds=variants_status(), profile=prof, worst=worst_rows)
 
 
 def assert_trajectory(oracle, p, name="", **kw):
@@ -363,26 +371,43 @@ def assert_trajectory(oracle, p, name="", **kw):
 
 
 _VARIANTS = None
+_VARIANTS_STATUS = "not needed"
+
+
+def variants_status():
+    """'not needed' (no stray cell asked for them), 'built' or 'unavailable: <why>'"""
+    return _VARIANTS_STATUS
 
 
 def reference_variants():
     """The oracle's own source in two further legal builds (tools/conditioning_evidence.py):
     B  -O3 -march=x86-64-v3 -ffp-contract=fast;  C  every libm result moved by -1/0/+1 ulp.
-    Built on first use into the temp directory (gcc is on the build container and the GPU box)."""
-    global _VARIANTS
+    Built on first use into the temp directory (gcc is on the build container and the GPU box).
+    A host without gcc gets an EMPTY dict, not an exception: no stray cell can then be excused, so a
+    comparison that needed the excuse reports a violation -- a verdict ('excuse builds unavailable' in
+    variants_status() and in the summaries) instead of a crash of the checker."""
+    global _VARIANTS, _VARIANTS_STATUS
     if _VARIANTS is None:
+        import shutil
         import subprocess
         import tempfile
         from .binding import Oracle
         src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "splash_oracle.c")
         out = {}
-        for tag, flags in (("B", ["-O3", "-march=x86-64-v3", "-ffp-contract=fast"]),
-                           ("C", ["-O2", "-DORC_PERTURB_LIBM"])):
-            so = os.path.join(tempfile.gettempdir(), f"liboracle_parity_{tag}_{os.getpid()}.so")
-            subprocess.check_call(["gcc", "-std=c11", "-fPIC", "-fopenmp", "-shared", "-Wl,-Bsymbolic"] + flags +
-                                  ["-o", so, src, "-lm"])
-            out[tag] = Oracle(so)
-        _VARIANTS = out
+        cc = os.environ.get("SPLASH_ORACLE_CC", "gcc")
+        if shutil.which(cc) is None:
+            _VARIANTS, _VARIANTS_STATUS = {}, f"unavailable: no `{cc}` on this host"
+            return _VARIANTS
+        try:
+            for tag, flags in (("B", ["-O3", "-march=x86-64-v3", "-ffp-contract=fast"]),
+                               ("C", ["-O2", "-DORC_PERTURB_LIBM"])):
+                so = os.path.join(tempfile.gettempdir(), f"liboracle_parity_{tag}_{os.getpid()}.so")
+                subprocess.check_call([cc, "-std=c11", "-fPIC", "-fopenmp", "-shared", "-Wl,-Bsymbolic"] + flags +
+                                      ["-o", so, src, "-lm"])
+                out[tag] = Oracle(so)
+            _VARIANTS, _VARIANTS_STATUS = out, "built"
+        except (OSError, subprocess.CalledProcessError) as e:
+            _VARIANTS, _VARIANTS_STATUS = {}, f"unavailable: {e}"
     return _VARIANTS
 
 

@@ -218,6 +218,15 @@ __device__ __forceinline__ bool same_bits(double a, double b)
     return __double_as_longlong(a) == __double_as_longlong(b); // NaN-safe (sticky NaN drainage time)
 }
 
+#ifdef SPL_DIFF_STATS
+// measurement build (tools/diff_stats.py): |end_sm - start_sm| of the first eight passes of spin-up #2, per cell
+__device__ float* g_diff_dbg = nullptr;
+extern "C" int splash_dbg_set_diff(float* p)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_diff_dbg), &p, sizeof p);
+}
+#endif
+
 // ================================================================ K4 spin-up ===================
 // Grid spin-up: both spin-ups of splash.point (R/splash.point.R:141-152) as a resumable per-cell
 // job.  The number of passes is data dependent (2..1000, src/SPLASH.cpp:1697): most cells need
@@ -501,6 +510,9 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         day_one(nxt, o, nullptr);
         double diff_sm = nxt.wn - e_wn; // end_sm - start_sm, :1678-1688
         if (diff_sm < 0) diff_sm = e_wn - nxt.wn;
+#ifdef SPL_DIFF_STATS
+        if (!done && stage == 2 && count <= 8 && g_diff_dbg) g_diff_dbg[(size_t)(count - 1) * a.ntotal + ci] = (float)diff_sm;
+#endif
         if (!done) {
             if (acc) a.ai[ci] = pet_sum / p_sum; // R/splash.point.R:150
             // :1697.  Spin-up #1 only feeds the aridity index, and that uses the PET of its first

@@ -159,7 +159,10 @@ def test_bench_launches_its_own_ranks():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
+    coll = d.pop("collective")
     assert d == {"dryrun": True, "n_gpus": 3, "sum_of_ranks": 6.0}
+    # the line says what the process group itself saw, not just WORLD_SIZE from the environment
+    assert coll["backend"] == "gloo" and coll["world_size"] == 3 and coll["bytes"] == 8
     # without a GPU the real ranks refuse loudly and the launcher reports the failure
     env.pop("SPLASH_BENCH_DRYRUN")
     if not torch.cuda.is_available():

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import ROOT, rel_err
 from gpu_pipeline import (assert_one_step, assert_trajectory, assert_whole_pipeline,
                           device_pipeline)
 
@@ -619,6 +619,30 @@ def test_every_cell_day_one_step_and_trajectory(api, oracle, case):
     assert np.isfinite(p["out"]["wn"]).all()
 
 
+def test_benchmark_grid_latitude_bands_one_step_and_trajectory(api, oracle):
+    """`benchmark-rows-bands`: the 4096 x 4096 grid of the metric (BASELINE.json configs[2]) sampled in eight
+    bands of two rows from 60 N to 60 S -- rows 0, 585, 1170, ..., 4094 -- each through the whole device
+    pipeline and compared on every cell-day, one-step and trajectory (src/SPLASH.cpp:920-1588,
+    src/SOLAR.cpp:149-165).  The 60 N rows of CASES see grazing winter sun and snow; the low latitudes
+    are the snow-free, ponding-prone, slower blocks that only builder-run tools had compared."""
+    Htot = W = 4096
+    rows = 2
+    seen_snow, seen_nosnow = False, False
+    for b in range(8):
+        r0 = int(round(b * (Htot - rows) / 7))
+        p = device_pipeline(api, 20221130, Htot, W, r0 * W, rows * W, 365, 1)
+        r1 = assert_one_step(oracle, p, f"rows {r0}+")
+        r2 = assert_trajectory(oracle, p, f"rows {r0}+", n_worst=3)
+        lat = 60.0 - 120.0 * (r0 + 1.0) / Htot
+        print(f"rows {r0}-{r0 + rows - 1} (lat {lat:+.1f}): one-step max rel err {max(r1['max_rel_err'].values()):.2e}, "
+              f"trajectory {max(r2['max_rel_err'].values()):.2e}, set aside {r2['set_aside_cell_days']} cell-days, "
+              f"{r2['critical_event_cells_that_differ']} of {r2['critical_event_cells']} critical-event cells differ; worst {r2['worst'][:1]}")
+        assert np.isfinite(p["out"]["wn"]).all()
+        seen_snow |= bool((p["out"]["snow"] > 0).any())
+        seen_nosnow |= not bool((p["out"]["snow"][:, ::7] > 0).any())
+    assert seen_snow and seen_nosnow   # the bands do cover both regimes
+
+
 def test_spin_up_runs_on_day_of_year_1_to_365_of_the_first_year(api, oracle):
     """src/SPLASH.cpp:1658/1674 + R/splash.point.R:141-152: spin_up(365, y[1], ...) evaluates
     quick_run(i+1, y, ...) -- orbit of day-of-year 1..365 of the first year -- on the first 365
@@ -1083,6 +1107,14 @@ def test_bench_line_keeps_the_contract():
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0
     assert d["value"] > 0 and abs(d["value"] - 64 * 64 * 365 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    # round 4: what the whole-call figure is made of, and a parity sample that says where it looked
+    assert d["inclusive"]["tail_seconds"] > 0 and d["inclusive"]["seconds"] >= d["inclusive"]["tail_seconds"]
+    ps = d["parity_sample"]
+    assert ps["bands"] and all("row0" in b and "max_rel_err" in b and "out_of_tolerance" in b for b in ps["bands"])
+    assert not ps["violations"], ps["violations"]
+    assert ps["excuse_builds"] in ("not needed", "built") or ps["excuse_builds"].startswith("unavailable")
+    assert all(v["kept"] == 0 or ps["cells_on_which_the_reference_disagrees_with_itself"] > 0
+               for v in ps["out_of_tolerance"].values())
 
 
 # ---------------------------------------------------------------- static rasters
@@ -1605,3 +1637,26 @@ def test_single_precision_result_transport_is_the_rounded_double(api, oracle):
                 os.environ[k] = v
     with pytest.raises(ValueError):       # a caller's array must have the dtype asked for
         call(out=dict(wn=np.empty((nt, n))), out_dtype=np.float32)
+
+
+@pytest.mark.gpu
+def test_product_bits_are_pinned(api, oracle):
+    """The product's OWN bits, pinned across commits: the exact int64 limbs of the monthly
+    water-balance totals and the sha256 of all nine result series, the end state, the aridity index and
+    the snow threshold of a fixed 64 x 128 x 400-day grid must equal tests/golden/product_bits.json, which
+    tools/make_product_bits.py wrote on an MI355X.  "Same bits" claims elsewhere (any blocking, lanes,
+    devices, pass mode) are relative to ONE build; this one is absolute: a commit that moves a bit has to
+    regenerate the file and say why in DESIGN.md ("product bits changelog")."""
+    import json
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_product_bits", os.path.join(ROOT, "tools", "make_product_bits.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "product_bits.json")))
+    got = mod.compute(api, oracle)
+    assert got["diag_acc_shape"] == want["diag_acc_shape"]
+    diff = [i for i, (a, b) in enumerate(zip(got["diag_acc"], want["diag_acc"])) if a != b]
+    assert not diff, f"{len(diff)} of {len(want['diag_acc'])} limbs of the water-balance totals moved (first at {diff[0]})"
+    moved = [k for k in want["sha256"] if got["sha256"][k] != want["sha256"][k]]
+    assert not moved, f"bits moved in: {moved} (pinned by: {want.get('why', '')!r})"
+    assert got["passes2_sum"] == want["passes2_sum"]

@@ -3,7 +3,14 @@ call -- NA scan, H2D forcing, soil_hydro, snow threshold, both spin-ups, run_all
 on a synthetic terrain grid held in host memory.  Not the bench metric (bench.py keeps rasters
 resident); recorded in DESIGN.md and profiles/.
 
-    python tools/bench_host_path.py [rows] [cols] [daily|monthly] [n_outputs] [f64|f32] [reps] [cells per block]
+    python tools/bench_host_path.py [rows] [cols] [daily|monthly] [n_outputs] [f64|f32] [reps] [cells per block] [out64|out32]
+
+out32 = single-precision transport of the results (splash_grid_out.out_f32, ABI 4).
+After the timed calls the results are VERIFIED: a strided set of columns (every 251st cell plus 512 cells
+around every multiple of 2^20, where the library's blocks meet) is recomputed by the device-resident
+pipeline (tests/gpu_pipeline.py's sequence: soil_hydro, snow threshold, both spin-ups, run_all, in one
+block on one stream) from the same host forcing, and compared bit for bit with those columns of the
+arrays the call filled; the JSON line carries `verify.differing_values` (must be 0).
 
 The output arrays are allocated and touched once before the timed calls (what the caller of a C ABI
 does: R's allocMatrix, or a reused buffer); f32 hands the forcing over in single precision (the
@@ -30,6 +37,8 @@ nout = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 f32 = len(sys.argv) > 5 and sys.argv[5] == "f32"
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 max_cells = int(sys.argv[7]) if len(sys.argv) > 7 else 0  # cells per block (0: the library's choice)
+out32 = len(sys.argv) > 8 and sys.argv[8] == "out32"
+odt = np.float32 if out32 else np.float64
 n, nt, SEED = H * W, 365, 20221130
 dev = torch.device("cuda:0")
 f64 = dict(dtype=torch.float64, device=dev)
@@ -61,7 +70,7 @@ for r0 in range(0, H, rows_chunk):
 torch.cuda.empty_cache()
 print(f"grid generated and copied to the host in {time.perf_counter() - t_gen:.1f} s", file=sys.stderr, flush=True)
 names = ("wn", "snow", "ro", "aet", "pet", "cond", "bflow", "netr", "sm_lim")[:nout]
-bufs = {k: np.zeros(((12 if monthly else nt), n)) for k in names}
+bufs = {k: np.zeros(((12 if monthly else nt), n), odt) for k in names}
 best = None
 times = []
 for rep in range(reps):
@@ -69,17 +78,61 @@ for rep in range(reps):
     out = api.splash_grid(host["sw"], host["tc"], host["pn"], host["elev"], host["soil"], host["lat"],
                           host["slop"], host["asp"], Au=host["au"], resolution=host["res"],
                           time_index=time_index, sim_control=dict(monthly_out=monthly), outputs=names,
-                          out=bufs, want_state=False, max_cells_per_launch=max_cells)
+                          out=bufs, want_state=False, max_cells_per_launch=max_cells, out_dtype=odt)
     dt = time.perf_counter() - t0
     print(f"call {rep}: {dt:.3f} s", file=sys.stderr, flush=True)
     times.append(dt)
     best = dt if best is None else min(best, dt)
 bytes_in = n * nt * (12 if f32 else 24)
-bytes_out = n * (12 if monthly else nt) * 8 * nout
+bytes_out = n * (12 if monthly else nt) * (4 if out32 else 8) * nout
+
+
+def verify(out):
+    """the device-resident pipeline on a strided set of the grid's cells, bitwise against the call's columns"""
+    idx = [np.arange(0, n, 251)]
+    for b in range(1 << 20, n, 1 << 20):
+        idx.append(np.arange(max(0, b - 256), min(n, b + 256)))
+    idx = np.unique(np.concatenate(idx))
+    m = len(idx)
+    t0 = time.perf_counter()
+    up = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)
+    lat, elev, slop, asp, res = (up(host[k][idx]) for k in ("lat", "elev", "slop", "asp", "res"))
+    soil, au = up(host["soil"][:, idx]), up(host["au"][:, idx])
+    sw, tc, pn = (up(host[k][:, idx]) for k in ("sw", "tc", "pn"))      # f32 forcing widens exactly
+    par = torch.empty(api.NPAR, m, **f64)
+    Tt = torch.empty(m, **f64)
+    state = torch.empty(api.NSTATE, m, **f64)
+    api.dev_soil_hydro(m, lat, elev, slop, asp, res, soil, au, par)
+    api.dev_snow_threshold(m, nt, tc, m, par, m, Tt)
+    work = torch.empty(api.spin_up_work_size(m), dtype=torch.uint8, device=dev)
+    api.dev_spin_up(cal, m, sw, tc, pn, m, Tt, par, m, state, m, work)
+    nt_out = 12 if monthly else nt
+    g = {k: torch.empty(nt_out, m, **f64) for k in names}
+    api.dev_run_all(cal, 0, nt, m, sw, tc, pn, m, Tt, par, m, state, m, g, m, monthly=monthly)
+    torch.cuda.synchronize()
+    differing, per = 0, {}
+    for k in names:
+        want = g[k].cpu().numpy()
+        got = out[k][:, idx]
+        if out32:
+            d = int((want.astype(np.float32).view(np.int32) != got.view(np.int32)).sum())
+        else:
+            d = int((want.view(np.int64) != got.view(np.int64)).sum())
+        per[k] = d
+        differing += d
+    return {"cells_compared": int(m), "values_compared": int(m) * nt_out * len(names), "differing_values": differing,
+            "per_series": per, "seconds": round(time.perf_counter() - t0, 2),
+            "against": "device-resident pipeline (one block, one stream) on the same host forcing; every 251st cell + "
+                       "512 cells around every multiple of 2^20"}
+
+
+ver = verify(out)
+print(f"verify: {ver['differing_values']} differing values of {ver['values_compared']}", file=sys.stderr, flush=True)
 print(json.dumps({"entry": "splash_grid_run (host buffers)", "forcing": "f32" if f32 else "f64", "rows": H, "cols": W,
                   "cells": n, "days": nt, "outputs": list(names), "monthly": monthly, "seconds": best,
                   "seconds_all_calls": [round(t, 3) for t in times], "cell_days_per_s": n * nt / best,
                   "pcie_bytes_in": bytes_in, "pcie_bytes_out": bytes_out,
                   "pcie_GBps_equivalent": (bytes_in + bytes_out) / best / 1e9,
                   "lanes": os.environ.get("SPLASH_HIP_LANES", "2 (default)"), "max_cells_per_block": max_cells,
-                  "wn_mean": float(np.nanmean(out["wn"]))}))
+                  "results": "f32" if out32 else "f64", "verify": ver,
+                  "wn_mean": float(np.nanmean(out["wn"][:, ::97], dtype=np.float64))}))
