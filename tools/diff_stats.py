@@ -63,7 +63,16 @@ for thr in (1.5, 2.0, 3.0, 5.0, 10.0):
     fl = surv & (d[1] >= thr)
     print(f"  d2 >= {thr} mm: flagged {fl.sum()} ({fl.sum() / n:.4f}); recall of >= 100-iteration jobs {(fl & (it >= 100)).sum()}/{(it >= 100).sum()}, "
           f">= 400: {(fl & (it >= 400)).sum()}/{(it >= 400).sum()}")
+# a predicate known BEFORE the spin-up: can the cell have snow at all?  (Tt = max(tc[p_snow >= 0.5]) is -inf
+# when no day qualifies, R/splash.point.R:122: f_rain == 1 all year)
+snowy = np.isfinite(Tt.cpu().numpy())
+snow_end = state[1].cpu().numpy() > 0
+for lim in (100, 400, 900):
+    L = it >= lim
+    print(f"  >= {lim} iterations: {L.sum()} jobs, of which snow-capable (finite Tt): {(L & snowy).sum()}, with snow on the ground at the "
+          f"end of the spin-up: {(L & snow_end).sum()}")
+print(f"  snow-capable cells: {snowy.sum()} of {n} ({snowy.mean():.3f})")
 keep = npass >= 4
-np.savez_compressed("gpurun_out/diff_stats.npz", cell=np.nonzero(keep)[0].astype(np.int32), d=d[:, keep], it=it[keep].astype(np.int16),
+np.savez_compressed(f"gpurun_out/diff_stats_r{r0}.npz", snowy=snowy[keep], snow_end=snow_end[keep], cell=np.nonzero(keep)[0].astype(np.int32), d=d[:, keep], it=it[keep].astype(np.int16),
                     tail=tail[keep], n=n, npass_hist=np.bincount(npass, minlength=9))
-print("wrote gpurun_out/diff_stats.npz:", keep.sum(), "cells")
+print(f"wrote gpurun_out/diff_stats_r{r0}.npz:", keep.sum(), "cells")
