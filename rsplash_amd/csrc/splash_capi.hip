@@ -487,7 +487,6 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
     double* const cache_all = (double*)(w + o_cache);
     a.cache_cap = spin_cache_cap(ncell);
     a.ntotal = ncell;
-    a.no_nd_skip = getenv("SPLASH_HIP_NO_ND_SKIP") ? 1 : 0; // tests: the detector of round 3 (same final bits, more passes)
     for (int ph = ph0; ph < ph1; ph++) {
         a.fresh = (ph == 0);
         a.budget = budget[ph];

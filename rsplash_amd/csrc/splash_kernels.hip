@@ -400,15 +400,6 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     __shared__ double s_chk[5][kBlock];
     __shared__ int s_chk_count[kBlock];
     s_chk_count[threadIdx.x] = -1;
-    // Has the snow age been looked at, or reset, since the cycle detector's checkpoint?  nd counts the
-    // days since the last snowfall (src/SPLASH.cpp:1225-1229) and is READ only while there is snow
-    // (the albedo of src/SOLAR.cpp:208-219).  A cell without snow carries an nd that grows by 365 every
-    // pass and never repeats, although nothing depends on it: see the detector below.
-    bool nd_touched = false;
-    auto note_snow = [&](const State& st_, double snf_) {
-        const double s_ = st_.snow + snf_; // what day_update() forms: the albedo branch runs when this is > 0 or NaN
-        nd_touched = nd_touched || !(s_ <= 0.0) || (snf_ > 0.0); // ... and nd is reset when snow falls
-    };
     // day 1 of the year is evaluated at the end of every pass (the closing step, :1674 == day 1 of
     // the next pass): from the cache when there is one, from the forcing otherwise
     auto day_one = [&](State& st_, DayOut& o_, double* p_day) {
@@ -426,7 +417,6 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             if (CACHED && cached) rec_store<RICH>(a.cache, a.cache_cap, 0, sl, r);
         }
         if (p_day) *p_day = r.rain + r.snf;
-        note_snow(st_, r.snf);
         day_update(c, r.T, r.V, r.rain, r.snf, st_, o_);
     };
     State cur;
@@ -464,14 +454,6 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     // an exact 2- or 3-cycle after a few dozen passes.  The checkpoint lives in LDS (one compare
     // per pass); it restarts with every phase, moving to the current state whenever the number of
     // passes since the phase began is a power of two.
-    // The snow age nd is part of the state but, in a cell without snow, not of the dynamics (round 4: at
-    // low latitudes 0.1 % of the cells sat in exact 2-cycles of wn, qin and td that were never detected
-    // because nd grew by 365 every pass -- 3 869 of 4.2 M cells ran ~1000 passes each,
-    // profiles/r04_spinup.md).  If since the checkpoint no day had snow on the ground or falling
-    // (nd_touched: the albedo branch never ran and nd was never reset), wn, snow, qin and td evolved
-    // without reading nd; if they repeat bit for bit, the same days follow again -- the branch condition
-    // is a function of snow, which repeats -- so they are periodic for good and nd simply grows by one
-    // per day step: after skipping k passes it is nd + 365 k, exactly (integers far below 2^53).
     bool done = !valid || finished_before || (READBACK && !cached);
     for (int it = 0; it < a.budget; it++) {
         const bool acc = !READBACK && a.fresh && it == 0; // first pass of spin-up #1 (uniform)
@@ -486,7 +468,6 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             for (int i = 1; i < a.n; i++) {
                 const DayRecord r = rec_decode<RICH>(c, w, RICH ? 0.0 : days[i].cd);
                 if (i + 1 < a.n) w = rec_load<RICH>(a.cache, a.cache_cap, i + 1, sl); // tomorrow's, untouched until tomorrow
-                note_snow(cur, r.snf);
                 day_update(c, r.T, r.V, r.rain, r.snf, cur, o);
             }
         } else if constexpr (!READBACK) {
@@ -513,7 +494,6 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 double swn, tcn, pnn;
                 f.raw(in_, swn, tcn, pnn);
                 if (CACHED && cached) rec_store<RICH>(a.cache, a.cache_cap, i, sl, r);
-                note_snow(cur, r.snf);
                 day_update(c, r.T, r.V, r.rain, r.snf, cur, o);
                 if (acc) { // pet_vec is only filled in the first pass (:1667), Pinit = rain + snow
                     const double pday = r.rain + r.snf;
@@ -543,16 +523,13 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             if (cont) {
                 count++;
                 const int cc = s_chk_count[threadIdx.x];
-                const bool same4 = cc >= 0 && same_bits(nxt.wn, s_chk[0][threadIdx.x]) &&
-                                   same_bits(nxt.snow, s_chk[1][threadIdx.x]) &&
-                                   same_bits(nxt.qin, s_chk[2][threadIdx.x]) &&
-                                   same_bits(nxt.td, s_chk[3][threadIdx.x]);
-                const bool same_nd = same_bits(nxt.nd, s_chk[4][threadIdx.x]);
-                const bool same = same4 && (same_nd || (!nd_touched && !a.no_nd_skip));
+                const bool same = cc >= 0 && same_bits(nxt.wn, s_chk[0][threadIdx.x]) &&
+                                  same_bits(nxt.snow, s_chk[1][threadIdx.x]) &&
+                                  same_bits(nxt.qin, s_chk[2][threadIdx.x]) &&
+                                  same_bits(nxt.td, s_chk[3][threadIdx.x]) &&
+                                  same_bits(nxt.nd, s_chk[4][threadIdx.x]);
                 if (same) {
-                    const int left = (1000 - count) % (count - cc);
-                    if (!same_nd) nxt.nd += (double)a.n * (double)((1000 - count) - left); // one per skipped day step
-                    count = 1000 - left;
+                    count = 1000 - ((1000 - count) % (count - cc));
                     s_chk_count[threadIdx.x] = -1; // the remaining < lam passes run plainly
                 } else if (((it + 1) & it) == 0) { // it + 1 = passes in this phase: 1, 2, 4, 8, ...
                     s_chk[0][threadIdx.x] = nxt.wn;
@@ -561,7 +538,6 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                     s_chk[3][threadIdx.x] = nxt.td;
                     s_chk[4][threadIdx.x] = nxt.nd;
                     s_chk_count[threadIdx.x] = count;
-                    nd_touched = false;
                 }
                 cur = nxt;
                 park_e(cur);

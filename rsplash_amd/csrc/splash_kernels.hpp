@@ -78,7 +78,6 @@ struct SpinPhaseArgs {
     int readback;           // 1: the read-back kernel (every job's records are in the cache already)
     int no_queue;           // 1: park unfinished jobs without queueing them (a launch over the same
                             //    cells follows and does the queueing)
-    int no_nd_skip;         // test aid (SPLASH_HIP_NO_ND_SKIP): the cycle detector compares the snow age too, always
     int rich;               // 1: the cache holds rich records, 20 words each, record by record (cache_cap = spin_cache_rich_cap of the
                             //    workspace's capacity), see splash_kernels.hip "Two layouts"
 };

@@ -627,7 +627,7 @@ def test_benchmark_grid_latitude_bands_one_step_and_trajectory(api, oracle):
     are the snow-free, ponding-prone, slower blocks that only builder-run tools had compared."""
     Htot = W = 4096
     rows = 2
-    seen_snow, seen_nosnow = False, False
+    snow_frac = []
     for b in range(8):
         r0 = int(round(b * (Htot - rows) / 7))
         p = device_pipeline(api, 20221130, Htot, W, r0 * W, rows * W, 365, 1)
@@ -638,9 +638,9 @@ def test_benchmark_grid_latitude_bands_one_step_and_trajectory(api, oracle):
               f"trajectory {max(r2['max_rel_err'].values()):.2e}, set aside {r2['set_aside_cell_days']} cell-days, "
               f"{r2['critical_event_cells_that_differ']} of {r2['critical_event_cells']} critical-event cells differ; worst {r2['worst'][:1]}")
         assert np.isfinite(p["out"]["wn"]).all()
-        seen_snow |= bool((p["out"]["snow"] > 0).any())
-        seen_nosnow |= not bool((p["out"]["snow"][:, ::7] > 0).any())
-    assert seen_snow and seen_nosnow   # the bands do cover both regimes
+        snow_frac.append(float((p["out"]["snow"] > 0).any(0).mean()))
+    print("cells that see snow, per band:", [round(x, 3) for x in snow_frac])
+    assert max(snow_frac) > 0.9 and min(snow_frac) < 0.5   # the bands do cover both regimes
 
 
 def test_spin_up_runs_on_day_of_year_1_to_365_of_the_first_year(api, oracle):
@@ -1660,43 +1660,3 @@ def test_product_bits_are_pinned(api, oracle):
     moved = [k for k in want["sha256"] if got["sha256"][k] != want["sha256"][k]]
     assert not moved, f"bits moved in: {moved} (pinned by: {want.get('why', '')!r})"
     assert got["passes2_sum"] == want["passes2_sum"]
-
-
-@pytest.mark.gpu
-def test_cycle_detector_ignores_an_idle_snow_age(api, oracle):
-    """Round 4: the spin-up's exact-cycle detector (k_spin_phase) no longer needs the snow age nd to repeat
-    when nothing read or reset it since the checkpoint (no snow on the ground, none falling): wn, snow, qin
-    and td then evolve without it, a bit-for-bit repeat of those four is a cycle for good, and nd is
-    advanced by 365 per skipped pass.  Two rows at the equator of the benchmark grid (no snow all year,
-    0.1 % of the cells in an exact 2-cycle of more than 1 mm): the spun-up state -- nd included --, the
-    aridity index, the pass counts and every daily series must equal, bit for bit, what the round-3
-    detector (SPLASH_HIP_NO_ND_SKIP=1: compares nd as well, i.e. runs those cells ~1000 passes) leaves;
-    the pass counts must also be the oracle's, which iterates all passes (src/SPLASH.cpp:1697-1743)."""
-    import os
-    Htot = W = 4096
-    r0, rows = 2040, 2
-    os.environ.pop("SPLASH_HIP_NO_ND_SKIP", None)
-    a = device_pipeline(api, 20221130, Htot, W, r0 * W, rows * W, 365, 1, want_passes=True)
-    os.environ["SPLASH_HIP_NO_ND_SKIP"] = "1"
-    try:
-        b = device_pipeline(api, 20221130, Htot, W, r0 * W, rows * W, 365, 1, want_passes=True)
-    finally:
-        os.environ.pop("SPLASH_HIP_NO_ND_SKIP")
-    capped = a["passes"][1] >= 1000
-    bare = ~(a["out"]["snow"] > 0).any(0) & (a["state0"][1] == 0)   # the case this is about: no snow at all
-    assert (capped & bare).sum() >= 5, (capped.sum(), (capped & bare).sum())
-    assert (a["state0"][4][capped & bare] >= 365000 - 2 * 365).all()   # nd after 1000 passes of 365 days
-    assert np.array_equal(a["passes"], b["passes"])
-    for k in ("state0", "state1", "par", "Tt"):
-        assert np.array_equal(a[k].view(np.int64), b[k].view(np.int64)), k
-    for k in a["out"]:
-        assert np.array_equal(a["out"][k].view(np.int64), b["out"][k].view(np.int64)), k
-    # the oracle's pass counts for the capped cells and a sample of the others (it really iterates)
-    doy, year, month, mid, nm = oracle.calendar(2001, 365)
-    sel = np.r_[np.nonzero(capped)[0][:12], np.arange(0, rows * W, 997)]
-    st = {k: (v[:, sel] if v.ndim == 2 else v[sel]) for k, v in a["statics"].items()}
-    ref, aux = oracle.grid(doy, year, month, mid, nm, np.ascontiguousarray(a["sw"][:, sel]),
-                           np.ascontiguousarray(a["tc"][:, sel]), np.ascontiguousarray(a["pn"][:, sel]), st["lat"],
-                           st["elev"], st["slop"], st["asp"], st["soil"], st["au"], st["resolution"])
-    agree = aux["passes2"].astype(np.int64) == a["passes"][1][sel]
-    assert agree.mean() >= 0.98 and agree[:min(12, int(capped.sum()))].all(), (aux["passes2"], a["passes"][1][sel])
