@@ -1,7 +1,9 @@
 """Randomised invariants of the host-buffer entry point (splash_grid_run through api.splash_grid), GPU box:
 for random grid shapes, NA masks, launch blockings, device lists {0,0}/{0,0,0}, pipeline lanes (1-4),
 straggler pools too small for a block (finished in place), calls in flight side by side
-(splash_grid_submit/_wait), single-precision transport, monthly/daily outputs and basin maps, the
+(splash_grid_submit/_wait), single-precision transport of forcing and of results, the large-call paths at
+small size (page mapping per block, page-locked caller arrays, the library's own blocking; outputs handed in
+filled with a sentinel), monthly/daily outputs and basin maps, the
 results must equal the plain call BITWISE on
 every valid cell, NA cells must come back NaN, and the per-basin totals must be identical limbs.
     python tools/fuzz_grid_run.py [n_cases=12]"""
@@ -47,12 +49,24 @@ for case in range(n_cases):
     variants[f"{lanes} lanes, blocked"] = dict(max_cells_per_launch=int(rng.integers(64, 400)), _env=dict(SPLASH_HIP_LANES=str(lanes)))
     variants["tiny pool, blocked"] = dict(max_cells_per_launch=int(rng.integers(64, 400)),
                                           _env=dict(SPLASH_HIP_POOL_CAP=str(int(rng.integers(1, 4)))))
+    # round 4: the paths that only ran for big calls (result pages mapped per block, caller arrays page-locked
+    # by a helper thread, the library's own many-blocks plan), sentinel-filled outputs handed in, and
+    # single-precision results
+    big = dict(SPLASH_HIP_PREFAULT_MIN_BYTES="0", SPLASH_HIP_REGISTER_MIN_BYTES="0",
+               SPLASH_HIP_MIN_BLOCK_CELLS=str(int(rng.integers(32, 200))), SPLASH_HIP_BLOCKS_PER_LANE=str(int(rng.integers(2, 7))),
+               SPLASH_HIP_PREFAULT=str(rng.choice(["populate", "touch"])), SPLASH_HIP_LANES=str(int(rng.integers(1, 5))))
+    variants["large-call paths"] = dict(_env=big, _sentinel=True)
+    variants["large-call paths, tiny pool"] = dict(_env=dict(big, SPLASH_HIP_POOL_CAP="2"), _sentinel=True)
+    variants["f32 results"] = dict(out_dtype=np.float32, max_cells_per_launch=int(rng.integers(64, 400)), _env=dict(big))
     variants["in flight (a)"] = dict(max_cells_per_launch=int(rng.integers(64, 400)), submit=True, mem_fraction=0.3)
     variants["in flight (b)"] = dict(devices=[0, 0], submit=True, mem_fraction=0.3)
     jobs = {}
     for tag, extra in variants.items():
         extra = dict(extra)
         env = extra.pop("_env", {})
+        if extra.pop("_sentinel", False):
+            nto = nm if monthly else nt
+            extra["out"] = {k: np.full((nto, n), -12345.678) for k in names}
         os.environ.update(env)
         g = api.splash_grid(swm, tcm, pnm, *args, **kw, **extra)
         for e in env:
@@ -61,8 +75,15 @@ for case in range(n_cases):
             jobs[tag] = g
             continue
         for k in names:
-            if not np.array_equal(g[k][:, ~mask].view(np.int64), ref[k][:, ~mask].view(np.int64)):
+            if extra.get("out_dtype") is np.float32:   # (float) of the double-precision call, bit for bit
+                same = g[k].dtype == np.float32 and np.array_equal(g[k][:, ~mask].view(np.int32),
+                                                                   ref[k][:, ~mask].astype(np.float32).view(np.int32))
+            else:
+                same = np.array_equal(g[k][:, ~mask].view(np.int64), ref[k][:, ~mask].view(np.int64))
+            if not same:
                 msgs.append(f"{tag}: {k} differs")
+            if not np.isnan(g[k][:, mask]).all():
+                msgs.append(f"{tag}: NA cells of {k} are not NaN")
         for k in g["diag"]:
             if not np.array_equal(np.asarray(g["diag"][k]).view(np.int64), np.asarray(ref["diag"][k]).view(np.int64)):
                 msgs.append(f"{tag}: basin totals of {k} differ")
