@@ -131,7 +131,7 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     the one call (one host thread per entry; the same ordinal may repeat).
     out: dict name -> preallocated array [nt_out, ...] of `out_dtype` to receive that series (what an R
     caller's allocMatrix is); series not in `out` are allocated here.
-    out_dtype=np.float32: single-precision transport of the results (splash_grid_out.out_f32): every
+    out_dtype=np.float32 (or a dict name -> dtype): single-precision transport of the results (splash_grid_out.out_f32): every
     value is rounded to the nearest float on the device -- what the reference's FLT4S bricks hold,
     R/splash.grid.R:186-216 -- which halves the device->host bytes; the arithmetic is FP64 either way.
     submit=True: splash_grid_submit -- the call runs on its own host thread and streams; a GridJob
@@ -179,22 +179,25 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     nm = int(month_ids(year, month)[-1]) + 1
     nt_out = nm if monthly else nt
     res = {}
-    odt = np.dtype(out_dtype)
-    if odt not in (np.dtype(np.float64), np.dtype(np.float32)):
+    # one precision for all series, or a dict name -> dtype (series not named: float64)
+    odts = {k: np.dtype(out_dtype.get(k, np.float64) if isinstance(out_dtype, dict) else out_dtype) for k in outputs}
+    if any(d not in (np.dtype(np.float64), np.dtype(np.float32)) for d in odts.values()):
         raise ValueError("out_dtype must be float64 or float32")
     for k in outputs:
         a = out.get(k) if out else None
         if a is None:
-            a = np.empty((nt_out,) + shp, odt)
-        elif a.shape != (nt_out,) + shp or a.dtype != odt or not a.flags.c_contiguous:
-            raise ValueError(f"out[{k!r}] must be a C-contiguous {odt} array of shape {(nt_out,) + shp}")
+            a = np.empty((nt_out,) + shp, odts[k])
+        elif a.shape != (nt_out,) + shp or a.dtype != odts[k] or not a.flags.c_contiguous:
+            raise ValueError(f"out[{k!r}] must be a C-contiguous {odts[k]} array of shape {(nt_out,) + shp}")
         res[k] = a
     gout = _lib.GridOut()
     for i, k in enumerate(OUT_NAMES):
-        if odt == np.float64:
-            gout.out[i] = res[k].ctypes.data_as(_dp) if k in res else None
+        if k not in res:
+            continue
+        if odts[k] == np.float64:
+            gout.out[i] = res[k].ctypes.data_as(_dp)
         else:
-            gout.out_f32[i] = res[k].ctypes.data_as(C.POINTER(C.c_float)) if k in res else None
+            gout.out_f32[i] = res[k].ctypes.data_as(C.POINTER(C.c_float))
     state_end = None
     if want_state:
         state_end = np.empty((NSTATE,) + shp)

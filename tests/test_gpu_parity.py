@@ -1618,6 +1618,13 @@ def test_single_precision_result_transport_is_the_rounded_double(api, oracle):
             same32(ref, call(monthly=monthly, out_dtype=np.float32), f"one block, monthly={monthly}")
             same32(ref, call(monthly=monthly, out_dtype=np.float32, max_cells_per_launch=700),
                    f"ragged blocks, monthly={monthly}")
+        # per series: some in single, some in double precision in the same call
+        mix = call(monthly=True, out_dtype=dict(wn=np.float32, aet=np.float32, sm_lim=np.float32), max_cells_per_launch=700)
+        for k in api.OUT_NAMES:
+            if k in ("wn", "aet", "sm_lim"):
+                assert mix[k].dtype == np.float32 and np.array_equal(ref[k].astype(np.float32).view(np.int32), mix[k].view(np.int32)), k
+            else:
+                assert mix[k].dtype == np.float64 and np.array_equal(ref[k].view(np.int64), mix[k].view(np.int64)), k
         os.environ["SPLASH_HIP_POOL_CAP"] = "2"
         same32(ref, call(monthly=True, out_dtype=np.float32, max_cells_per_launch=1024), "pool overflow")
         os.environ.pop("SPLASH_HIP_POOL_CAP")

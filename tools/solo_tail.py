@@ -1,0 +1,85 @@
+"""How long is the spin-up's chain when the long job has a wavefront to ITSELF?  (round 4 experiment)
+
+In the tail launch the jobs are packed 64 to a wavefront, and a wavefront executes the union of its lanes'
+branches (finished lanes keep stepping).  If a long job alone executed markedly fewer instructions per day
+step, a final "solo" stage for the few hundred longest jobs would shorten the chain.  This measures it:
+  1. a full spin-up with the measurement build (-DSPL_TAIL_STATS) tells which cells run >= 900 tail iterations;
+  2. spin_up_begin again, then the pending list in the workspace is REPLACED by (a) one such cell, (b) 64 such
+     cells (one wavefront of long jobs), (c) left as it is; spin_up_finish is timed for each.
+    SPLASH_HIP_LIBRARY=gpurun_ab/lib_diff.so python tools/solo_tail.py [rows=1024] [row0=1536]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from rsplash_amd import api
+
+dev = torch.device("cuda:0")
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+r0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1536
+W, nt, SEED = 4096, 365, 20221130
+n = H * W
+cal = api.Calendar.from_dates(np.datetime64("2001-01-01") + np.arange(nt))
+f64 = dict(dtype=torch.float64, device=dev)
+lat, elev, slop, asp, res = (torch.empty(n, **f64) for _ in range(5))
+soil, au = torch.empty(6, n, **f64), torch.empty(3, n, **f64)
+api.dev_synth_statics(SEED, 4096, W, r0 * W, n, 1, lat, elev, slop, asp, res, soil, au)
+sw, tc, pn = (torch.empty(nt, n, **f64) for _ in range(3))
+api.dev_synth_forcing(SEED, cal, 0, nt, r0 * W, n, lat, elev, sw, tc, pn, n)
+par0 = torch.empty(api.NPAR, n, **f64)
+Tt = torch.empty(n, **f64)
+api.dev_soil_hydro(n, lat, elev, slop, asp, res, soil, au, par0)
+api.dev_snow_threshold(n, nt, tc, n, par0, n, Tt)
+al = lambda b: (b + 255) & ~255
+o_meta = al(n * 4) * 2
+o_cnt = al(n * 4) * 3 + al(n * 8)
+work = torch.zeros(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
+
+
+def begin():
+    par, state = par0.clone(), torch.empty(api.NSTATE, n, **f64)
+    api.dev_spin_up_begin(cal, n, sw, tc, pn, n, Tt, par, n, state, n, work)
+    torch.cuda.synchronize()
+    return par, state
+
+
+par, state = begin()
+t0 = time.perf_counter()
+api.dev_spin_up_finish(cal, n, sw, tc, pn, n, Tt, par, n, state, n, work)
+torch.cuda.synchronize()
+t_full = time.perf_counter() - t0
+meta = work[o_meta:o_meta + 4 * n].view(torch.int32).cpu().numpy()
+it = np.where(meta <= -100000, -(meta + 100000) - 2, 0)
+long_cells = np.nonzero(it >= 900)[0]
+cnt = work[o_cnt:o_cnt + 64].view(torch.int32)
+n_pend = int(cnt[6].item())
+print(f"{n} cells, {n_pend} jobs in the tail, {len(long_cells)} of them run >= 900 iterations; the whole tail: {t_full * 1e3:.1f} ms", flush=True)
+ref_state = state.clone()
+
+
+def tail_with(cells, label):
+    par, state = begin()
+    lst = torch.tensor(np.asarray(cells, dtype=np.int32), device=dev)
+    work[0:4 * len(cells)].view(torch.int32).copy_(lst)
+    cnt[6] = len(cells)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    api.dev_spin_up_finish(cal, n, sw, tc, pn, n, Tt, par, n, state, n, work)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = torch.equal(state[:, lst.long()].view(torch.int64), ref_state[:, lst.long()].view(torch.int64))
+    m = work[o_meta:o_meta + 4 * n].view(torch.int32)[lst.long()].cpu().numpy()
+    its = -(m + 100000) - 2
+    print(f"{label}: {dt * 1e3:.1f} ms, iterations {its.min()}..{its.max()}, same bits as in the full tail: {ok}", flush=True)
+    return dt
+
+
+for c in long_cells[:3]:
+    tail_with([int(c)], f"ONE long job (cell {int(c)}) on its own wavefront")
+tail_with(long_cells[:64], "64 long jobs = one wavefront")
+tail_with(long_cells[:8], "8 long jobs on one wavefront")
+tail_with(long_cells[:min(len(long_cells), 1024)], f"{min(len(long_cells), 1024)} long jobs packed 64 to a wavefront")
