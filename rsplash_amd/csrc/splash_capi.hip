@@ -487,6 +487,7 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
     double* const cache_all = (double*)(w + o_cache);
     a.cache_cap = spin_cache_cap(ncell);
     a.ntotal = ncell;
+    a.no_nd_skip = getenv("SPLASH_HIP_NO_ND_SKIP") ? 1 : 0; // tests: the detector of round 3 (same final bits, more passes)
     for (int ph = ph0; ph < ph1; ph++) {
         a.fresh = (ph == 0);
         a.budget = budget[ph];
@@ -541,7 +542,33 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
             a.budget = budget[ph] - 1;
             a.readback = 1;
             a.ncell = std::min(n_all, a.cache_cap);
-            HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+            const bool no_solo = getenv("SPLASH_HIP_NO_SOLO_TAIL") != nullptr; // A/B and tests: the round-3 tail (read per call)
+            if (ph == kSpinPhases - 1 && !no_solo) {
+                // The tail in two stages.  (A) kTailPacked passes with the jobs packed 64 to a wavefront: the
+                // cycle detector ends most jobs here.  (B) the survivors -- a few hundred of 16.7 M cells -- are
+                // dealt one (or a few) to a wavefront, where a job only executes the branches IT takes: a pass
+                // of the year in about half the time (k_spin_phase, "Spread").  Stage A queues the survivors by
+                // their position in this list, which stays their cache slot (wl_slots).
+                constexpr int kTailPacked = 64;
+                a.budget = kTailPacked;
+                a.queue_slots = 1;
+                a.pending = nullptr;
+                HIP_TRY(hipMemsetAsync(cnt + ph, 0, sizeof(uint32_t), s), nullptr, 0);
+                HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+                a.queue_slots = 0;
+                a.budget = budget[ph] - 1 - kTailPacked;
+                a.spread = 1;
+                a.wl_slots = wl[ph & 1];
+                a.n_in = cnt + ph;
+                a.no_queue = 1; // (the budget covers the 1000-pass cap: nothing is left to queue)
+                HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+                a.spread = 0;
+                a.wl_slots = nullptr;
+                a.n_in = cnt + (ph - 1);
+                a.no_queue = 0;
+            } else {
+                HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+            }
             a.readback = 0;
             if (n_all > a.cache_cap) {
                 a.slot0 = a.cache_cap;

@@ -359,11 +359,33 @@ template <bool CACHED, bool READBACK = false, bool RICH = false>
 __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPhaseArgs a)
 {
     const size_t nin = a.n_in ? (size_t)*a.n_in : a.ncell;
-    if ((size_t)blockIdx.x * kBlock + a.slot0 >= nin) return; // whole workgroup past the list
+    // Launch position -> job.  Packed (default): 64 jobs to a wavefront.  Spread (the tail's last stage,
+    // READBACK only): the jobs are dealt over 1024 wavefronts -- one per SIMD of the chip --, k = ceil(n / 1024)
+    // to each, and the other lanes of a wavefront leave at once.  A wavefront executes the union of the
+    // branches of its lanes: a job that has the wavefront to itself skips the rare branches (ponding, deep
+    // column, second transmittance, drainage time, snow) on the days IT does not take them and runs a pass
+    // of the year in half the time of a job packed with 63 others (measured: 530 against 1 035 ms for the
+    // 971 passes of the longest chains, tools/solo_tail.py, profiles/r04_spinup.md).
+    size_t slot;
+    bool valid;
+    if (READBACK && a.spread) {
+        size_t k = (nin + 1023) / 1024;
+        k = k < 1 ? 1 : (k > 64 ? 64 : k);
+        const size_t wave = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+        if ((size_t)blockIdx.x * (kBlock / 64) * k >= nin) return; // whole workgroup past the list
+        slot = wave * k + (threadIdx.x & 63);
+        valid = (threadIdx.x & 63) < k && slot < nin;
+    } else {
+        if ((size_t)blockIdx.x * kBlock + a.slot0 >= nin) return; // whole workgroup past the list
+        slot = (size_t)blockIdx.x * kBlock + threadIdx.x + a.slot0;
+        valid = slot < nin;
+    }
     lds_tables_init();
-    const size_t slot = (size_t)blockIdx.x * kBlock + threadIdx.x + a.slot0;
-    const bool valid = slot < nin;
-    const size_t sl = valid ? slot : nin - 1;
+    if (READBACK && a.spread && !valid) return; // (after the tables' barrier) the wavefront belongs to its k jobs
+    // the list may hold positions of ANOTHER list (wl_slots: the survivors of the tail's first stage keep
+    // the cache slot = position they had there)
+    const size_t sl0 = valid ? slot : nin - 1;
+    const size_t sl = a.wl_slots ? (size_t)a.wl_slots[sl0] : sl0;
     const size_t ci = a.wl_in ? (size_t)a.wl_in[sl] : a.cell0 + sl;
     const bool cached = CACHED && a.cache != nullptr && sl < a.cache_cap;
 
@@ -379,6 +401,10 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     DayOut o;
     double pet_sum = 0.0, p_sum = 0.0;
     bool finished_before = false; // a job of this list that an earlier launch of the phase completed
+    // "dry year": none of the 365 records has snowfall.  The snow age nd is then never reset and, once it
+    // has passed 64 days, never influences anything (see the cycle detector).  Established by a pass that
+    // forms the records (any_snf), carried by the parked job (bit 24 of meta), read by the read-back kernel.
+    bool dry = false, any_snf = false;
     if (!READBACK && a.fresh) {
         stage = 1;
         count = 1;
@@ -389,8 +415,9 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             finished_before = true;
             m = (2 << 16) | 1;
         }
-        stage = m >> 16;
+        stage = (m >> 16) & 0xFF;
         count = m & 0xFFFF;
+        dry = ((m >> 24) & 1) != 0;
         cell_setup(c, a.par, a.ldp, ci, stage == 1 ? a.par[P_CELLOUT * a.ldp + ci] : a.ai[ci], a.vt);
     }
     // The job's start-of-pass state (the state after day 1 of the current pass) is only needed
@@ -411,6 +438,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             f.raw(0, sw0, tc0, pn0);
             f.split<true>(d0, tc0, pn0, 0.0, r.rain, r.snf);
             asm volatile("" : "+v"(r.rain), "+v"(r.snf)); // finished doubles, like the terms below
+            any_snf = any_snf || (r.snf != 0.0);          // (true for NaN as well)
             day_terms(c, day_const(d0), day_prefetch(c, tc0), sw0, tc0, r.T);
             terms_fence(r.T);
             r.V = visc_terms(c, r.T);
@@ -486,6 +514,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 // are read back from the cache: the same bits from either kernel variant and from
                 // any split of the passes over launches
                 asm volatile("" : "+v"(r.rain), "+v"(r.snf));
+                any_snf = any_snf || (r.snf != 0.0);
                 day_terms(c, day_const(d), pre, swv, tcv, r.T);
                 terms_fence(r.T);
                 r.V = visc_terms(c, r.T);
@@ -508,6 +537,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         }
         State nxt = cur; // the closing day-1 step (:1674/:1729) == day 1 of the next pass
         day_one(nxt, o, nullptr);
+        if (!READBACK && it == 0) dry = !any_snf; // this launch's first pass has formed all 365 records
         double diff_sm = nxt.wn - e_wn; // end_sm - start_sm, :1678-1688
         if (diff_sm < 0) diff_sm = e_wn - nxt.wn;
 #ifdef SPL_DIFF_STATS
@@ -523,13 +553,25 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             if (cont) {
                 count++;
                 const int cc = s_chk_count[threadIdx.x];
-                const bool same = cc >= 0 && same_bits(nxt.wn, s_chk[0][threadIdx.x]) &&
-                                  same_bits(nxt.snow, s_chk[1][threadIdx.x]) &&
-                                  same_bits(nxt.qin, s_chk[2][threadIdx.x]) &&
-                                  same_bits(nxt.td, s_chk[3][threadIdx.x]) &&
-                                  same_bits(nxt.nd, s_chk[4][threadIdx.x]);
+                const bool same4 = cc >= 0 && same_bits(nxt.wn, s_chk[0][threadIdx.x]) &&
+                                   same_bits(nxt.snow, s_chk[1][threadIdx.x]) &&
+                                   same_bits(nxt.qin, s_chk[2][threadIdx.x]) &&
+                                   same_bits(nxt.td, s_chk[3][threadIdx.x]);
+                const double nd_chk = s_chk[4][threadIdx.x];
+                const bool same_nd = same_bits(nxt.nd, nd_chk);
+                // The snow age nd (days since the last snowfall, src/SPLASH.cpp:1225-1229) is part of the state
+                // but, in a dry year, not of the dynamics: without snowfall it is never reset, grows by one per
+                // day step, and is read in one place only -- the snow albedo 0.5563 + 0.4437 exp(-0.895189 nd),
+                // src/SOLAR.cpp:208 -- where from nd = 64 on the second term (< 6e-26) is below half an ulp of the
+                // first: the sum IS 0.5563 whatever nd.  So if wn, snow, qin and td repeat bit for bit and nd was
+                // >= 64 at the checkpoint, the same days follow for good; nd after k skipped passes is nd + 365 k,
+                // exactly (integers far below 2^53).  Round 4: at low latitudes 0.1 % of the cells sat in such
+                // 2-cycles and ran ~1000 passes each because nd never repeats (profiles/r04_spinup.md).
+                const bool same = same4 && (same_nd || (dry && nd_chk >= 64.0 && !a.no_nd_skip));
                 if (same) {
-                    count = 1000 - ((1000 - count) % (count - cc));
+                    const int left = (1000 - count) % (count - cc);
+                    if (!same_nd) nxt.nd += (double)a.n * (double)((1000 - count) - left); // one per skipped day step
+                    count = 1000 - left;
                     s_chk_count[threadIdx.x] = -1; // the remaining < lam passes run plainly
                 } else if (((it + 1) & it) == 0) { // it + 1 = passes in this phase: 1, 2, 4, 8, ...
                     s_chk[0][threadIdx.x] = nxt.wn;
@@ -580,11 +622,11 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         a.state[2 * a.lds + ci] = s_e[2][threadIdx.x];
         a.state[3 * a.lds + ci] = s_e[3][threadIdx.x];
         a.state[4 * a.lds + ci] = s_e[4][threadIdx.x];
-        a.meta[ci] = (stage << 16) | count;
+        a.meta[ci] = (stage << 16) | count | (dry ? (1 << 24) : 0);
         if (!a.no_queue) {
             if (a.pending) a.pending[ci] = 1;
             const uint32_t k = atomicAdd(a.n_out, 1u);
-            a.wl_out[k] = (uint32_t)ci;
+            a.wl_out[k] = a.queue_slots ? (uint32_t)sl : (uint32_t)ci; // (the tail's first stage queues positions: see wl_slots)
         }
     }
 }
@@ -1721,10 +1763,13 @@ hipError_t launch_snow_threshold(size_t ncell, int nt, const double* tc, size_t 
 hipError_t launch_spin_phase(const SpinPhaseArgs& a, hipStream_t s)
 {
     if (a.ncell == 0) return hipSuccess;
+    if (a.spread && !a.readback) return hipErrorInvalidValue;
+    // spread: 1024 wavefronts (256 workgroups) take ceil(n/1024) jobs each; more only for lists beyond 65 536 jobs
+    const unsigned g_rb = a.spread ? std::max(nblk(a.ncell, kBlock), 256u) : nblk(a.ncell, kBlock);
     if (a.readback && a.rich)
-        hipLaunchKernelGGL((k_spin_phase<true, true, true>), dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL((k_spin_phase<true, true, true>), dim3(g_rb), dim3(kBlock), 0, s, a);
     else if (a.readback)
-        hipLaunchKernelGGL((k_spin_phase<true, true, false>), dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL((k_spin_phase<true, true, false>), dim3(g_rb), dim3(kBlock), 0, s, a);
     else if (a.cache && a.rich)
         hipLaunchKernelGGL((k_spin_phase<true, false, true>), dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
     else if (a.cache)

@@ -1667,3 +1667,46 @@ def test_product_bits_are_pinned(api, oracle):
     moved = [k for k in want["sha256"] if got["sha256"][k] != want["sha256"][k]]
     assert not moved, f"bits moved in: {moved} (pinned by: {want.get('why', '')!r})"
     assert got["passes2_sum"] == want["passes2_sum"]
+
+
+@pytest.mark.gpu
+def test_cycle_detector_ignores_an_idle_snow_age(api, oracle):
+    """Round 4: the spin-up's exact-cycle detector (k_spin_phase) no longer needs the snow age nd to repeat
+    in a dry year (no record of the 365 has snowfall: nd is never reset) once it has passed 64 days (from
+    there on the snow albedo 0.5563 + 0.4437 exp(-0.895 nd) IS 0.5563): wn, snow, qin and td then evolve
+    without it, a bit-for-bit repeat of those four is a cycle for good, and nd is advanced by 365 per
+    skipped pass.  Two rows at the equator of the benchmark grid (no snow all year,
+    0.1 % of the cells in an exact 2-cycle of more than 1 mm): the spun-up state -- nd included --, the
+    aridity index, the pass counts and every daily series must equal, bit for bit, what the round-3
+    detector (SPLASH_HIP_NO_ND_SKIP=1: compares nd as well, i.e. runs those cells ~1000 passes) leaves;
+    the pass counts must also be the oracle's, which iterates all passes (src/SPLASH.cpp:1697-1743)."""
+    import os
+    Htot = W = 4096
+    r0, rows = 2040, 2
+    os.environ.pop("SPLASH_HIP_NO_ND_SKIP", None)
+    a = device_pipeline(api, 20221130, Htot, W, r0 * W, rows * W, 365, 1, want_passes=True)
+    os.environ["SPLASH_HIP_NO_ND_SKIP"] = "1"
+    os.environ["SPLASH_HIP_NO_SOLO_TAIL"] = "1"   # and the tail in one packed stage, as in round 3
+    try:
+        b = device_pipeline(api, 20221130, Htot, W, r0 * W, rows * W, 365, 1, want_passes=True)
+    finally:
+        os.environ.pop("SPLASH_HIP_NO_ND_SKIP")
+        os.environ.pop("SPLASH_HIP_NO_SOLO_TAIL")
+    capped = a["passes"][1] >= 1000
+    bare = ~(a["out"]["snow"] > 0).any(0) & (a["state0"][1] == 0)   # the case this is about: no snow at all
+    assert (capped & bare).sum() >= 5, (capped.sum(), (capped & bare).sum())
+    assert (a["state0"][4][capped & bare] >= 365000 - 2 * 365).all()   # nd after 1000 passes of 365 days
+    assert np.array_equal(a["passes"], b["passes"])
+    for k in ("state0", "state1", "par", "Tt"):
+        assert np.array_equal(a[k].view(np.int64), b[k].view(np.int64)), k
+    for k in a["out"]:
+        assert np.array_equal(a["out"][k].view(np.int64), b["out"][k].view(np.int64)), k
+    # the oracle's pass counts for the capped cells and a sample of the others (it really iterates)
+    doy, year, month, mid, nm = oracle.calendar(2001, 365)
+    sel = np.r_[np.nonzero(capped)[0][:12], np.arange(0, rows * W, 997)]
+    st = {k: (v[:, sel] if v.ndim == 2 else v[sel]) for k, v in a["statics"].items()}
+    ref, aux = oracle.grid(doy, year, month, mid, nm, np.ascontiguousarray(a["sw"][:, sel]),
+                           np.ascontiguousarray(a["tc"][:, sel]), np.ascontiguousarray(a["pn"][:, sel]), st["lat"],
+                           st["elev"], st["slop"], st["asp"], st["soil"], st["au"], st["resolution"])
+    agree = aux["passes2"].astype(np.int64) == a["passes"][1][sel]
+    assert agree.mean() >= 0.98 and agree[:min(12, int(capped.sum()))].all(), (aux["passes2"], a["passes"][1][sel])
