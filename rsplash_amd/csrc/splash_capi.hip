@@ -549,7 +549,8 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
                 // dealt one (or a few) to a wavefront, where a job only executes the branches IT takes: a pass
                 // of the year in about half the time (k_spin_phase, "Spread").  Stage A queues the survivors by
                 // their position in this list, which stays their cache slot (wl_slots).
-                constexpr int kTailPacked = 64;
+                int kTailPacked = 64;
+                if (const char* e = getenv("SPLASH_HIP_TAIL_PACKED")) kTailPacked = std::max(1, std::min(512, atoi(e))); // experiments
                 a.budget = kTailPacked;
                 a.queue_slots = 1;
                 a.pending = nullptr;

@@ -256,6 +256,11 @@ constexpr int kNRecCompact = kNTermWords + 2;
 constexpr int kNRecRich = kNRecCompact + 4; // (words that carry data; kRichStride in memory)
 static_assert(kNRecRich <= 20, "rich record");
 constexpr int kRichStride = 20; // words per rich record in memory (16-byte aligned pairs)
+// Round 4: rich records are laid out JOB by job, [slot][day][20]: a job's year is 58 KB of consecutive memory.
+// Day by day ([day][slot][20], round 3) the next day's record lay cap x 160 B = 63 MB further on -- a new page
+// every day -- and a job alone on its wavefront (the tail's last stage, 1.7 us per day step) waited for it on
+// most CUs: the same job took 600 to 1 590 ms depending on where it ran (tools/solo_tail.py, SOLO_SAME).
+constexpr size_t kRichDays = 365;
 struct DayRecord {
     DayTerms T;
     ViscTerms V;
@@ -272,7 +277,7 @@ __device__ __forceinline__ void rec_store(double* __restrict__ base, size_t cap,
                                    r.T.econ, r.T.inv_econ, r.T.eetc, r.T.pw, __longlong_as_double((long long)vw),
                                    r.rain, r.snf, r.T.rv, r.V.ipk, r.V.kv, r.V.ikv24, 0.0};
     if constexpr (RICH) {
-        double2* p = reinterpret_cast<double2*>(base + ((size_t)day * cap + slot) * kRichStride);
+        double2* p = reinterpret_cast<double2*>(base + (slot * kRichDays + (size_t)day) * kRichStride);
 #pragma unroll
         for (int k = 0; k < kRichStride / 2; k++) p[k] = double2{v[2 * k], v[2 * k + 1]};
     } else {
@@ -294,7 +299,7 @@ __device__ __forceinline__ RawRecord<RICH> rec_load(const double* __restrict__ b
 {
     RawRecord<RICH> w;
     if constexpr (RICH) {
-        const double2* p = reinterpret_cast<const double2*>(base + ((size_t)day * cap + slot) * kRichStride);
+        const double2* p = reinterpret_cast<const double2*>(base + (slot * kRichDays + (size_t)day) * kRichStride);
 #pragma unroll
         for (int k = 0; k < kRichStride / 2; k++) {
             const double2 x = p[k];
@@ -358,6 +363,9 @@ __device__ __forceinline__ DayRecord rec_decode(const CellConst& c, const RawRec
 template <bool CACHED, bool READBACK = false, bool RICH = false>
 __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPhaseArgs a)
 {
+#if defined(SPL_TAIL_STATS) && defined(SPL_DIFF_STATS)
+    const unsigned long long t_wave_start = wall_clock64();
+#endif
     const size_t nin = a.n_in ? (size_t)*a.n_in : a.ncell;
     // Launch position -> job.  Packed (default): 64 jobs to a wavefront.  Spread (the tail's last stage,
     // READBACK only): the jobs are dealt over 1024 wavefronts -- one per SIMD of the chip --, k = ceil(n / 1024)
@@ -367,21 +375,28 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     // of the year in half the time of a job packed with 63 others (measured: 530 against 1 035 ms for the
     // 971 passes of the longest chains, tools/solo_tail.py, profiles/r04_spinup.md).
     size_t slot;
-    bool valid;
+    bool valid, writer = true;
     if (READBACK && a.spread) {
         size_t k = (nin + 1023) / 1024;
         k = k < 1 ? 1 : (k > 64 ? 64 : k);
         const size_t wave = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
         if ((size_t)blockIdx.x * (kBlock / 64) * k >= nin) return; // whole workgroup past the list
-        slot = wave * k + (threadIdx.x & 63);
-        valid = (threadIdx.x & 63) < k && slot < nin;
+        // The other lanes of the wavefront REPEAT its k jobs (lane % k) -- same data, same branches, nothing
+        // added to what the wavefront executes -- instead of leaving: a wavefront with one active lane ran the
+        // same job in 600 ms on some CUs and in up to 1 590 ms on others, with all 64 lanes active in 576-580 ms
+        // on every CU (tools/solo_tail.py SOLO_SAME; no micro-benchmark of ours reproduces it: tools/ubench/cu_variance*).
+        // Only the first k lanes store anything (`writer`).
+        slot = wave * k + ((threadIdx.x & 63) % k);
+        if (slot >= nin) slot = wave * k;
+        valid = slot < nin;
+        writer = (threadIdx.x & 63) < k && wave * k + (threadIdx.x & 63) < nin;
     } else {
         if ((size_t)blockIdx.x * kBlock + a.slot0 >= nin) return; // whole workgroup past the list
         slot = (size_t)blockIdx.x * kBlock + threadIdx.x + a.slot0;
         valid = slot < nin;
     }
     lds_tables_init();
-    if (READBACK && a.spread && !valid) return; // (after the tables' barrier) the wavefront belongs to its k jobs
+    if (READBACK && a.spread && !valid) return; // (a wavefront past the list; after the tables' barrier)
     // the list may hold positions of ANOTHER list (wl_slots: the survivors of the tail's first stage keep
     // the cache slot = position they had there)
     const size_t sl0 = valid ? slot : nin - 1;
@@ -495,7 +510,9 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             RawRecord<RICH> w = rec_load<RICH>(a.cache, a.cache_cap, 1, sl);
             for (int i = 1; i < a.n; i++) {
                 const DayRecord r = rec_decode<RICH>(c, w, RICH ? 0.0 : days[i].cd);
+#ifndef SPL_NOLOAD // (experiment: every day uses the first record -- wrong results, the loop's timing without its loads)
                 if (i + 1 < a.n) w = rec_load<RICH>(a.cache, a.cache_cap, i + 1, sl); // tomorrow's, untouched until tomorrow
+#endif
                 day_update(c, r.T, r.V, r.rain, r.snf, cur, o);
             }
         } else if constexpr (!READBACK) {
@@ -597,13 +614,27 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 park_e(cur);
                 e_wn = cur.wn;
             } else {
-                a.state[ci] = cur.wn; // initial$sm[365] etc., R/splash.point.R:164-172
-                a.state[a.lds + ci] = cur.snow;
-                a.state[2 * a.lds + ci] = cur.qin;
-                a.state[3 * a.lds + ci] = cur.td;
-                a.state[4 * a.lds + ci] = cur.nd;
-                if (a.passes) a.passes[a.ntotal + ci] = count;
+                if (writer) {
+                    a.state[ci] = cur.wn; // initial$sm[365] etc., R/splash.point.R:164-172
+                    a.state[a.lds + ci] = cur.snow;
+                    a.state[2 * a.lds + ci] = cur.qin;
+                    a.state[3 * a.lds + ci] = cur.td;
+                    a.state[4 * a.lds + ci] = cur.nd;
+                    if (a.passes) a.passes[a.ntotal + ci] = count;
+                }
 #ifdef SPL_TAIL_STATS
+#ifdef SPL_DIFF_STATS
+                if (READBACK && g_diff_dbg) { // when (ms since the wavefront started) and where the job ended
+                    g_diff_dbg[(size_t)6 * a.ntotal + ci] = (float)((double)(wall_clock64() - t_wave_start) * 1e-5);
+                    unsigned hwid;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                    unsigned xcc;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                    g_diff_dbg[(size_t)7 * a.ntotal + ci] = (float)((hwid & 0xFFFF) | ((xcc & 0xF) << 16));
+                    g_diff_dbg[(size_t)4 * a.ntotal + slot] = (float)((double)(wall_clock64() - t_wave_start) * 1e-5); // by list position
+                    g_diff_dbg[(size_t)5 * a.ntotal + slot] = (float)((hwid & 0xFFFF) | ((xcc & 0xF) << 16));
+                }
+#endif
                 a.meta[ci] = -(it + 2) - (READBACK ? 100000 : 0); // executed iterations of this launch
 #else
                 a.meta[ci] = -1; // completed (a later launch over the same list leaves it alone)
@@ -615,7 +646,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         }
         if (__all(done)) break;
     }
-    if (!done && valid && !finished_before && !(READBACK && !cached)) { // park the job (its start-of-pass
+    if (!done && valid && writer && !finished_before && !(READBACK && !cached)) { // park the job (its start-of-pass
                                                                         // state), queue the cell for the next phase
         a.state[ci] = s_e[0][threadIdx.x];
         a.state[a.lds + ci] = s_e[1][threadIdx.x];
