@@ -399,7 +399,7 @@ def run_resident(ctx):
     mask_p, cells_p, ncells_p = api.dev_spin_up_pending(work, n)
     late_cap = max(4096, n // 64)
     late = {k: torch.empty(nt, late_cap, **f64) for k in OUT5}  # noqa
-    s2 = torch.cuda.Stream(device=dev)
+    s2 = torch.cuda.Stream(device=dev, priority=-1)   # the tail's stream: its few workgroups are dispatched first
     par_i = par.clone()
     par_i[15] = par0_cellout
     torch.cuda.synchronize()

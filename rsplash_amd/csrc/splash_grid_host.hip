@@ -172,6 +172,13 @@ struct Stream {
         }
     }
     hipError_t create() { return hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+    // for the straggler pool's tail: a few wavefronts on the critical path of the call, dispatched ahead of the lanes' work
+    hipError_t create_high_priority()
+    {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return create();
+        return hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi);
+    }
 };
 struct Event {
     hipEvent_t e = nullptr;
@@ -652,7 +659,7 @@ int Worker::finish_pool(char* err, size_t errlen)
     const size_t cap = pool.cap;
     const int nt = P.nt, nt_out = P.nt_out, n_out = P.n_out;
     Stream st;
-    HIP_TRY(st.create(), err, errlen);
+    HIP_TRY(st.create_high_priority(), err, errlen);
     hipStream_t s = st.s;
     {
         std::unique_lock<std::mutex> lk(mu);

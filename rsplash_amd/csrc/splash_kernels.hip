@@ -397,6 +397,9 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     }
     lds_tables_init();
     if (READBACK && a.spread && !valid) return; // (a wavefront past the list; after the tables' barrier)
+    // The tail is the critical path of a call and a handful of wavefronts; whatever shares a SIMD with them (the
+    // transient run of the finished cells, launched beside it) is throughput work: the tail's wavefronts issue first.
+    if (READBACK && RICH) __builtin_amdgcn_s_setprio(3);
     // the list may hold positions of ANOTHER list (wl_slots: the survivors of the tail's first stage keep
     // the cache slot = position they had there)
     const size_t sl0 = valid ? slot : nin - 1;

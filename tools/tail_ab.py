@@ -32,12 +32,16 @@ o_cnt = al(n * 4) * 3 + al(n * 8)
 work = torch.zeros(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
 cnt = work[o_cnt:o_cnt + 64].view(torch.int32)
 ref = None
+modes = ["packed only", "packed + spread"] + [f"packed {p} + spread" for p in os.environ.get("PACKED_SWEEP", "").split(",") if p]
 for rep in range(2):
-    for mode in ("packed only", "packed + spread"):
+    for mode in modes:
+        os.environ.pop("SPLASH_HIP_TAIL_PACKED", None)
         if mode == "packed only":
             os.environ["SPLASH_HIP_NO_SOLO_TAIL"] = "1"
         else:
             os.environ.pop("SPLASH_HIP_NO_SOLO_TAIL", None)
+            if mode.split()[1].isdigit():
+                os.environ["SPLASH_HIP_TAIL_PACKED"] = mode.split()[1]
         par, state = par0.clone(), torch.empty(api.NSTATE, n, **f64)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -51,5 +55,5 @@ for rep in range(2):
         same = "-" if ref is None else bool(torch.equal(state.view(torch.int64), ref.view(torch.int64)))
         if ref is None:
             ref = state.clone()
-        print(f"{mode:16s}: begin {1e3 * (t1 - t0):7.1f} ms, tail {1e3 * (t2 - t1):7.1f} ms; jobs per phase list {c[:8].tolist()}; "
+        print(f"{mode:20s}: begin {1e3 * (t1 - t0):7.1f} ms, tail {1e3 * (t2 - t1):7.1f} ms; jobs per phase list {c[:8].tolist()}; "
               f"same bits as the first run: {same}", flush=True)
