@@ -544,12 +544,12 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
             a.ncell = std::min(n_all, a.cache_cap);
             const bool no_solo = getenv("SPLASH_HIP_NO_SOLO_TAIL") != nullptr; // A/B and tests: the round-3 tail (read per call)
             if (ph == kSpinPhases - 1 && !no_solo) {
-                // The tail in two stages.  (A) kTailPacked passes with the jobs packed 64 to a wavefront: the
+                // The tail in two stages.  (A) kTailPacked passes (96) with the jobs packed 64 to a wavefront: the
                 // cycle detector ends most jobs here.  (B) the survivors -- a few hundred of 16.7 M cells -- are
                 // dealt one (or a few) to a wavefront, where a job only executes the branches IT takes: a pass
                 // of the year in about half the time (k_spin_phase, "Spread").  Stage A queues the survivors by
                 // their position in this list, which stays their cache slot (wl_slots).
-                int kTailPacked = 64;
+                int kTailPacked = 96; // (measured, 16.7 M cells: 64 leaves 1 305 survivors = 2 to a wavefront, 768 ms; 96: 881, 663 ms; 128: 796, 675 ms)
                 if (const char* e = getenv("SPLASH_HIP_TAIL_PACKED")) kTailPacked = std::max(1, std::min(512, atoi(e))); // experiments
                 a.budget = kTailPacked;
                 a.queue_slots = 1;
