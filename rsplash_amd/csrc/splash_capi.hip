@@ -397,6 +397,7 @@ extern "C" int splash_dev_snow_threshold(size_t ncell, int nt, const double* tc,
 // workspace of splash_dev_spin_up: two worklists, job records, aridity index, phase counters, and
 // the cache of state-independent day terms: 365 x 19 doubles per slot, 2^19 slots at most (29 GB).
 // Phase 0 walks the cells in blocks of that many; the later phases' worklists are far shorter.
+constexpr size_t kSpinSnapshots = 1024;
 static size_t spin_cache_cap(size_t ncell)
 {
     size_t lim = (size_t)1 << 19;
@@ -418,7 +419,7 @@ size_t splash::host::spin_work_layout(size_t ncell, size_t* o_wl_b, size_t* o_me
         return at;
     };
     take(ncell * 4); // wl_a at 0
-    size_t wl_b = take(ncell * 4), meta = take(ncell * 4), ai = take(ncell * 8), cnt = take(64);
+    size_t wl_b = take(ncell * 4), meta = take(ncell * 4), ai = take(ncell * 8), cnt = take(64 + 4 * kSpinSnapshots); // 16 counters + list positions per block of phase 0
     size_t pend = take(ncell);
     size_t cache = take(spin_cache_cap(ncell) * spin_cache_bytes_per_slot());
     if (o_pend) *o_pend = pend;
@@ -488,7 +489,9 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
     a.cache_cap = spin_cache_cap(ncell);
     a.ntotal = ncell;
     a.no_nd_skip = getenv("SPLASH_HIP_NO_ND_SKIP") ? 1 : 0; // tests: the detector of round 3 (same final bits, more passes)
+    bool phase1_done_per_block = false;
     for (int ph = ph0; ph < ph1; ph++) {
+        if (ph == 1 && phase1_done_per_block) continue;
         a.fresh = (ph == 0);
         a.budget = budget[ph];
         a.wl_in = ph == 0 ? nullptr : wl[(ph - 1) & 1];
@@ -506,7 +509,17 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
             // records), then the other passes of the phase by the read-back kernel, which is the
             // smaller program (see k_spin_phase<true, true>) and does the queueing
             const bool split = a.cache != nullptr && budget[ph] >= 2;
-            for (size_t c0 = 0; c0 < ncell; c0 += a.cache_cap) {
+            // Phase 1 -- one more pass for what phase 0 leaves, two thirds of the cells -- is run block by block
+            // too, right behind the block's phase 0, while the block's records are still in the cache: a read-back
+            // pass (1 360 instructions per day step) instead of a pass of the general kernel, which forms the day
+            // terms again (1 900).  The block's survivors are the entries phase 0 has just appended to its list,
+            // from a position only the device knows (snapshot of the counter -> first_dev); a job's cache slot is
+            // its cell's position in the block.  Same bits (the records are what the general kernel would form).
+            static const bool no_p1 = getenv("SPLASH_HIP_NO_BLOCK_PHASE1") != nullptr; // A/B: the round-3 order
+            const bool block_p1 = split && !no_p1 && ph1 > 1 && (ncell + a.cache_cap - 1) / a.cache_cap <= kSpinSnapshots;
+            uint32_t* const snap = cnt + 16;
+            size_t blk = 0;
+            for (size_t c0 = 0; c0 < ncell; c0 += a.cache_cap, blk++) {
                 a.cell0 = c0;
                 a.ncell = std::min(a.cache_cap, ncell - c0);
                 if (split) {
@@ -517,7 +530,24 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
                     a.no_queue = 0;
                     a.fresh = 0;
                     a.readback = 1;
+                    if (block_p1) HIP_TRY(hipMemcpyAsync(snap + blk, cnt, sizeof(uint32_t), hipMemcpyDeviceToDevice, s), nullptr, 0);
                     HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+                    if (block_p1) { // phase 1 of this block's survivors: wl[0][snap, cnt[0]) -> wl[1]
+                        a.budget = budget[1];
+                        a.wl_in = wl[0];
+                        a.n_in = cnt;
+                        a.first_dev = snap + blk;
+                        a.slot_by_cell = 1;
+                        a.wl_out = wl[1];
+                        a.n_out = cnt + 1;
+                        HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+                        a.wl_in = nullptr;
+                        a.n_in = nullptr;
+                        a.first_dev = nullptr;
+                        a.slot_by_cell = 0;
+                        a.wl_out = wl[0];
+                        a.n_out = cnt;
+                    }
                     a.readback = 0;
                     a.fresh = 1;
                 } else {
@@ -526,6 +556,7 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
             }
             a.cell0 = 0;
             a.ncell = ncell;
+            phase1_done_per_block = block_p1;
         } else if (a.cache && budget[ph] > 1) {
             // A phase of several passes as three launches over the SAME worklist (launch positions =
             // cache slots): one pass of the general kernel stores every job's 365 records (it parks

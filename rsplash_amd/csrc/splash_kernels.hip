@@ -391,8 +391,11 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         valid = slot < nin;
         writer = (threadIdx.x & 63) < k && wave * k + (threadIdx.x & 63) < nin;
     } else {
-        if ((size_t)blockIdx.x * kBlock + a.slot0 >= nin) return; // whole workgroup past the list
-        slot = (size_t)blockIdx.x * kBlock + threadIdx.x + a.slot0;
+        // (first_dev: the launch covers the list from a position known on the device only -- the survivors a
+        // block of phase 0 has just appended, see spin_phases)
+        const size_t first = a.slot0 + (a.first_dev ? (size_t)*a.first_dev : 0);
+        if ((size_t)blockIdx.x * kBlock + first >= nin) return; // whole workgroup past the list
+        slot = (size_t)blockIdx.x * kBlock + threadIdx.x + first;
         valid = slot < nin;
     }
     lds_tables_init();
@@ -405,7 +408,10 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     const size_t sl0 = valid ? slot : nin - 1;
     const size_t sl = a.wl_slots ? (size_t)a.wl_slots[sl0] : sl0;
     const size_t ci = a.wl_in ? (size_t)a.wl_in[sl] : a.cell0 + sl;
-    const bool cached = CACHED && a.cache != nullptr && sl < a.cache_cap;
+    // cache slot: the job's position in the launch, or (slot_by_cell) its cell's position in the block of
+    // phase 0 whose records are still in the cache
+    const size_t cs = a.slot_by_cell ? ci - a.cell0 : sl;
+    const bool cached = CACHED && a.cache != nullptr && cs < a.cache_cap;
 
     s_cell_Tt[threadIdx.x] = a.Tt[ci]; // own slot: no barrier needed
     Forcing f{a.sw, a.tc, a.pn, nullptr, a.ldf, 0.0,
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     auto day_one = [&](State& st_, DayOut& o_, double* p_day) {
         DayRecord r;
         if (READBACK || (CACHED && cached && p_day == nullptr)) {
-            r = rec_decode<RICH>(c, rec_load<RICH>(a.cache, a.cache_cap, 0, sl), d0.cd);
+            r = rec_decode<RICH>(c, rec_load<RICH>(a.cache, a.cache_cap, 0, cs), d0.cd);
         } else if constexpr (!READBACK) {
             double sw0, tc0, pn0;
             f.raw(0, sw0, tc0, pn0);
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             day_terms(c, day_const(d0), day_prefetch(c, tc0), sw0, tc0, r.T);
             terms_fence(r.T);
             r.V = visc_terms(c, r.T);
-            if (CACHED && cached) rec_store<RICH>(a.cache, a.cache_cap, 0, sl, r);
+            if (CACHED && cached) rec_store<RICH>(a.cache, a.cache_cap, 0, cs, r);
         }
         if (p_day) *p_day = r.rain + r.snf;
         day_update(c, r.T, r.V, r.rain, r.snf, st_, o_);
@@ -510,11 +516,11 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         // cur = state after day 1 of this pass (== the parked start-of-pass state)
         if (READBACK || (CACHED && cached && it > 0)) {
             // read-back pass: next day's record is requested a day ahead
-            RawRecord<RICH> w = rec_load<RICH>(a.cache, a.cache_cap, 1, sl);
+            RawRecord<RICH> w = rec_load<RICH>(a.cache, a.cache_cap, 1, cs);
             for (int i = 1; i < a.n; i++) {
                 const DayRecord r = rec_decode<RICH>(c, w, RICH ? 0.0 : days[i].cd);
 #ifndef SPL_NOLOAD // (experiment: every day uses the first record -- wrong results, the loop's timing without its loads)
-                if (i + 1 < a.n) w = rec_load<RICH>(a.cache, a.cache_cap, i + 1, sl); // tomorrow's, untouched until tomorrow
+                if (i + 1 < a.n) w = rec_load<RICH>(a.cache, a.cache_cap, i + 1, cs); // tomorrow's, untouched until tomorrow
 #endif
                 day_update(c, r.T, r.V, r.rain, r.snf, cur, o);
             }
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
                 const int in_ = i + 1 < a.n ? i + 1 : i; // the last day reads its own row again
                 double swn, tcn, pnn;
                 f.raw(in_, swn, tcn, pnn);
-                if (CACHED && cached) rec_store<RICH>(a.cache, a.cache_cap, i, sl, r);
+                if (CACHED && cached) rec_store<RICH>(a.cache, a.cache_cap, i, cs, r);
                 day_update(c, r.T, r.V, r.rain, r.snf, cur, o);
                 if (acc) { // pet_vec is only filled in the first pass (:1667), Pinit = rain + snow
                     const double pday = r.rain + r.snf;

@@ -78,6 +78,8 @@ struct SpinPhaseArgs {
     int readback;           // 1: the read-back kernel (every job's records are in the cache already)
     int no_queue;           // 1: park unfinished jobs without queueing them (a launch over the same
                             //    cells follows and does the queueing)
+    const uint32_t* first_dev; // optional (packed launches): device-side first list position of this launch
+    int slot_by_cell;       // 1: a job's cache slot is its cell's position in the block (cell - cell0), not its launch position
     int spread;             // read-back kernel only: deal the jobs over 1024 wavefronts (ceil(n/1024) each) instead of packing
                             //    64 to a wavefront -- the tail's last stage (see k_spin_phase)
     const uint32_t* wl_slots; // optional: the launch's list holds POSITIONS of wl_in (and cache slots), not cells
