@@ -409,6 +409,8 @@ static size_t spin_cache_cap(size_t ncell)
     return (cap + 63) & ~(size_t)63;
 }
 
+static size_t g_spin_wl_c_offset(size_t ncell); // third worklist (the tail's cascade), see below
+
 size_t splash::host::spin_work_layout(size_t ncell, size_t* o_wl_b, size_t* o_meta, size_t* o_ai,
                                       size_t* o_cnt, size_t* o_cache, size_t* o_pend)
 {
@@ -421,6 +423,7 @@ size_t splash::host::spin_work_layout(size_t ncell, size_t* o_wl_b, size_t* o_me
     take(ncell * 4); // wl_a at 0
     size_t wl_b = take(ncell * 4), meta = take(ncell * 4), ai = take(ncell * 8), cnt = take(64 + 4 * kSpinSnapshots); // 16 counters + list positions per block of phase 0
     size_t pend = take(ncell);
+    take(ncell * 4); // wl_c: a third list for the tail's cascade (g_spin_wl_c_offset)
     size_t cache = take(spin_cache_cap(ncell) * spin_cache_bytes_per_slot());
     if (o_pend) *o_pend = pend;
     if (o_wl_b) *o_wl_b = wl_b;
@@ -429,6 +432,13 @@ size_t splash::host::spin_work_layout(size_t ncell, size_t* o_wl_b, size_t* o_me
     if (o_cnt) *o_cnt = cnt;
     if (o_cache) *o_cache = cache;
     return off;
+}
+
+static size_t g_spin_wl_c_offset(size_t ncell)
+{
+    size_t o_pend;
+    spin_work_layout(ncell, nullptr, nullptr, nullptr, nullptr, nullptr, &o_pend);
+    return o_pend + ((ncell + 255) & ~(size_t)255);
 }
 
 extern "C" size_t splash_dev_spin_up_work_size(size_t ncell)
@@ -575,29 +585,49 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
             a.ncell = std::min(n_all, a.cache_cap);
             const bool no_solo = getenv("SPLASH_HIP_NO_SOLO_TAIL") != nullptr; // A/B and tests: the round-3 tail (read per call)
             if (ph == kSpinPhases - 1 && !no_solo) {
-                // The tail in two stages.  (A) kTailPacked passes (96) with the jobs packed 64 to a wavefront: the
-                // cycle detector ends most jobs here.  (B) the survivors -- a few hundred of 16.7 M cells -- are
-                // dealt one (or a few) to a wavefront, where a job only executes the branches IT takes: a pass
-                // of the year in about half the time (k_spin_phase, "Spread").  Stage A queues the survivors by
-                // their position in this list, which stays their cache slot (wl_slots).
-                int kTailPacked = 96; // (measured, 16.7 M cells: 64 leaves 1 305 survivors = 2 to a wavefront, 768 ms; 96: 881, 663 ms; 128: 796, 675 ms)
-                if (const char* e = getenv("SPLASH_HIP_TAIL_PACKED")) kTailPacked = std::max(1, std::min(512, atoi(e))); // experiments
-                a.budget = kTailPacked;
-                a.queue_slots = 1;
+                // The tail as a cascade of read-back launches over shrinking lists, every one of them SPREAD: the
+                // jobs dealt over 1 024 wavefronts, ceil(n / 1024) to each, the other lanes repeating them
+                // (k_spin_phase, "Spread": a wavefront executes the union of its jobs' branches; ONE job runs a
+                // pass of the year in about half the time of 64 packed together).  The cycle detector ends most
+                // jobs within the first hundred passes, so: 32 passes (8 837 jobs of the benchmark grid: 9 to a
+                // wavefront), 64 passes (2 319: 3 to a wavefront), the rest (881: one each).  A stage queues its
+                // survivors by their position in the tail's list, which stays their cache slot (wl_slots).
+                // SPLASH_HIP_TAIL_STAGES="a,b" sets the first two budgets (experiments).
+                int stage_budget[3] = {32, 64, 0};
+                if (const char* e = getenv("SPLASH_HIP_TAIL_STAGES")) {
+                    int b0 = 0, b1 = 0;
+                    if (sscanf(e, "%d,%d", &b0, &b1) == 2) {
+                        stage_budget[0] = std::max(0, std::min(400, b0));
+                        stage_budget[1] = std::max(0, std::min(400, b1));
+                    }
+                }
+                stage_budget[2] = budget[ph] - 1 - stage_budget[0] - stage_budget[1];
+                uint32_t* const lists[3] = {nullptr, wl[ph & 1], (uint32_t*)(w + g_spin_wl_c_offset(ncell))};
+                uint32_t* const counts[3] = {cnt + (ph - 1), cnt + ph, cnt + ph + 1};
+                HIP_TRY(hipMemsetAsync(cnt + ph, 0, 2 * sizeof(uint32_t), s), nullptr, 0);
                 a.pending = nullptr;
-                HIP_TRY(hipMemsetAsync(cnt + ph, 0, sizeof(uint32_t), s), nullptr, 0);
-                HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
-                a.queue_slots = 0;
-                a.budget = budget[ph] - 1 - kTailPacked;
                 a.spread = 1;
-                a.wl_slots = wl[ph & 1];
-                a.n_in = cnt + ph;
-                a.no_queue = 1; // (the budget covers the 1000-pass cap: nothing is left to queue)
-                HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+                int prev = 0; // the stage whose output the next one reads
+                for (int st = 0; st < 3; st++) {
+                    if (stage_budget[st] <= 0) continue;
+                    const bool last = st == 2;
+                    a.budget = stage_budget[st];
+                    a.wl_slots = lists[prev];
+                    a.n_in = counts[prev];
+                    a.queue_slots = last ? 0 : 1;
+                    a.no_queue = last ? 1 : 0; // (the budgets cover the 1000-pass cap: nothing is left after the last stage)
+                    a.wl_out = last ? wl[ph & 1] : lists[st + 1];
+                    a.n_out = last ? cnt + ph : counts[st + 1];
+                    HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+                    prev = st + 1;
+                }
                 a.spread = 0;
                 a.wl_slots = nullptr;
-                a.n_in = cnt + (ph - 1);
+                a.queue_slots = 0;
                 a.no_queue = 0;
+                a.n_in = cnt + (ph - 1);
+                a.wl_out = wl[ph & 1];
+                a.n_out = cnt + ph;
             } else {
                 HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
             }

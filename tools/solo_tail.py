@@ -85,7 +85,7 @@ if os.environ.get("SOLO_WHERE"):
     dbg = torch.full((8, n), -1.0, dtype=torch.float32, device=dev)
     lib.splash_dbg_set_diff.argtypes = [C.c_void_p]
     assert lib.splash_dbg_set_diff(dbg.data_ptr()) == 0
-    os.environ["SPLASH_HIP_TAIL_PACKED"] = "1"
+    os.environ["SPLASH_HIP_TAIL_STAGES"] = "1,0"
     for m in (16, 64):
         cells = [int(c) for c in long_cells[:m]]
         tail_with(cells, f"{m} jobs")
@@ -122,7 +122,7 @@ if os.environ.get("SOLO_SAME"):
     dbg = torch.full((8, n), -1.0, dtype=torch.float32, device=dev)
     lib.splash_dbg_set_diff.argtypes = [C.c_void_p]
     assert lib.splash_dbg_set_diff(dbg.data_ptr()) == 0
-    os.environ["SPLASH_HIP_TAIL_PACKED"] = "1"
+    os.environ["SPLASH_HIP_TAIL_STAGES"] = "1,0"
     for which in (0, 12):
         cells = [int(long_cells[which])] * 64
         par, state = begin()
@@ -142,7 +142,7 @@ if os.environ.get("SOLO_SAME"):
             print(f"   workgroup {g:2d}: ends {d[4, 4 * g:4 * g + 4].round(0).tolist()} ms; xcc {hw >> 16} se {(hw >> 13) & 7} cu {(hw >> 8) & 15}")
     sys.exit(0)
 if os.environ.get("SOLO_REPEAT"):
-    os.environ["SPLASH_HIP_TAIL_PACKED"] = "1"
+    os.environ["SPLASH_HIP_TAIL_STAGES"] = "1,0"
     for rep in range(10):
         tail_with([int(long_cells[0])], f"run {rep}: the same ONE job")
     for rep in range(4):
@@ -151,7 +151,7 @@ if os.environ.get("SOLO_REPEAT"):
 if os.environ.get("SOLO_PAD"):
     # long jobs at every 4th list position, short ones (done within 3 iterations) between: one long-running wavefront
     # per workgroup -- against the same long jobs side by side (four to a workgroup, on the four SIMDs of one CU)
-    os.environ["SPLASH_HIP_TAIL_PACKED"] = "1"
+    os.environ["SPLASH_HIP_TAIL_STAGES"] = "1,0"
     short = [int(c) for c in np.nonzero((it >= 1) & (it <= 3))[0]]
     for m in (4, 16, 64):
         padded = []
@@ -161,7 +161,7 @@ if os.environ.get("SOLO_PAD"):
         tail_with([int(c) for c in long_cells[:m]], f"{m} long jobs side by side")
     sys.exit(0)
 if os.environ.get("SOLO_SWEEP"):
-    os.environ["SPLASH_HIP_TAIL_PACKED"] = "1"
+    os.environ["SPLASH_HIP_TAIL_STAGES"] = "1,0"
     for m in (1, 4, 16, 64, 128, 236, 700):
         cells = list(long_cells[:m]) if m <= len(long_cells) else list(long_cells) + [int(c) for c in np.nonzero((it > 0) & (it < 900))[0][:m - len(long_cells)]]
         tail_with(cells, f"{len(cells)} jobs, one packed pass then spread")

@@ -1,5 +1,5 @@
-"""Same-process A/B of the spin-up's tail: one packed stage (round 3, SPLASH_HIP_NO_SOLO_TAIL=1) against packed + spread
-(round 4).  Prints the list lengths and the time of splash_dev_spin_up_finish, and checks the states' bits.
+"""Same-process A/B of the spin-up's tail: one packed stage (round 3, SPLASH_HIP_NO_SOLO_TAIL=1) against the cascade of
+spread stages (round 4; STAGE_SWEEP="32,64;16,48;..." tries other budgets).  Prints the list lengths and the time of splash_dev_spin_up_finish, and checks the states' bits.
     python tools/tail_ab.py [rows=1024] [row0=1536]"""
 import os
 import sys
@@ -32,16 +32,16 @@ o_cnt = al(n * 4) * 3 + al(n * 8)
 work = torch.zeros(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
 cnt = work[o_cnt:o_cnt + 64].view(torch.int32)
 ref = None
-modes = ["packed only", "packed + spread"] + [f"packed {p} + spread" for p in os.environ.get("PACKED_SWEEP", "").split(",") if p]
+modes = ["packed only", "cascade (default)"] + [f"stages {p}" for p in os.environ.get("STAGE_SWEEP", "").split(";") if p]
 for rep in range(2):
     for mode in modes:
-        os.environ.pop("SPLASH_HIP_TAIL_PACKED", None)
+        os.environ.pop("SPLASH_HIP_TAIL_STAGES", None)
         if mode == "packed only":
             os.environ["SPLASH_HIP_NO_SOLO_TAIL"] = "1"
         else:
             os.environ.pop("SPLASH_HIP_NO_SOLO_TAIL", None)
-            if mode.split()[1].isdigit():
-                os.environ["SPLASH_HIP_TAIL_PACKED"] = mode.split()[1]
+            if mode.startswith("stages "):
+                os.environ["SPLASH_HIP_TAIL_STAGES"] = mode.split()[1]
         par, state = par0.clone(), torch.empty(api.NSTATE, n, **f64)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
