@@ -498,6 +498,7 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
     double* const cache_all = (double*)(w + o_cache);
     a.cache_cap = spin_cache_cap(ncell);
     a.ntotal = ncell;
+    if (const char* e = getenv("SPLASH_DBG_ACTIVE_LANES")) a.dbg_active_lanes = atoi(e); // (read by measurement builds only)
     a.no_nd_skip = getenv("SPLASH_HIP_NO_ND_SKIP") ? 1 : 0; // tests: the detector of round 3 (same final bits, more passes)
     bool phase1_done_per_block = false;
     for (int ph = ph0; ph < ph1; ph++) {

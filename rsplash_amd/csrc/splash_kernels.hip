@@ -400,6 +400,9 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     }
     lds_tables_init();
     if (READBACK && a.spread && !valid) return; // (a wavefront past the list; after the tables' barrier)
+#if defined(SPL_TAIL_STATS) && defined(SPL_DIFF_STATS)
+    if (READBACK && a.spread && a.dbg_active_lanes > 0 && (int)(threadIdx.x & 63) >= a.dbg_active_lanes) return; // measurement: how many lanes must stay?
+#endif
     // The tail is the critical path of a call and a handful of wavefronts; whatever shares a SIMD with them (the
     // transient run of the finished cells, launched beside it) is throughput work: the tail's wavefronts issue first.
     if (READBACK && RICH) __builtin_amdgcn_s_setprio(3);

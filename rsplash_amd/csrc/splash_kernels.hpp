@@ -84,6 +84,7 @@ struct SpinPhaseArgs {
                             //    64 to a wavefront -- the tail's last stage (see k_spin_phase)
     const uint32_t* wl_slots; // optional: the launch's list holds POSITIONS of wl_in (and cache slots), not cells
     int queue_slots;        // 1: unfinished jobs are queued by their position (for a wl_slots launch), not by cell
+    int dbg_active_lanes;   // measurement builds only (tools/solo_tail.py): lanes of a spread wavefront that stay active
     int no_nd_skip;         // test aid (SPLASH_HIP_NO_ND_SKIP): the cycle detector compares the snow age too, always
     int rich;               // 1: the cache holds rich records, 20 words each, record by record (cache_cap = spin_cache_rich_cap of the
                             //    workspace's capacity), see splash_kernels.hip "Two layouts"

@@ -123,7 +123,11 @@ if os.environ.get("SOLO_SAME"):
     lib.splash_dbg_set_diff.argtypes = [C.c_void_p]
     assert lib.splash_dbg_set_diff(dbg.data_ptr()) == 0
     os.environ["SPLASH_HIP_TAIL_STAGES"] = "1,0"
-    for which in (0, 12):
+    lanes_list = [int(x) for x in os.environ.get("ACTIVE_LANES", "0").split(",")]
+    for which in ([0] * len(lanes_list) if len(lanes_list) > 1 else (0, 12)):
+        if len(lanes_list) > 1:   # measurement build: only that many lanes of a spread wavefront stay active
+            os.environ["SPLASH_DBG_ACTIVE_LANES"] = str(lanes_list.pop(0))
+            print("active lanes per wavefront:", os.environ["SPLASH_DBG_ACTIVE_LANES"])
         cells = [int(long_cells[which])] * 64
         par, state = begin()
         lst = torch.tensor(np.asarray(cells, dtype=np.int32), device=dev)
