@@ -256,10 +256,10 @@ constexpr int kNRecCompact = kNTermWords + 2;
 constexpr int kNRecRich = kNRecCompact + 4; // (words that carry data; kRichStride in memory)
 static_assert(kNRecRich <= 20, "rich record");
 constexpr int kRichStride = 20; // words per rich record in memory (16-byte aligned pairs)
-// Round 4: rich records are laid out JOB by job, [slot][day][20]: a job's year is 58 KB of consecutive memory.
-// Day by day ([day][slot][20], round 3) the next day's record lay cap x 160 B = 63 MB further on -- a new page
-// every day -- and a job alone on its wavefront (the tail's last stage, 1.7 us per day step) waited for it on
-// most CUs: the same job took 600 to 1 590 ms depending on where it ran (tools/solo_tail.py, SOLO_SAME).
+// Round 4: rich records are laid out JOB by job, [slot][day][20]: a job's year is 58 KB of consecutive memory (a
+// page or two), where day by day ([day][slot][20], round 3) the next day's record lay cap x 160 B = 63 MB further
+// on, a new page every day.  (It made no measurable difference to the tail -- a day step leaves a load 1.6 us --
+// but it is the layout a job alone on its wavefront wants, and the one a prefetcher can follow.)
 constexpr size_t kRichDays = 365;
 struct DayRecord {
     DayTerms T;
@@ -367,13 +367,12 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     const unsigned long long t_wave_start = wall_clock64();
 #endif
     const size_t nin = a.n_in ? (size_t)*a.n_in : a.ncell;
-    // Launch position -> job.  Packed (default): 64 jobs to a wavefront.  Spread (the tail's last stage,
-    // READBACK only): the jobs are dealt over 1024 wavefronts -- one per SIMD of the chip --, k = ceil(n / 1024)
-    // to each, and the other lanes of a wavefront leave at once.  A wavefront executes the union of the
-    // branches of its lanes: a job that has the wavefront to itself skips the rare branches (ponding, deep
-    // column, second transmittance, drainage time, snow) on the days IT does not take them and runs a pass
-    // of the year in half the time of a job packed with 63 others (measured: 530 against 1 035 ms for the
-    // 971 passes of the longest chains, tools/solo_tail.py, profiles/r04_spinup.md).
+    // Launch position -> job.  Packed (default): 64 jobs to a wavefront.  Spread (the tail's stages, READBACK
+    // only): the jobs are dealt over 1024 wavefronts -- one per SIMD of the chip --, k = ceil(n / 1024) to each.
+    // A wavefront executes the union of the branches of its lanes: a job that has the wavefront to itself skips
+    // the rare branches (ponding, deep column, second transmittance, drainage time, snow) on the days IT does not
+    // take them and runs a pass of the year in half the time of a job packed with 63 others (measured: 530
+    // against 1 035 ms for the 971 passes of the longest chains, tools/solo_tail.py, profiles/r04_spinup.md).
     size_t slot;
     bool valid, writer = true;
     if (READBACK && a.spread) {
@@ -384,8 +383,8 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         // The other lanes of the wavefront REPEAT its k jobs (lane % k) -- same data, same branches, nothing
         // added to what the wavefront executes -- instead of leaving: a wavefront with one active lane ran the
         // same job in 600 ms on some CUs and in up to 1 590 ms on others, with all 64 lanes active in 576-580 ms
-        // on every CU (tools/solo_tail.py SOLO_SAME; no micro-benchmark of ours reproduces it: tools/ubench/cu_variance*).
-        // Only the first k lanes store anything (`writer`).
+        // on every CU; the threshold is 16 active lanes (tools/solo_tail.py SOLO_SAME / ACTIVE_LANES; no
+        // micro-benchmark of ours reproduces it: tools/ubench/cu_variance*).  Only the first k lanes store (`writer`).
         slot = wave * k + ((threadIdx.x & 63) % k);
         if (slot >= nin) slot = wave * k;
         valid = slot < nin;
@@ -522,9 +521,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             RawRecord<RICH> w = rec_load<RICH>(a.cache, a.cache_cap, 1, cs);
             for (int i = 1; i < a.n; i++) {
                 const DayRecord r = rec_decode<RICH>(c, w, RICH ? 0.0 : days[i].cd);
-#ifndef SPL_NOLOAD // (experiment: every day uses the first record -- wrong results, the loop's timing without its loads)
                 if (i + 1 < a.n) w = rec_load<RICH>(a.cache, a.cache_cap, i + 1, cs); // tomorrow's, untouched until tomorrow
-#endif
                 day_update(c, r.T, r.V, r.rain, r.snf, cur, o);
             }
         } else if constexpr (!READBACK) {
