@@ -526,6 +526,8 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
             // terms again (1 900).  The block's survivors are the entries phase 0 has just appended to its list,
             // from a position only the device knows (snapshot of the counter -> first_dev); a job's cache slot is
             // its cell's position in the block.  Same bits (the records are what the general kernel would form).
+            // (measured, 16.7 M cells: 1 150 -> 1 131 ms for phases 0-6 -- less than the instruction counts promise:
+            // the survivors' records are read at 65 % density and the pass is bound by those reads.)
             static const bool no_p1 = getenv("SPLASH_HIP_NO_BLOCK_PHASE1") != nullptr; // A/B: the round-3 order
             const bool block_p1 = split && !no_p1 && ph1 > 1 && (ncell + a.cache_cap - 1) / a.cache_cap <= kSpinSnapshots;
             uint32_t* const snap = cnt + 16;
