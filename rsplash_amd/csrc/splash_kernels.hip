@@ -5,7 +5,9 @@
 // contiguous bytes per series per day; the per-day table is read through scalar loads (uniform
 // index).  Lanes past ncell stay alive (clamped index, masked stores) so wave-level votes and
 // reductions always see full waves.
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 
 #include "splash_kernels.hpp"
 
@@ -522,7 +524,17 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             for (int i = 1; i < a.n; i++) {
                 const DayRecord r = rec_decode<RICH>(c, w, RICH ? 0.0 : days[i].cd);
                 if (i + 1 < a.n) w = rec_load<RICH>(a.cache, a.cache_cap, i + 1, cs); // tomorrow's, untouched until tomorrow
+#ifdef SPL_TOUCH_AHEAD // (measurement builds: the record SPL_TOUCH_AHEAD days on is pulled towards the CU as well)
+                unsigned t2a = 0, t2b = 0;
+                if (RICH && i + SPL_TOUCH_AHEAD < a.n) {
+                    const double* q = a.cache + (cs * kRichDays + (size_t)(i + SPL_TOUCH_AHEAD)) * kRichStride;
+                    asm volatile("global_load_dword %0, %2, off\n global_load_dword %1, %2, off offset:128" : "=&v"(t2a), "=&v"(t2b) : "v"(q) : "memory");
+                }
+#endif
                 day_update(c, r.T, r.V, r.rain, r.snf, cur, o);
+#ifdef SPL_TOUCH_AHEAD
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(t2a), "+v"(t2b) : : "memory");
+#endif
             }
         } else if constexpr (!READBACK) {
             // order of the day's vector-memory traffic as in k_run_all: gathers at the top; once
@@ -635,6 +647,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
 #ifdef SPL_DIFF_STATS
                 if (READBACK && g_diff_dbg) { // when (ms since the wavefront started) and where the job ended
                     g_diff_dbg[(size_t)6 * a.ntotal + ci] = (float)((double)(wall_clock64() - t_wave_start) * 1e-5);
+                    g_diff_dbg[(size_t)3 * a.ntotal + ci] = (float)((double)(t_wave_start & 0xFFFFFFFull) * 1e-5); // start, ms mod 2 684
                     unsigned hwid;
                     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
                     unsigned xcc;
@@ -1806,9 +1819,35 @@ hipError_t launch_spin_phase(const SpinPhaseArgs& a, hipStream_t s)
     if (a.spread && !a.readback) return hipErrorInvalidValue;
     // spread: 1024 wavefronts (256 workgroups) take ceil(n/1024) jobs each; more only for lists beyond 65 536 jobs
     const unsigned g_rb = a.spread ? std::max(nblk(a.ncell, kBlock), 256u) : nblk(a.ncell, kBlock);
-    if (a.readback && a.rich)
-        hipLaunchKernelGGL((k_spin_phase<true, true, true>), dim3(g_rb), dim3(kBlock), 0, s, a);
-    else if (a.readback)
+    if (a.readback && a.rich) {
+        // Spread launches ask for more than half of a CU's LDS (160 KB), so that no two of their workgroups can be
+        // resident on one CU: beside other work (the transient run of the finished cells, whose workgroups come
+        // and go every few ms) the dispatcher otherwise puts a few of them on CUs that already hold one, two of
+        // the tail's wavefronts then share a SIMD, and each runs its passes 1.6x slower -- the whole tail waits
+        // for them (0.68 -> 0.85-0.9 s, run by run; tools/overlap_where.py).  The pad is never touched; a
+        // workgroup of k_run_all (26 KB) still fits beside one of these.  (The grid is sized for the longest
+        // possible list; the workgroups past the 256 that hold jobs return at once.  Lists beyond 65 536 jobs --
+        // more than 256 busy workgroups -- run one per CU instead of two.)
+        unsigned pad = 0;
+        if (a.spread) {
+            // (the attribute belongs to the function ON A DEVICE: asked for once per device of the process)
+            static std::atomic<int> granted[64]; // 0: not asked yet, > 0: bytes, -1: refused or switched off
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+            int g = dev < 0 ? -1 : granted[dev].load(std::memory_order_acquire);
+            if (g == 0) {
+                const char* e = getenv("SPLASH_HIP_TAIL_LDS_PAD"); // (A/B: 0 switches it off)
+                const int want = e ? atoi(e) : 57344;              // static 25.9 KB + 56 KB > 80 KB
+                g = want > 0 && hipFuncSetAttribute((const void*)k_spin_phase<true, true, true>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess
+                        ? want : -1;
+                (void)hipGetLastError();
+                granted[dev].store(g, std::memory_order_release);
+            }
+            pad = g > 0 ? (unsigned)g : 0u;
+        }
+        hipLaunchKernelGGL((k_spin_phase<true, true, true>), dim3(g_rb), dim3(kBlock), pad, s, a);
+    } else if (a.readback)
         hipLaunchKernelGGL((k_spin_phase<true, true, false>), dim3(g_rb), dim3(kBlock), 0, s, a);
     else if (a.cache && a.rich)
         hipLaunchKernelGGL((k_spin_phase<true, false, true>), dim3(nblk(a.ncell, kBlock)), dim3(kBlock), 0, s, a);
