@@ -1827,7 +1827,8 @@ hipError_t launch_spin_phase(const SpinPhaseArgs& a, hipStream_t s)
         // for them (0.68 -> 0.85-0.9 s, run by run; tools/overlap_where.py).  The pad is never touched; a
         // workgroup of k_run_all (26 KB) still fits beside one of these.  (The grid is sized for the longest
         // possible list; the workgroups past the 256 that hold jobs return at once.  Lists beyond 65 536 jobs --
-        // more than 256 busy workgroups -- run one per CU instead of two.)
+        // more than 256 busy workgroups -- run one per CU instead of two, and the tails of two calls in flight on
+        // one device take their CUs in turn instead of sharing them at 1.6x the time each.)
         unsigned pad = 0;
         if (a.spread) {
             // (the attribute belongs to the function ON A DEVICE: asked for once per device of the process)
