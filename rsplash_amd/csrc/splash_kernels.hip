@@ -524,17 +524,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             for (int i = 1; i < a.n; i++) {
                 const DayRecord r = rec_decode<RICH>(c, w, RICH ? 0.0 : days[i].cd);
                 if (i + 1 < a.n) w = rec_load<RICH>(a.cache, a.cache_cap, i + 1, cs); // tomorrow's, untouched until tomorrow
-#ifdef SPL_TOUCH_AHEAD // (measurement builds: the record SPL_TOUCH_AHEAD days on is pulled towards the CU as well)
-                unsigned t2a = 0, t2b = 0;
-                if (RICH && i + SPL_TOUCH_AHEAD < a.n) {
-                    const double* q = a.cache + (cs * kRichDays + (size_t)(i + SPL_TOUCH_AHEAD)) * kRichStride;
-                    asm volatile("global_load_dword %0, %2, off\n global_load_dword %1, %2, off offset:128" : "=&v"(t2a), "=&v"(t2b) : "v"(q) : "memory");
-                }
-#endif
                 day_update(c, r.T, r.V, r.rain, r.snf, cur, o);
-#ifdef SPL_TOUCH_AHEAD
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(t2a), "+v"(t2b) : : "memory");
-#endif
             }
         } else if constexpr (!READBACK) {
             // order of the day's vector-memory traffic as in k_run_all: gathers at the top; once
