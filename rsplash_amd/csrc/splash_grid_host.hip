@@ -777,7 +777,15 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
     const bool f32 = W.f32;
     const double t_w0 = now_s();
     const size_t want = v1 - v0;
-    int n_lanes = 2;
+    // Lanes: two keep the link and the GPU busy when the results are the bulk of the traffic (daily outputs in
+    // double precision: device->host is the bottleneck and a third lane only adds blocks); a call whose results are
+    // light -- monthly outputs, or daily ones in single precision -- is bound by its kernels, and a third lane
+    // fills the gaps between them (*measured*, whole grid monthly 2.56 -> 2.47 s, 2048x4096 x 5 daily f32 results
+    // 1.86 -> 1.73 s; daily f64 results 2.52 -> 2.62 s, hence the rule).  SPLASH_HIP_LANES overrides.
+    size_t out_bytes_cell = 0;
+    for (int k = 0; k < SPLASH_NOUT; k++) out_bytes_cell += P.dst[k] ? (size_t)nt_out * (size_t)P.esz[k] : 0;
+    const size_t in_bytes_cell = (size_t)nt * 3 * (f32 ? 4 : 8);
+    int n_lanes = out_bytes_cell <= 2 * in_bytes_cell ? 3 : 2;
     if (const char* e = getenv("SPLASH_HIP_LANES")) n_lanes = std::max(1, std::min(4, atoi(e)));
     const size_t acc_bytes = splash_dev_diag_acc_size(P.n_basin, P.nmonth);
     {
