@@ -15,7 +15,7 @@ def build_library(force=False, verbose=False):
     if os.environ.get("SPLASH_HIP_LIBRARY"):
         return library_path()
     csrc = os.path.join(_HERE, "csrc")
-    cmd = ["make", "-C", csrc]
+    cmd = ["make", "-j4", "-C", csrc]
     if force:
         cmd.append("-B")
     subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)

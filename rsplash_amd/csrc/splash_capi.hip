@@ -55,6 +55,85 @@ extern "C" int splash_hip_device_count(void)
 
 extern "C" const char* splash_hip_last_error(void) { return g_err.c_str(); }
 
+// ------------------------------------------------------------------ environment knobs
+namespace {
+std::mutex g_knobs_mu;
+splash::host::Knobs g_knobs;
+bool g_knobs_read = false;
+
+size_t env_size(const char* name, size_t dflt)
+{
+    const char* e = getenv(name);
+    if (!e || !*e) return dflt;
+    char* end = nullptr;
+    const unsigned long long v = strtoull(e, &end, 10);
+    return end == e ? dflt : (size_t)v;
+}
+
+void knobs_read_locked()
+{
+    splash::host::Knobs k;
+    k.no_pool = getenv("SPLASH_HIP_NO_POOL") != nullptr;
+    if (g_knobs_read) {
+        k.spin_cache_cap = g_knobs.spin_cache_cap; // frozen
+    } else if (const char* e = getenv("SPLASH_HIP_SPIN_CACHE_CAP")) {
+        k.spin_cache_cap = atol(e);
+    }
+    if (const char* e = getenv("SPLASH_DBG_ACTIVE_LANES")) k.dbg_active_lanes = atoi(e);
+    k.no_nd_skip = getenv("SPLASH_HIP_NO_ND_SKIP") != nullptr;
+    k.no_block_phase1 = getenv("SPLASH_HIP_NO_BLOCK_PHASE1") != nullptr;
+    k.no_solo_tail = getenv("SPLASH_HIP_NO_SOLO_TAIL") != nullptr;
+    if (const char* e = getenv("SPLASH_HIP_TAIL_STAGES")) {
+        int b0 = 0, b1 = 0;
+        if (sscanf(e, "%d,%d", &b0, &b1) == 2) {
+            k.tail_stage[0] = std::max(0, std::min(400, b0));
+            k.tail_stage[1] = std::max(0, std::min(400, b1));
+        }
+    }
+    if (const char* e = getenv("SPLASH_HIP_TAIL_LDS_PAD")) k.tail_lds_pad = atoi(e);
+    if (const char* e = getenv("SPLASH_HIP_PREFAULT")) {
+        if (!strcmp(e, "touch")) k.prefault_mode = splash::host::PREFAULT_TOUCH;
+        else if (!strcmp(e, "off") || !strcmp(e, "0")) k.prefault_mode = splash::host::PREFAULT_OFF;
+    }
+    k.prefault_min_bytes = env_size("SPLASH_HIP_PREFAULT_MIN_BYTES", k.prefault_min_bytes);
+    k.prefault_delay_ms = env_size("SPLASH_HIP_PREFAULT_DELAY_MS", 0);
+    k.test_prefault_whole_range = getenv("SPLASH_HIP_TEST_PREFAULT_WHOLE_RANGE") != nullptr;
+    k.trace = getenv("SPLASH_TRACE") != nullptr;
+    if (const char* e = getenv("SPLASH_HIP_LANES")) k.lanes = std::max(1, std::min(4, atoi(e)));
+    if (const char* e = getenv("SPLASH_HIP_FAKE_DEVICE_BYTES")) {
+        k.fake_device = true;
+        k.fake_device_bytes = (size_t)atoll(e);
+    }
+    if (const char* e = getenv("SPLASH_HIP_POOL_CAP")) k.pool_cap = std::max<size_t>(1, (size_t)atol(e));
+    k.blocks_per_lane = std::max<size_t>(1, env_size("SPLASH_HIP_BLOCKS_PER_LANE", 4));
+    k.min_block_cells = std::max<size_t>(1, env_size("SPLASH_HIP_MIN_BLOCK_CELLS", (size_t)1 << 20));
+    k.no_register = getenv("SPLASH_HIP_NO_REGISTER") != nullptr;
+    k.register_min_bytes = env_size("SPLASH_HIP_REGISTER_MIN_BYTES", (size_t)8 << 30);
+    g_knobs = k;
+    g_knobs_read = true;
+}
+} // namespace
+
+void splash::host::knobs_refresh()
+{
+    std::lock_guard<std::mutex> lk(g_knobs_mu);
+    knobs_read_locked();
+}
+
+splash::host::Knobs splash::host::knobs()
+{
+    std::lock_guard<std::mutex> lk(g_knobs_mu);
+    if (!g_knobs_read) knobs_read_locked(); // (a library-internal thread never gets here first: every
+                                            //  entry point that starts one has refreshed)
+    return g_knobs;
+}
+
+int splash::host::enter_device(char* err, size_t errlen)
+{
+    knobs_refresh();
+    return need_device(err, errlen);
+}
+
 int splash::host::need_device(char* err, size_t errlen)
 {
     if (splash_hip_device_count() <= 0)
@@ -129,7 +208,7 @@ hipError_t pool_alloc(void** out, size_t bytes)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || getenv("SPLASH_HIP_NO_POOL")) return hipMalloc(out, bytes);
+    if (dev < 0 || dev >= 64 || knobs().no_pool) return hipMalloc(out, bytes);
     std::lock_guard<std::recursive_mutex> lk(g_dev_mu[dev]);
     DevCtx& c = g_ctx[dev];
     PoolSlot* best = nullptr;
@@ -293,7 +372,7 @@ extern "C" int splash_calendar_create(int nt, const int* doy, const int* year, c
 {
     if (!out || nt <= 0 || !doy || !year || !month)
         return fail(SPLASH_EINVAL, err, errlen, "calendar: nt must be > 0 and doy/year/month given");
-    if (int rc = need_device(err, errlen)) return rc;
+    if (int rc = enter_device(err, errlen)) return rc;
     auto* cal = new splash_calendar;
     cal->nt = nt;
     cal->host.resize(nt);
@@ -377,7 +456,7 @@ extern "C" int splash_dev_soil_hydro(size_t ncell, const double* lat, const doub
                                      double* cellpar, void* stream)
 {
     REQ(lat && elev && slop && asp && resolution && soil && cellpar, "soil_hydro: NULL argument");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_soil_hydro(ncell, lat, elev, slop, asp, resolution, soil, au, cellpar,
                               (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
@@ -388,23 +467,27 @@ extern "C" int splash_dev_snow_threshold(size_t ncell, int nt, const double* tc,
 {
     REQ(tc && cellpar && Tt && nt > 0, "snow_threshold: NULL argument or nt <= 0");
     REQ(ldf >= ncell && ldp >= ncell, "snow_threshold: leading dimension smaller than ncell");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_snow_threshold(ncell, nt, tc, ldf, cellpar, ldp, Tt, (hipStream_t)stream),
             nullptr, 0);
     return SPLASH_OK;
 }
 
-// workspace of splash_dev_spin_up: two worklists, job records, aridity index, phase counters, and
-// the cache of state-independent day terms: 365 x 19 doubles per slot, 2^19 slots at most (29 GB).
-// Phase 0 walks the cells in blocks of that many; the later phases' worklists are far shorter.
+// workspace of splash_dev_spin_up: three worklists, job records, aridity index, phase counters, and
+// the cache of state-independent day terms: 365 x kNRecCompact (15) doubles = 43 800 B per slot, 2^19
+// slots at most (23 GB).  Phase 0 walks the cells in blocks of that many with compact records; the
+// later phases lay RICH records (20 words, job by job) over the same bytes: spin_cache_rich_cap() =
+// 15/20 of the compact capacity rounded down to whole wavefronts (393 216 slots at 2^19), with no
+// slack behind the last slot -- which is why k_spin_phase never forms an address from a slot beyond
+// the capacity (cs_ld) and why a spread launch deals only the positions below it.
 constexpr size_t kSpinSnapshots = 1024;
 static size_t spin_cache_cap(size_t ncell)
 {
     size_t lim = (size_t)1 << 19;
     // test / tuning aid: a small capacity makes small grids walk phase 0 in several blocks and gives
-    // the later phases jobs beyond the cache (read once: the workspace layout depends on it)
-    static const char* env = getenv("SPLASH_HIP_SPIN_CACHE_CAP");
-    if (env && atol(env) >= 64) lim = (size_t)atol(env);
+    // the later phases jobs beyond the cache (read once per process: the workspace layout depends on it)
+    const long env = knobs().spin_cache_cap;
+    if (env >= 64) lim = (size_t)env;
     size_t cap = std::min<size_t>(ncell, lim);
     return (cap + 63) & ~(size_t)63;
 }
@@ -498,8 +581,10 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
     double* const cache_all = (double*)(w + o_cache);
     a.cache_cap = spin_cache_cap(ncell);
     a.ntotal = ncell;
-    if (const char* e = getenv("SPLASH_DBG_ACTIVE_LANES")) a.dbg_active_lanes = atoi(e); // (read by measurement builds only)
-    a.no_nd_skip = getenv("SPLASH_HIP_NO_ND_SKIP") ? 1 : 0; // tests: the detector of round 3 (same final bits, more passes)
+    const Knobs kn = knobs(); // (the snapshot of the call's entry: no getenv on lane or pool threads)
+    a.dbg_active_lanes = kn.dbg_active_lanes; // (read by measurement builds only)
+    a.lds_pad = kn.tail_lds_pad;
+    a.no_nd_skip = kn.no_nd_skip ? 1 : 0; // tests: the detector of round 3 (same final bits, more passes)
     bool phase1_done_per_block = false;
     for (int ph = ph0; ph < ph1; ph++) {
         if (ph == 1 && phase1_done_per_block) continue;
@@ -528,7 +613,7 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
             // its cell's position in the block.  Same bits (the records are what the general kernel would form).
             // (measured, 16.7 M cells: 1 150 -> 1 131 ms for phases 0-6 -- less than the instruction counts promise:
             // the survivors' records are read at 65 % density and the pass is bound by those reads.)
-            static const bool no_p1 = getenv("SPLASH_HIP_NO_BLOCK_PHASE1") != nullptr; // A/B: the round-3 order
+            const bool no_p1 = kn.no_block_phase1; // A/B: the round-3 order
             const bool block_p1 = split && !no_p1 && ph1 > 1 && (ncell + a.cache_cap - 1) / a.cache_cap <= kSpinSnapshots;
             uint32_t* const snap = cnt + 16;
             size_t blk = 0;
@@ -586,7 +671,7 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
             a.budget = budget[ph] - 1;
             a.readback = 1;
             a.ncell = std::min(n_all, a.cache_cap);
-            const bool no_solo = getenv("SPLASH_HIP_NO_SOLO_TAIL") != nullptr; // A/B and tests: the round-3 tail (read per call)
+            const bool no_solo = kn.no_solo_tail; // A/B and tests: the round-3 tail
             if (ph == kSpinPhases - 1 && !no_solo) {
                 // The tail as a cascade of read-back launches over shrinking lists, every one of them SPREAD: the
                 // jobs dealt over 1 024 wavefronts, ceil(n / 1024) to each, the other lanes repeating them
@@ -597,12 +682,9 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
                 // survivors by their position in the tail's list, which stays their cache slot (wl_slots).
                 // SPLASH_HIP_TAIL_STAGES="a,b" sets the first two budgets (experiments).
                 int stage_budget[3] = {32, 64, 0};
-                if (const char* e = getenv("SPLASH_HIP_TAIL_STAGES")) {
-                    int b0 = 0, b1 = 0;
-                    if (sscanf(e, "%d,%d", &b0, &b1) == 2) {
-                        stage_budget[0] = std::max(0, std::min(400, b0));
-                        stage_budget[1] = std::max(0, std::min(400, b1));
-                    }
+                if (kn.tail_stage[0] >= 0) {
+                    stage_budget[0] = kn.tail_stage[0];
+                    stage_budget[1] = kn.tail_stage[1];
                 }
                 stage_budget[2] = budget[ph] - 1 - stage_budget[0] - stage_budget[1];
                 uint32_t* const lists[3] = {nullptr, wl[ph & 1], (uint32_t*)(w + g_spin_wl_c_offset(ncell))};
@@ -715,7 +797,7 @@ extern "C" int splash_dev_diag_finalize(const int64_t* diag_acc, int n_basin, in
                                         double* diag, double* counts, void* stream)
 {
     REQ(diag_acc && diag && nmonth >= 0, "diag_finalize: NULL argument");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_diag_finalize((const long long*)diag_acc, std::max(n_basin, 1) * nmonth, diag,
                                  counts, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
@@ -755,7 +837,7 @@ extern "C" int splash_dev_run_all(const splash_calendar* cal, int t0, int nt, si
     REQ(!(out->monthly && (out->extra[0] || out->extra[1] || out->extra[2])),
         "run_all: the qin_prev/tdrain/snwage series are daily (monthly = 0)");
     REQ(ncell <= kMaxCellsPerLaunch, "run_all: more than 2^29-1 cells in one call (32-bit lane byte offsets)");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     if (nt == 0 || ncell == 0) return SPLASH_OK;
     RunArgs a{};
     a.days = cal->dev + t0;
@@ -796,7 +878,7 @@ extern "C" int splash_dev_synth_statics(uint64_t seed, int H, int W, int64_t cel
 {
     REQ(lat && elev && slop && asp && resolution && soil && au && H > 0 && W > 0,
         "synth_statics: NULL argument");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_synth_statics(seed, H, W, cell0, ncell, terrain, lat, elev, slop, asp,
                                  resolution, soil, au, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
@@ -810,7 +892,7 @@ extern "C" int splash_dev_synth_forcing(uint64_t seed, const splash_calendar* ca
     REQ(cal && lat && elev && sw_in && tc && pn, "synth_forcing: NULL argument");
     REQ(t0 >= 0 && nt >= 0 && t0 + nt <= cal->nt, "synth_forcing: day range outside the calendar");
     REQ(ldf >= ncell, "synth_forcing: leading dimension < ncell");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_synth_forcing(seed, cal->dev + t0, t0, nt, cell0, ncell, lat, elev, sw_in, tc,
                                  pn, ldf, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
@@ -824,7 +906,7 @@ extern "C" int splash_dev_terrain(int H, int W, const double* elev, double ymax,
     REQ(elev && H > 0 && W > 0, "terrain: NULL elevation or empty grid");
     REQ(yres > 0 && xres > 0, "terrain: cell size must be positive (degrees)");
     REQ(slope_deg || aspect_deg || lat || resolution_m || flowdir, "terrain: no output requested");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_terrain(H, W, elev, ymax, yres, xres, na_to_zero, slope_deg, aspect_deg, lat,
                            resolution_m, flowdir, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
@@ -834,7 +916,7 @@ extern "C" int splash_dev_ncellflow(int H, int W, const double* flowdir, const d
                                     int pad, double* ncell, void* stream)
 {
     REQ(flowdir && codes9 && ncell && H > 0 && W > 0, "ncellflow: NULL argument or empty grid");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_ncellflow(H, W, flowdir, codes9, pad, ncell, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
 }
@@ -846,7 +928,7 @@ extern "C" int splash_dev_sinkfill(int H, int W, const double* elev, double reso
     REQ(elev && filled && H > 0 && W > 0, "sinkfill: NULL argument or empty grid");
     REQ(elev != filled, "sinkfill: the filled surface needs its own raster");
     REQ(resolution_m > 0 && degree >= 0 && degree < 90, "sinkfill: resolution must be positive, 0 <= degree < 90");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_sinkfill(H, W, elev, resolution_m, degree, filled, sweeps, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
 }
@@ -860,7 +942,7 @@ extern "C" int splash_dev_flow_accumulation(int H, int W, const double* flowdir,
     REQ(ups_ncell || ups_area, "flow_accumulation: no output requested");
     REQ(!ups_area || resolution_m, "flow_accumulation: the area needs the resolution raster");
     REQ((size_t)H * W < ((size_t)1 << 32), "flow_accumulation: more than 2^32-1 cells");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_flow_accumulation(H, W, flowdir, elev, tau_codes, resolution_m, ups_ncell, ups_area, levels,
                                      (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
@@ -872,7 +954,7 @@ extern "C" int splash_dev_mfd_area(int H, int W, const double* elev, double reso
     REQ(elev && area && H > 0 && W > 0, "mfd_area: NULL argument or empty grid");
     REQ(resolution_m > 0, "mfd_area: resolution must be positive");
     REQ((size_t)H * W < ((size_t)1 << 32), "mfd_area: more than 2^32-1 cells");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_mfd_area(H, W, elev, resolution_m, area, levels, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
 }
@@ -885,7 +967,7 @@ extern "C" int splash_dev_unswc(size_t ncell, int nt, const double* wn, size_t l
     REQ(wn && soil && (wn_z || wtd || theta), "unswc: NULL argument");
     REQ(ldw >= ncell && ldo >= ncell && nt >= 0, "unswc: leading dimension < ncell");
     REQ(uns_depth > 0, "unswc: uns_depth must be positive");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_unswc(ncell, nt, wn, ldw, soil, uns_depth, wn_z, wtd, theta, ldo,
                          (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
@@ -901,7 +983,7 @@ extern "C" int splash_dev_evap_batch(size_t m, const double* lat, const double* 
     (void)stream;
     REQ(lat && elv && sw && n && y && sw_in && tc && slop && asp && snow && nd && out,
         "evap_batch: NULL argument");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     if (m == 0) return SPLASH_OK;
     std::vector<double> orb(3 * m);
     for (size_t i = 0; i < m; i++) orbit_day(n[i], y[i], orb[i], orb[m + i], orb[2 * m + i]);
@@ -929,7 +1011,7 @@ extern "C" int splash_dev_evap_batch(size_t m, const double* lat, const double* 
 extern "C" int splash_dev_math_probe(size_t n, const double* x, const double* y, double* out)
 {
     REQ(x && y && out, "math_probe: NULL argument");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     if (n == 0) return SPLASH_OK;
     DevBuf dx, dy, dout;
     HIP_TRY(dx.alloc(n * 8), nullptr, 0);
@@ -950,7 +1032,7 @@ extern "C" int splash_dev_infiltration_probe(size_t n, const double* cellpar, co
 {
     REQ(cellpar && wn && ksat_visc && P && theta_surf && infiltration,
         "infiltration_probe: NULL argument");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     if (n == 0) return SPLASH_OK;
     DevBuf dp, dw, dk, dP, dt, di;
     const double* hin[3] = {wn, ksat_visc, P};
@@ -1016,7 +1098,7 @@ extern "C" int splash_unswc_run(size_t ncell, int nt, const double* wn, const do
                                 char* err, size_t errlen)
 {
     if (!wn || !soil) return fail(SPLASH_EINVAL, err, errlen, "unswc_run: NULL input");
-    if (int rc = need_device(err, errlen)) return rc;
+    if (int rc = enter_device(err, errlen)) return rc;
     if (ncell == 0 || nt <= 0) return SPLASH_OK;
     const size_t n = ncell * (size_t)nt;
     DevBuf dw, ds, dz, dt_, dh;
@@ -1045,7 +1127,7 @@ extern "C" int splash_static_rasters_run(int H, int W, const double* elev, doubl
 {
     if (!elev || !out || H <= 0 || W <= 0)
         return fail(SPLASH_EINVAL, err, errlen, "static_rasters_run: NULL argument or empty grid");
-    if (int rc = need_device(err, errlen)) return rc;
+    if (int rc = enter_device(err, errlen)) return rc;
     const size_t n = (size_t)H * W, nb = n * sizeof(double);
     const bool graph = out->filled || out->flowdir || out->ups_ncell || out->ups_area || out->ncellin ||
                        out->ncellout || out->ups_area_mfd;
@@ -1160,7 +1242,7 @@ extern "C" int splash_mod_spin_up(double lat, double elv, int n, int y, const do
                                   double* snwage, double* pet, int* passes)
 {
     REQ(n > 0 && sw_in && tair && pn && snowfall && soil_info, "mod_spin_up: bad argument");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     std::vector<DayRec> days(n);
     for (int i = 0; i < n; i++) {
         DayRec& d = days[i];
@@ -1225,7 +1307,7 @@ extern "C" int splash_mod_run_all(double lat, double elv, int nt, const int* doy
 {
     REQ(nt > 0 && doys && yrs && sw_in && tair && pn && snowfall && soil_info,
         "mod_run_all: bad argument");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     std::vector<DayRec> days(nt);
     for (int i = 0; i < nt; i++) {
         DayRec& d = days[i];
@@ -1304,7 +1386,7 @@ extern "C" int splash_mod_moist_surf(double depth, double z, double bub_p, doubl
                                      double RES, double lambda, double* theta)
 {
     REQ(theta, "mod_moist_surf: NULL result");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     DevBuf d;
     HIP_TRY(d.alloc(8), nullptr, 0);
     HIP_TRY(launch_moist_surf(depth, z, bub_p, wn, SAT, RES, lambda, d.as<double>(), nullptr),
@@ -1318,7 +1400,7 @@ extern "C" int splash_mod_inf_GA(double bub_press, double theta_i, double Ksat, 
                                  double* infiltration)
 {
     REQ(infiltration, "mod_inf_GA: NULL result");
-    if (int rc = need_device(nullptr, 0)) return rc;
+    if (int rc = enter_device(nullptr, 0)) return rc;
     DevBuf d;
     HIP_TRY(d.alloc(8), nullptr, 0);
     HIP_TRY(launch_inf_GA(bub_press, theta_i, Ksat, theta_s, lambda, P, tdur, slop, d.as<double>(),

@@ -24,16 +24,8 @@
 using namespace splash;
 using namespace splash::host;
 
-// ------------------------------------------------------------------ knobs
-// Environment variables read at every call (tests flip them inside one process).
-static size_t env_size(const char* name, size_t dflt)
-{
-    const char* e = getenv(name);
-    if (!e || !*e) return dflt;
-    char* end = nullptr;
-    const unsigned long long v = strtoull(e, &end, 10);
-    return end == e ? dflt : (size_t)v;
-}
+// (Environment knobs: splash::host::knobs(), sampled at every call's entry on the caller's thread --
+// tests flip them inside one process; no thread of this file calls getenv.)
 
 // Mapping the caller's (typically freshly allocated) result arrays before the device->host copies
 // reach them: columns [c0, c0+ncols) of every row of the [nrows][N] arrays of `esz`-byte elements, on a
@@ -48,15 +40,6 @@ static size_t env_size(const char* name, size_t dflt)
 //   off                 nothing.
 // SPLASH_HIP_PREFAULT selects the mode, SPLASH_HIP_PREFAULT_MIN_BYTES the block size (bytes of one
 // block's share of the arrays) from which it pays: 64 MiB.
-enum { PREFAULT_POPULATE = 0, PREFAULT_TOUCH = 1, PREFAULT_OFF = 2 };
-static int prefault_mode()
-{
-    const char* e = getenv("SPLASH_HIP_PREFAULT");
-    if (!e) return PREFAULT_POPULATE;
-    if (!strcmp(e, "touch")) return PREFAULT_TOUCH;
-    if (!strcmp(e, "off") || !strcmp(e, "0")) return PREFAULT_OFF;
-    return PREFAULT_POPULATE;
-}
 
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23
@@ -65,12 +48,13 @@ static int prefault_mode()
 static void prefault_outputs(void* const* bufs, const int* esz, int nbuf, size_t N, size_t c0, size_t ncols,
                              size_t nrows)
 {
-    const int mode = prefault_mode();
+    const Knobs kn = knobs();
+    const int mode = kn.prefault_mode;
     if (mode == PREFAULT_OFF || ncols == 0 || nrows == 0) return;
     size_t bytes = 0;
     for (int k = 0; k < nbuf; k++) bytes += bufs[k] ? ncols * nrows * (size_t)esz[k] : 0;
-    if (bytes < env_size("SPLASH_HIP_PREFAULT_MIN_BYTES", (size_t)64 << 20)) return; // small: not worth threads
-    if (const size_t ms = env_size("SPLASH_HIP_PREFAULT_DELAY_MS", 0)) // test aid: let the other lanes deliver first
+    if (bytes < kn.prefault_min_bytes) return; // small: not worth threads
+    if (const size_t ms = kn.prefault_delay_ms) // test aid: let the other lanes deliver first
         std::this_thread::sleep_for(std::chrono::milliseconds(ms));
     const size_t page = (size_t)sysconf(_SC_PAGESIZE);
     unsigned nthr = std::thread::hardware_concurrency();
@@ -265,7 +249,7 @@ struct Worker {
     Worker(const GridPlan& P_, int dev, size_t a, size_t b) : P(P_), device(dev), v0(a), v1(b), nb_max(0)
     {
         f32 = (P.in->sw_in == nullptr);
-        trace = getenv("SPLASH_TRACE") != nullptr;
+        trace = knobs().trace;
     }
     ~Worker() { splash_calendar_destroy(cal); }
 
@@ -495,7 +479,7 @@ int Worker::run_block(Lane& L, size_t k)
     // neighbouring block's results at this moment, and a page-touching write outside the block's own
     // columns would race with them (see prefault_outputs).
     if (P.dense) {
-        if (getenv("SPLASH_HIP_TEST_PREFAULT_WHOLE_RANGE")) // fault injection for the regression test ONLY: the
+        if (knobs().test_prefault_whole_range) // fault injection for the regression test ONLY: the
             prefault_outputs(P.dst, P.esz, SPLASH_NOUT, N, P.idx[v0], v1 - v0, (size_t)nt_out); // range of the first version
         else
             prefault_outputs(P.dst, P.esz, SPLASH_NOUT, N, c0, nb, (size_t)nt_out);
@@ -786,7 +770,8 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
     for (int k = 0; k < SPLASH_NOUT; k++) out_bytes_cell += P.dst[k] ? (size_t)nt_out * (size_t)P.esz[k] : 0;
     const size_t in_bytes_cell = (size_t)nt * 3 * (f32 ? 4 : 8);
     int n_lanes = out_bytes_cell <= 2 * in_bytes_cell ? 3 : 2;
-    if (const char* e = getenv("SPLASH_HIP_LANES")) n_lanes = std::max(1, std::min(4, atoi(e)));
+    const Knobs kn = knobs();
+    if (kn.lanes > 0) n_lanes = kn.lanes;
     const size_t acc_bytes = splash_dev_diag_acc_size(P.n_basin, P.nmonth);
     {
         // Sizing and allocation happen under the device's allocation lock: a second job on the same
@@ -794,8 +779,8 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
         std::lock_guard<std::recursive_mutex> alloc_lock(device_alloc_mutex(device));
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b), err, errlen);
-        if (const char* e = getenv("SPLASH_HIP_FAKE_DEVICE_BYTES")) { // test aid: a device of that many bytes, of
-            const size_t fake = (size_t)atoll(e), held = pool_held_bytes(device); // which the pool's buffers are taken
+        if (kn.fake_device) { // test aid: a device of that many bytes, of
+            const size_t fake = kn.fake_device_bytes, held = pool_held_bytes(device); // which the pool's buffers are taken
             free_b = std::min(free_b, fake > held ? fake - held : 0);
         }
         free_b += pool_idle_bytes(device); // buffers kept from earlier calls are ours to reuse or release
@@ -804,7 +789,7 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
         size_t pcap = std::min<size_t>(std::max<size_t>(want / 128, 16384), (size_t)1 << 18);
         pcap = std::min(pcap, (want + 255) & ~(size_t)255);
         pcap = (pcap + 255) & ~(size_t)255;
-        if (const char* e = getenv("SPLASH_HIP_POOL_CAP")) pcap = std::max<size_t>(1, (size_t)atol(e)); // tests: force the overflow path
+        if (kn.pool_cap) pcap = kn.pool_cap; // tests: force the overflow path
         const size_t pool_per_slot = (size_t)nt * 3 * 8 + (size_t)nt_out * std::max(n_out, 1) * 8 +
                                      (SPLASH_NPAR + SPLASH_NSTATE + 1) * 8 + 8 + 2 * 4 + 4;
         const double pool_bytes = (double)pcap * (double)pool_per_slot + (double)splash_dev_spin_up_work_size(pcap);
@@ -817,8 +802,8 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
         // least (a block's later spin-up phases are short worklists, i.e. latency: ~30 ms per block)
         // (SPLASH_HIP_BLOCKS_PER_LANE / SPLASH_HIP_MIN_BLOCK_CELLS: tests run the many-blocks plan on small grids)
         size_t nb_max = want;
-        const size_t per_lane = std::max<size_t>(1, env_size("SPLASH_HIP_BLOCKS_PER_LANE", 4));
-        const size_t min_block = std::max<size_t>(1, env_size("SPLASH_HIP_MIN_BLOCK_CELLS", (size_t)1 << 20));
+        const size_t per_lane = kn.blocks_per_lane;
+        const size_t min_block = kn.min_block_cells;
         if (want > min_block) nb_max = std::max<size_t>(min_block, (want + per_lane * n_lanes - 1) / (per_lane * n_lanes));
         if (P.max_cells) nb_max = std::min(nb_max, P.max_cells);
         auto lanes_for = [&](size_t nb) { return (int)std::min<size_t>((size_t)n_lanes, (want + nb - 1) / nb); };
@@ -913,8 +898,10 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
 
 } // namespace
 
-extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
-                               const splash_grid_out* out, char* err, size_t errlen)
+// the call itself, on whatever thread runs it (the caller's, or the job thread of splash_grid_submit:
+// the environment knobs were sampled by the entry point, on the caller's thread)
+static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const splash_grid_out* out, char* err,
+                         size_t errlen)
 {
     if (!in || !out) return fail(SPLASH_EINVAL, err, errlen, "grid_run: NULL in/out");
     const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -1077,8 +1064,8 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
         for (int k = 0; k < SPLASH_NOUT; k++) total += P.dst[k] ? elems_each * (size_t)P.esz[k] : 0;
         // SPLASH_HIP_REGISTER_MIN_BYTES: result bytes from which registering pays (tests set 0 to run the
         // path on small grids); SPLASH_HIP_NO_REGISTER=1 disables it
-        const bool off = getenv("SPLASH_HIP_NO_REGISTER") != nullptr;
-        if (!off && P.dense && total >= env_size("SPLASH_HIP_REGISTER_MIN_BYTES", (size_t)8 << 30)) {
+        const Knobs kn = knobs();
+        if (!kn.no_register && P.dense && total >= kn.register_min_bytes) {
             const int dev0 = devs[0];
             // the forcing too (both directions must be page-locked for the copies to overlap), first:
             // its copies start at once
@@ -1116,12 +1103,19 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
         if (out->diag_acc) std::copy(total.begin(), total.end(), out->diag_acc);
         if (out->diag) splash_diag_finalize_host(total.data(), P.n_basin, P.nmonth, out->diag, nullptr);
     }
-    if (getenv("SPLASH_TRACE")) {
+    if (knobs().trace) {
         const double t_end = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
         fprintf(stderr, "[splash] grid_run: NA scan %.3f s, workers %.3f s, total %.3f s\n", t_scan - t_enter,
                 t_end - t_scan, t_end - t_enter);
     }
     return SPLASH_OK;
+}
+
+extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
+                               const splash_grid_out* out, char* err, size_t errlen)
+{
+    knobs_refresh();
+    return grid_run_impl(in, opt, out, err, errlen);
 }
 
 struct splash_grid_job {
@@ -1139,7 +1133,7 @@ extern "C" int splash_grid_submit(const splash_grid_in* in, const splash_opts* o
                                   splash_grid_job** job, char* err, size_t errlen)
 {
     if (!in || !out || !job) return fail(SPLASH_EINVAL, err, errlen, "grid_submit: NULL in/out/job");
-    if (int rc = need_device(err, errlen)) return rc;
+    if (int rc = enter_device(err, errlen)) return rc;
     auto* j = new splash_grid_job;
     j->in = *in;
     j->out = *out;
@@ -1152,7 +1146,7 @@ extern "C" int splash_grid_submit(const splash_grid_in* in, const splash_opts* o
         }
     }
     try {
-        j->th = std::thread([j] { j->rc = splash_grid_run(&j->in, j->has_opt ? &j->opt : nullptr, &j->out, j->msg, sizeof j->msg); });
+        j->th = std::thread([j] { j->rc = grid_run_impl(&j->in, j->has_opt ? &j->opt : nullptr, &j->out, j->msg, sizeof j->msg); });
     } catch (...) {
         delete j;
         return fail(SPLASH_ENOMEM, err, errlen, "grid_submit: could not start a host thread");

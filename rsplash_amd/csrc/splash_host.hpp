@@ -25,6 +25,39 @@ namespace host {
 extern thread_local std::string g_err;
 int fail(int code, char* err, size_t errlen, const char* fmt, ...) __attribute__((format(printf, 4, 5)));
 int need_device(char* err, size_t errlen);
+int enter_device(char* err, size_t errlen); // knobs_refresh() + need_device(): public entry points (caller's thread)
+
+// Environment knobs (tests, A/B timing, tuning aids; INTEGRATION.md lists them).  getenv() is only
+// ever called on the thread that ENTERS the library (knobs_refresh(), first statement of the public
+// entry points that start work): lane, pool and helper threads read the snapshot, so no thread of
+// the library reads the environment while the caller's thread may be changing it between calls.
+// A job in flight (splash_grid_submit) sees the snapshot of the latest entry.
+struct Knobs {
+    bool no_pool = false;              // SPLASH_HIP_NO_POOL
+    long spin_cache_cap = 0;           // SPLASH_HIP_SPIN_CACHE_CAP (frozen at the first entry: the workspace layout depends on it)
+    int dbg_active_lanes = 0;          // SPLASH_DBG_ACTIVE_LANES (measurement builds)
+    bool no_nd_skip = false;           // SPLASH_HIP_NO_ND_SKIP
+    bool no_block_phase1 = false;      // SPLASH_HIP_NO_BLOCK_PHASE1
+    bool no_solo_tail = false;         // SPLASH_HIP_NO_SOLO_TAIL
+    int tail_stage[2] = {-1, -1};      // SPLASH_HIP_TAIL_STAGES="a,b"
+    int tail_lds_pad = 57344;          // SPLASH_HIP_TAIL_LDS_PAD
+    int prefault_mode = 0;             // SPLASH_HIP_PREFAULT (populate | touch | off)
+    size_t prefault_min_bytes = (size_t)64 << 20; // SPLASH_HIP_PREFAULT_MIN_BYTES
+    size_t prefault_delay_ms = 0;      // SPLASH_HIP_PREFAULT_DELAY_MS (test aid)
+    bool test_prefault_whole_range = false; // SPLASH_HIP_TEST_PREFAULT_WHOLE_RANGE (fault injection, tests only)
+    bool trace = false;                // SPLASH_TRACE
+    int lanes = 0;                     // SPLASH_HIP_LANES (0: chosen by the call)
+    bool fake_device = false;          // SPLASH_HIP_FAKE_DEVICE_BYTES given
+    size_t fake_device_bytes = 0;
+    size_t pool_cap = 0;               // SPLASH_HIP_POOL_CAP (0: chosen by the call)
+    size_t blocks_per_lane = 4;        // SPLASH_HIP_BLOCKS_PER_LANE
+    size_t min_block_cells = (size_t)1 << 20; // SPLASH_HIP_MIN_BLOCK_CELLS
+    bool no_register = false;          // SPLASH_HIP_NO_REGISTER
+    size_t register_min_bytes = (size_t)8 << 30; // SPLASH_HIP_REGISTER_MIN_BYTES
+};
+enum { PREFAULT_POPULATE = 0, PREFAULT_TOUCH = 1, PREFAULT_OFF = 2 };
+void knobs_refresh(); // the calling thread of a public entry point
+Knobs knobs();        // the snapshot (any thread)
 
 // device buffers of the host-buffer entry points are kept between calls (splash_capi.hip)
 hipError_t pool_alloc(void** out, size_t bytes);

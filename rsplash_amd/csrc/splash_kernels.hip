@@ -229,6 +229,30 @@ extern "C" int splash_dbg_set_diff(float* p)
 }
 #endif
 
+#ifdef SPL_CHECK_SLOTS
+// checking build (librsplash_hip_check.so; tests/test_gpu_parity.py::test_read_back_never_addresses_a_slot_beyond_the_cache):
+// every access to the spin-up's record cache reports its slot.  [0] wavefront-level accesses, [1] lane accesses
+// whose slot lies beyond the capacity the launch was given -- must stay 0.
+__device__ unsigned long long g_slot_check[2];
+__device__ __forceinline__ void slot_check(size_t slot, size_t cap)
+{
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_slot_check[0], 1ull);
+    if (slot >= cap) atomicAdd(&g_slot_check[1], 1ull);
+}
+extern "C" int splash_dbg_slot_check(unsigned long long out[2], int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slot_check), 2 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[2] = {0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_slot_check), z, sizeof z);
+    }
+    return (int)e;
+}
+#define SPL_SLOT_CHECK(slot, cap) slot_check(slot, cap)
+#else
+#define SPL_SLOT_CHECK(slot, cap) ((void)0)
+#endif
+
 // ================================================================ K4 spin-up ===================
 // Grid spin-up: both spin-ups of splash.point (R/splash.point.R:141-152) as a resumable per-cell
 // job.  The number of passes is data dependent (2..1000, src/SPLASH.cpp:1697): most cells need
@@ -273,6 +297,7 @@ __device__ __forceinline__ void rec_store(double* __restrict__ base, size_t cap,
                                           const DayRecord& r)
 {
     // the viscosity is a float: its 32 bits and the melt flag share one word, exactly
+    SPL_SLOT_CHECK(slot, cap);
     const unsigned long long vw = (unsigned long long)__float_as_uint((float)r.T.visc) |
                                   ((unsigned long long)(r.T.warm ? 1u : 0u) << 32);
     const double v[kRichStride] = {r.T.ru, r.T.ruv, r.T.hs, r.T.sin_hs, r.T.xrw, r.T.rnl, r.T.s, r.T.g,
@@ -300,6 +325,7 @@ template <bool RICH>
 __device__ __forceinline__ RawRecord<RICH> rec_load(const double* __restrict__ base, size_t cap, int day, size_t slot)
 {
     RawRecord<RICH> w;
+    SPL_SLOT_CHECK(slot, cap);
     if constexpr (RICH) {
         const double2* p = reinterpret_cast<const double2*>(base + (slot * kRichDays + (size_t)day) * kRichStride);
 #pragma unroll
@@ -368,7 +394,11 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
 #if defined(SPL_TAIL_STATS) && defined(SPL_DIFF_STATS)
     const unsigned long long t_wave_start = wall_clock64();
 #endif
-    const size_t nin = a.n_in ? (size_t)*a.n_in : a.ncell;
+    size_t nin = a.n_in ? (size_t)*a.n_in : a.ncell;
+    // A spread launch over the tail's own list (no wl_slots: list position == cache slot) deals only the
+    // positions the host sized the launch for, a.ncell = min(list bound, cache capacity): positions beyond
+    // the cache have no records here and belong to the general-kernel launch that follows (spin_phases).
+    if (READBACK && a.spread && !a.wl_slots && nin > a.ncell) nin = a.ncell;
     // Launch position -> job.  Packed (default): 64 jobs to a wavefront.  Spread (the tail's stages, READBACK
     // only): the jobs are dealt over 1024 wavefronts -- one per SIMD of the chip --, k = ceil(n / 1024) to each.
     // A wavefront executes the union of the branches of its lanes: a job that has the wavefront to itself skips
@@ -406,7 +436,9 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
 #endif
     // The tail is the critical path of a call and a handful of wavefronts; whatever shares a SIMD with them (the
     // transient run of the finished cells, launched beside it) is throughput work: the tail's wavefronts issue first.
-    if (READBACK && RICH) __builtin_amdgcn_s_setprio(3);
+    // (Only the spread launches: the packed read-back launches of phases 1-6 are throughput work themselves --
+    // up to 4e5 jobs -- and must not out-prioritise another lane's wavefronts on a shared SIMD.)
+    if (READBACK && RICH && a.spread) __builtin_amdgcn_s_setprio(3);
     // the list may hold positions of ANOTHER list (wl_slots: the survivors of the tail's first stage keep
     // the cache slot = position they had there)
     const size_t sl0 = valid ? slot : nin - 1;
@@ -416,6 +448,10 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     // phase 0 whose records are still in the cache
     const size_t cs = a.slot_by_cell ? ci - a.cell0 : sl;
     const bool cached = CACHED && a.cache != nullptr && cs < a.cache_cap;
+    // No address is ever formed from a slot the cache does not have: a read-back lane without a slot is `done`
+    // from the start but steps along with its wavefront, and with records laid out job by job its loads would
+    // land (cs - cache_cap) x 58 KB past the workspace.  Such lanes read slot 0's records (and store nothing).
+    const size_t cs_ld = cached ? cs : 0;
 
     s_cell_Tt[threadIdx.x] = a.Tt[ci]; // own slot: no barrier needed
     Forcing f{a.sw, a.tc, a.pn, nullptr, a.ldf, 0.0,
@@ -460,7 +496,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     auto day_one = [&](State& st_, DayOut& o_, double* p_day) {
         DayRecord r;
         if (READBACK || (CACHED && cached && p_day == nullptr)) {
-            r = rec_decode<RICH>(c, rec_load<RICH>(a.cache, a.cache_cap, 0, cs), d0.cd);
+            r = rec_decode<RICH>(c, rec_load<RICH>(a.cache, a.cache_cap, 0, cs_ld), d0.cd);
         } else if constexpr (!READBACK) {
             double sw0, tc0, pn0;
             f.raw(0, sw0, tc0, pn0);
@@ -512,6 +548,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     // passes since the phase began is a power of two.
     bool done = !valid || finished_before || (READBACK && !cached);
     for (int it = 0; it < a.budget; it++) {
+        if (READBACK && it == 0 && __all(done)) break; // a wavefront with nothing to do here (every job beyond the cache)
         const bool acc = !READBACK && a.fresh && it == 0; // first pass of spin-up #1 (uniform)
         // (Finished lanes keep stepping along with the wavefront.  Masking them out of the pass -- so that
         // only the branches of the jobs still running are executed -- was measured in round 3: the
@@ -520,10 +557,10 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
         // cur = state after day 1 of this pass (== the parked start-of-pass state)
         if (READBACK || (CACHED && cached && it > 0)) {
             // read-back pass: next day's record is requested a day ahead
-            RawRecord<RICH> w = rec_load<RICH>(a.cache, a.cache_cap, 1, cs);
+            RawRecord<RICH> w = rec_load<RICH>(a.cache, a.cache_cap, 1, cs_ld);
             for (int i = 1; i < a.n; i++) {
                 const DayRecord r = rec_decode<RICH>(c, w, RICH ? 0.0 : days[i].cd);
-                if (i + 1 < a.n) w = rec_load<RICH>(a.cache, a.cache_cap, i + 1, cs); // tomorrow's, untouched until tomorrow
+                if (i + 1 < a.n) w = rec_load<RICH>(a.cache, a.cache_cap, i + 1, cs_ld); // tomorrow's, untouched until tomorrow
                 day_update(c, r.T, r.V, r.rain, r.snf, cur, o);
             }
         } else if constexpr (!READBACK) {
@@ -1827,8 +1864,7 @@ hipError_t launch_spin_phase(const SpinPhaseArgs& a, hipStream_t s)
             if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
             int g = dev < 0 ? -1 : granted[dev].load(std::memory_order_acquire);
             if (g == 0) {
-                const char* e = getenv("SPLASH_HIP_TAIL_LDS_PAD"); // (A/B: 0 switches it off)
-                const int want = e ? atoi(e) : 57344;              // static 25.9 KB + 56 KB > 80 KB
+                const int want = a.lds_pad;                        // static 25.9 KB + 56 KB > 80 KB (A/B: 0 switches it off)
                 g = want > 0 && hipFuncSetAttribute((const void*)k_spin_phase<true, true, true>,
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess
                         ? want : -1;

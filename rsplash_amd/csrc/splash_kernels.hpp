@@ -70,7 +70,7 @@ struct SpinPhaseArgs {
     int fresh;              // phase 0
     unsigned char* pending; // [ncell] or NULL: set to 1 for every job parked by this launch
     ViscTables vt;
-    double* cache;          // [365][19][cache_cap] records of the day terms, or NULL
+    double* cache;          // records of the day terms (compact: [365][15][cache_cap]; rich: [cache_cap][365][20]), or NULL
     size_t cache_cap;       // jobs (launch positions) the cache has room for
     size_t cell0;           // phase 0 runs in blocks of cache_cap cells: first cell of this launch
     size_t ntotal;          // cells of the whole call (row stride of `passes`)
@@ -86,6 +86,7 @@ struct SpinPhaseArgs {
     int queue_slots;        // 1: unfinished jobs are queued by their position (for a wl_slots launch), not by cell
     int dbg_active_lanes;   // measurement builds only (tools/solo_tail.py): lanes of a spread wavefront that stay active
     int no_nd_skip;         // test aid (SPLASH_HIP_NO_ND_SKIP): the cycle detector compares the snow age too, always
+    int lds_pad;            // spread launches: bytes of dynamic LDS asked for and never touched (one workgroup per CU), 0: none
     int rich;               // 1: the cache holds rich records, 20 words each, record by record (cache_cap = spin_cache_rich_cap of the
                             //    workspace's capacity), see splash_kernels.hip "Two layouts"
 };

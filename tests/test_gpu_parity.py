@@ -1281,6 +1281,78 @@ np.savez(sys.argv[1], **out)
     assert a["passes"][1].max() == 1000 and a["passes"][1].min() >= 1   # the tail is exercised
 
 
+def test_read_back_never_addresses_a_slot_beyond_the_cache():
+    """the read-back kernel formed record addresses from slots the cache does not have (lanes
+    beyond the capacity are `done` but step along with their wavefront; with records laid out job by job
+    that was (slot - cap) x 58 KB past the workspace, harmless only because torch's segment was mapped).
+    The checking build of the library (librsplash_hip_check.so: the same sources with -DSPL_CHECK_SLOTS)
+    reports every access to the record cache with its slot and the capacity the launch was given.  A
+    capacity of 128 compact = 64 rich slots on a 128 x 512 grid gives every later phase a list far longer
+    than the cache (packed launches) and the tail a list longer than 64 jobs (spread launches: before the
+    fix they dealt ALL jobs of the list); no access may name a slot >= the capacity, and the states must
+    equal the product library's with its default layout, bit for bit."""
+    import subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    chk = os.path.join(root, "rsplash_amd", "librsplash_hip_check.so")
+    assert os.path.exists(chk), "librsplash_hip_check.so is built by rsplash_amd.build_library() (make all)"
+    code = r'''
+import sys, ctypes as C, numpy as np, torch
+sys.path.insert(0, %r)
+from rsplash_amd import api
+from rsplash_amd._lib import lib
+dev = torch.device("cuda:0")
+H, W, nt = 128, 512, 365
+n = H * W
+cal = api.Calendar.from_dates(np.datetime64("2001-01-01") + np.arange(nt))
+f64 = dict(dtype=torch.float64, device=dev)
+lat, elev, slop, asp, res = (torch.empty(n, **f64) for _ in range(5))
+soil, au = torch.empty(6, n, **f64), torch.empty(3, n, **f64)
+api.dev_synth_statics(424242, H, W, 0, n, 1, lat, elev, slop, asp, res, soil, au)
+sw, tc, pn = (torch.empty(nt, n, **f64) for _ in range(3))
+api.dev_synth_forcing(424242, cal, 0, nt, 0, n, lat, elev, sw, tc, pn, n)
+par = torch.empty(api.NPAR, n, **f64); Tt = torch.empty(n, **f64)
+api.dev_soil_hydro(n, lat, elev, slop, asp, res, soil, au, par)
+api.dev_snow_threshold(n, nt, tc, n, par, n, Tt)
+state = torch.empty(api.NSTATE, n, **f64)
+# the workspace is the LAST bytes of its allocation (exact size, nothing of ours behind the cache)
+work = torch.empty(api.spin_up_work_size(n), dtype=torch.uint8, device=dev)
+api.dev_spin_up_begin(cal, n, sw, tc, pn, n, Tt, par, n, state, n, work)
+pending = api.dev_spin_up_pending_count(work, n)
+api.dev_spin_up_finish(cal, n, sw, tc, pn, n, Tt, par, n, state, n, work)
+torch.cuda.synchronize()
+out = dict(state=state.cpu().numpy(), ai=par[15].cpu().numpy(), pending=np.array([pending]))
+if hasattr(lib, "splash_dbg_slot_check"):
+    v = (C.c_ulonglong * 2)()
+    lib.splash_dbg_slot_check.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    assert lib.splash_dbg_slot_check(v, 0) == 0
+    out["slots"] = np.array([v[0], v[1]], dtype=np.uint64)
+np.savez(sys.argv[1], **out)
+''' % root
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, lib_, cap in (("product", None, None), ("check", chk, "128")):
+            env = dict(os.environ)
+            env.pop("SPLASH_HIP_SPIN_CACHE_CAP", None)
+            env.pop("SPLASH_HIP_LIBRARY", None)
+            if lib_:
+                env["SPLASH_HIP_LIBRARY"] = lib_
+            if cap:
+                env["SPLASH_HIP_SPIN_CACHE_CAP"] = cap
+            f = os.path.join(d, tag + ".npz")
+            subprocess.run([sys.executable, "-c", code, f], env=env, check=True)
+            res[tag] = dict(np.load(f))
+    a, b = res["product"], res["check"]
+    assert "slots" in b and "slots" not in a          # the checking build ran where it was meant to
+    accesses, beyond = int(b["slots"][0]), int(b["slots"][1])
+    assert accesses > 10_000, accesses                 # the cached paths were exercised
+    assert int(b["pending"][0]) > 64, b["pending"]     # a tail list longer than the 64 rich slots
+    assert beyond == 0, f"{beyond} record accesses named a slot beyond the cache's capacity"
+    for k in ("state", "ai"):
+        assert np.array_equal(a[k].view(np.int64), b[k].view(np.int64)), k
+    assert int(a["pending"][0]) == int(b["pending"][0])
+
+
+@pytest.mark.gpu
 def test_overlapped_spin_up_gives_the_same_bits(api, oracle):
     """splash_dev_spin_up_begin / _finish with the transient run of the finished cells in between
     (skip mask) and the late cells in list mode afterwards == the plain sequence, bit for bit, water-
