@@ -1287,7 +1287,8 @@ def test_read_back_never_addresses_a_slot_beyond_the_cache():
     that was (slot - cap) x 58 KB past the workspace, harmless only because torch's segment was mapped).
     The checking build of the library (librsplash_hip_check.so: the same sources with -DSPL_CHECK_SLOTS)
     reports every access to the record cache with its slot and the capacity the launch was given.  A
-    capacity of 128 compact = 64 rich slots on a 128 x 512 grid gives every later phase a list far longer
+    capacity of 128 compact = 64 rich slots on 64 low-latitude rows of the benchmark grid (262 144 cells,
+    where the long chains are densest) gives every later phase a list far longer
     than the cache (packed launches) and the tail a list longer than 64 jobs (spread launches: before the
     fix they dealt ALL jobs of the list); no access may name a slot >= the capacity, and the states must
     equal the product library's with its default layout, bit for bit."""
@@ -1301,15 +1302,15 @@ sys.path.insert(0, %r)
 from rsplash_amd import api
 from rsplash_amd._lib import lib
 dev = torch.device("cuda:0")
-H, W, nt = 128, 512, 365
-n = H * W
+H, W, nt = 4096, 4096, 365
+cell0, n = 1800 * W, 64 * W
 cal = api.Calendar.from_dates(np.datetime64("2001-01-01") + np.arange(nt))
 f64 = dict(dtype=torch.float64, device=dev)
 lat, elev, slop, asp, res = (torch.empty(n, **f64) for _ in range(5))
 soil, au = torch.empty(6, n, **f64), torch.empty(3, n, **f64)
-api.dev_synth_statics(424242, H, W, 0, n, 1, lat, elev, slop, asp, res, soil, au)
+api.dev_synth_statics(20221130, H, W, cell0, n, 1, lat, elev, slop, asp, res, soil, au)
 sw, tc, pn = (torch.empty(nt, n, **f64) for _ in range(3))
-api.dev_synth_forcing(424242, cal, 0, nt, 0, n, lat, elev, sw, tc, pn, n)
+api.dev_synth_forcing(20221130, cal, 0, nt, cell0, n, lat, elev, sw, tc, pn, n)
 par = torch.empty(api.NPAR, n, **f64); Tt = torch.empty(n, **f64)
 api.dev_soil_hydro(n, lat, elev, slop, asp, res, soil, au, par)
 api.dev_snow_threshold(n, nt, tc, n, par, n, Tt)
