@@ -1,0 +1,213 @@
+"""splash.grid() end to end, with the reference's signature (R/splash.grid.R:28):
+
+    splash_grid(sw_in, tc, pn, elev, soil, outdir=os.getcwd(), tmpdir=None,
+                sim_control=dict(monthly_out=True, inmem=False))
+
+What the reference does around its per-cell calls, and where each part lives here:
+
+  R/splash.grid.R:40       compareRaster of the five inputs        -> _compare()
+  :76-110                  resolution, upslope area (Au), latitude,
+                           slope/aspect with NA slopes of valid
+                           cells as flats                           -> api.static_rasters (HIP: §8 f-1, f-2)
+  :120-181                 time axis of the inputs and the outputs  -> io.output_time_axis
+  :186-216                 nine empty bricks on disk                -> io.BrickWriter (NetCDF, streamed)
+  :260-275                 row blocks (blockSize)                   -> row_blocks()
+  :277-308, 315-400        clFun on the cluster's nodes, the
+                           receive loop that writes a block and
+                           hands the free node the next one        -> one splash_grid_submit per block, `inflight`
+                                                                       of them in the library at a time; a block
+                                                                       is written while the next ones compute
+  :409-449                 writeStop, the returned list             -> paths (inmem=False) or arrays (inmem=True)
+
+This is the Python twin of r/splash_hip.R::splash.grid() (which cannot be run in this image: no R);
+the GPU tests run THIS loop and compare it with one call over the whole grid, bit for bit.
+
+Rasters: a `Raster` carries what splash.grid reads off a RasterLayer/RasterBrick -- values
+[H, W] or [nl, H, W] (anything that can be sliced by rows: ndarray, numpy.memmap, a variable of
+scipy.io.netcdf_file opened with mmap=True), the extent's ymax/xmin, the resolution and, for the
+forcing bricks, the layer dates (getZ).  A lon/lat grid is assumed, as raster::area() and the
+reference's latitude raster do.
+"""
+import os
+from dataclasses import dataclass
+from typing import Any, Optional, Sequence
+
+import numpy as np
+
+from . import api, io as _io
+
+
+@dataclass
+class Raster:
+    values: Any                      # [H, W] or [nl, H, W], row 0 = northernmost
+    ymax: float                      # extent: northern edge (degrees)
+    xmin: float                      # extent: western edge
+    yres: float                      # cell height (degrees, > 0)
+    xres: float                      # cell width
+    z: Optional[Sequence] = None     # layer dates (getZ) of a forcing brick
+
+    @property
+    def nrow(self):
+        return int(np.shape(self.values)[-2])
+
+    @property
+    def ncol(self):
+        return int(np.shape(self.values)[-1])
+
+    def like(self, values, z=None):
+        return Raster(values, self.ymax, self.xmin, self.yres, self.xres, z)
+
+    def lat(self):
+        return self.ymax - self.yres * (np.arange(self.nrow) + 0.5)
+
+    def lon(self):
+        return self.xmin + self.xres * (np.arange(self.ncol) + 0.5)
+
+    def rows(self, r0, r1):
+        """getValues(x, row, nrows): rows [r0, r1) as a C-contiguous float array"""
+        v = self.values
+        a = v[r0:r1] if np.ndim(v) == 2 else v[:, r0:r1]
+        a = np.asarray(a)
+        if a.dtype not in (np.float32, np.float64) or not a.dtype.isnative:
+            a = a.astype(np.float32 if a.dtype.itemsize == 4 and a.dtype.kind == "f" else np.float64)
+        return np.ascontiguousarray(a)
+
+
+def _compare(rasters, tol=0.5):
+    """compareRaster(..., extent=TRUE, res=TRUE, rotation=FALSE, values=FALSE) with
+    rasterOptions(tolerance = 0.5) (R/splash.grid.R:39-40): same rows/columns, and extent and resolution
+    equal to within `tol` cells.  The reference only warns (stopiffalse=FALSE) and then fails somewhere
+    inside a worker; here a mismatch is an error."""
+    a = rasters[0]
+    for b in rasters[1:]:
+        if (a.nrow, a.ncol) != (b.nrow, b.ncol):
+            raise ValueError(f"rasters differ in rows/columns: {(a.nrow, a.ncol)} vs {(b.nrow, b.ncol)}")
+        if abs(a.ymax - b.ymax) > tol * a.yres or abs(a.xmin - b.xmin) > tol * a.xres:
+            raise ValueError("rasters differ in extent")
+        if abs(a.yres - b.yres) > tol * a.yres or abs(a.xres - b.xres) > tol * a.xres:
+            raise ValueError("rasters differ in resolution")
+
+
+def row_blocks(nrow, ncol, bytes_per_cell, target_bytes=2 << 30, minblocks=2, block_rows=None):
+    """raster::blockSize: [(row0, nrows)] covering the grid once, whole rows, at least `minblocks`
+    blocks (the reference asks for 2 per node, 10 on one node, R/splash.grid.R:266-270) of at most
+    `target_bytes` of values each."""
+    if block_rows is None:
+        by_mem = max(1, int(target_bytes // max(1, bytes_per_cell * ncol)))
+        by_count = max(1, -(-nrow // max(1, minblocks)))
+        block_rows = min(by_mem, by_count)
+    block_rows = max(1, min(int(block_rows), nrow))
+    return [(r, min(block_rows, nrow - r)) for r in range(0, nrow, block_rows)]
+
+
+def grid_statics(elev, degree=1.0, method=None):
+    """R/splash.grid.R:76-110 from the elevation raster alone: latitude, slope/aspect (NA slopes of
+    valid cells are flats, :107), resolution = sqrt(cell area) and the Au stack (contributing area,
+    cells draining in, cells draining out; R/upslope_area.R:56).  Like the reference, large or coarse
+    grids (ncell > 1e7, or 0.1 < resolution < 1 degree) take the D8 area of `upslope_areav2`, the others
+    the multiple-flow-direction area of `upslope_area` (:76-77); `method` ("tau" / "top") overrides."""
+    e = np.ascontiguousarray(np.asarray(elev.values, dtype=np.float64))
+    if method is None:
+        method = "tau" if (e.size > 1e7 or 0.1 < elev.xres < 1) else "top"
+    area_key = "ups_area" if method == "tau" else "ups_area_mfd"
+    s = api.static_rasters(e, elev.ymax, elev.yres, elev.xres, na_to_zero=True, degree=degree,
+                           want=("slope", "aspect", "lat", "resolution", area_key, "ncellin", "ncellout"))
+    return dict(lat=s["lat"], slop=s["slope"], asp=s["aspect"], resolution=s["resolution"],
+                Au=np.stack([s[area_key], s["ncellin"], s["ncellout"]]), method=method)
+
+
+def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control=None, *,
+                devices=None, inflight=2, block_rows=None, statics=None, out_dtype=np.float64,
+                want_diag=False, basin=None, n_basin=0, progress=None):
+    """R/splash.grid.R:28.  sw_in, tc, pn: Raster bricks [nl, H, W] with layer dates (`z`, taken from
+    pn like getZ(pn), :144); elev: Raster [H, W]; soil: Raster [6, H, W] (sand, clay, OM, gravel, bulk
+    density, depth).  sim_control = dict(monthly_out=True, inmem=False) as the reference's default.
+    Returns the reference's list (:449) as a dict wn, ro, pet, aet, snow, bflow, cond, netrad, sm_lim:
+    paths of the NetCDF bricks under `outdir` (inmem=False) or [nl_out, H, W] arrays (inmem=True), plus
+    "statics" (what :76-110 derived) and, with want_diag, the exact water-balance totals summed over the
+    blocks ("diag", "diag_acc": integer limbs, so the sum over blocks IS the one-call total).
+    `tmpdir` is accepted for the signature's sake (the reference parks intermediate rasters there; nothing
+    is parked here).  devices: HIP ordinals every block is split over inside the library; inflight:
+    blocks in the library at a time; block_rows: rows per block (default: ~2 GB of forcing per block, at
+    least two blocks)."""
+    ctl = dict(monthly_out=True, inmem=False)
+    ctl.update(sim_control or {})
+    monthly, inmem = bool(ctl["monthly_out"]), bool(ctl["inmem"])
+    _compare([sw_in, tc, pn, elev, soil])
+    if pn.z is None:
+        raise ValueError("pn carries no layer dates (Raster.z): getZ(pn), R/splash.grid.R:144")
+    ztime = np.asarray(pn.z, dtype="datetime64[D]")
+    nt = int(np.shape(pn.values)[0])
+    if ztime.size != nt or np.shape(sw_in.values)[0] != nt or np.shape(tc.values)[0] != nt:
+        raise ValueError("the forcing bricks and the layer dates differ in length")
+    if np.shape(soil.values)[0] != 6:
+        raise ValueError("soil needs six layers: sand, clay, OM, gravel, bulk density, depth")
+    H, W = elev.nrow, elev.ncol
+    st = statics or grid_statics(elev)
+    z_out, _, _, y0, y1 = _io.output_time_axis(ztime, monthly)
+    nl = z_out.size
+    if not monthly and nl != nt:
+        raise ValueError("daily output needs whole calendar years of input (R/splash.grid.R:161-181)")
+    keys = api.OUT_NAMES
+    writer = None
+    mats = None
+    if inmem:
+        mats = {k: np.empty((nl, H, W), out_dtype) for k in keys}
+    else:
+        outdir = outdir or os.getcwd()
+        writer = _io.BrickWriter(outdir, keys, elev.lon(), elev.lat(), ztime, monthly)
+    itemsize = 4 if all(np.asarray(x.values[:1, :1, :1]).dtype == np.float32 for x in (sw_in, tc, pn)) else 8
+    bs = row_blocks(H, W, 3 * nt * itemsize, minblocks=2, block_rows=block_rows)
+    inflight = max(1, min(int(inflight), len(bs)))
+    acc_total = None
+    if basin is not None and not n_basin:   # one numbering for every block (a block sees only its own ids)
+        n_basin = int(np.nanmax(np.asarray(basin))) + 1
+
+    def submit(i):
+        r0, nr = bs[i]
+        r1 = r0 + nr
+        cut = lambda a: np.ascontiguousarray(np.asarray(a)[..., r0:r1, :])
+        return api.splash_grid(
+            sw_in.rows(r0, r1), tc.rows(r0, r1), pn.rows(r0, r1), elev.rows(r0, r1), soil.rows(r0, r1),
+            cut(st["lat"]), cut(st["slop"]), cut(st["asp"]), cut(st["Au"]), cut(st["resolution"]),
+            time_index=ztime, sim_control=dict(monthly_out=monthly), devices=devices, submit=True,
+            mem_fraction=0.8 / inflight, want_state=False, out_dtype=out_dtype, want_diag=want_diag,
+            basin=None if basin is None else cut(np.asarray(basin).reshape(H, W)), n_basin=n_basin)
+
+    # the receive loop of R/splash.grid.R:359-400: collect block i, hand the free slot block i + inflight,
+    # write block i while the others compute
+    jobs = [None] * len(bs)
+    try:
+        for i in range(inflight):
+            jobs[i] = submit(i)
+        for i, (r0, nr) in enumerate(bs):
+            res = jobs[i].wait()
+            jobs[i] = None
+            if i + inflight < len(bs):
+                jobs[i + inflight] = submit(i + inflight)
+            for k in keys:
+                if inmem:
+                    mats[k][:, r0:r0 + nr, :] = res[k]
+                else:
+                    writer.write(k, r0, res[k])
+            if want_diag:
+                acc_total = res["diag_acc"].copy() if acc_total is None else acc_total + res["diag_acc"]
+            if progress:
+                progress(i + 1, len(bs))
+    finally:
+        for j in jobs:          # an error mid-way: wait for what is still in the library before the
+            if j is not None:   # arrays it reads and writes go away
+                j.close()
+        if writer:
+            writer.close()
+    ret_names = dict(wn="wn", ro="ro", pet="pet", aet="aet", snow="snow", bflow="bflow", cond="cond",
+                     netr="netrad", sm_lim="sm_lim")     # R/splash.grid.R:449
+    src = mats if inmem else writer.paths
+    out = {ret_names[k]: src[k] for k in ("wn", "ro", "pet", "aet", "snow", "bflow", "cond", "netr", "sm_lim")}
+    out["statics"] = st
+    out["blocks"] = bs
+    if want_diag:
+        out["diag_acc"] = acc_total
+        d, _ = api.diag_finalize_host(acc_total)
+        out["diag"] = {k: (d[:, :, j] if basin is not None else d[0, :, j]) for j, k in enumerate(api.DIAG_NAMES)}
+    return out

@@ -84,3 +84,138 @@ def write_bricks(outdir, res, lon, lat, time_index, monthly_out):
             f.title = "SPLASH v2.0 " + longname
         paths[key] = path
     return paths
+
+
+# ---------------------------------------------------------------------------------------------------
+# Streaming bricks: the file is created once (header + coordinate variables), the data variable is a
+# window of the file that row blocks are stored into as they arrive -- what raster's writeStart /
+# writeValues(brick, block, row) / writeStop do around the reference's receive loop
+# (R/splash.grid.R:186-216, 370-400, 409-417).  scipy's writer keeps a whole variable in memory until
+# close(); a brick of the benchmark grid is tens of GB, so the classic format (64-bit offsets) is laid
+# out here directly -- header per the NetCDF-3 specification, big-endian data, the data variable last
+# so that it may exceed 4 GB -- and mapped with numpy.memmap.
+_NC_BYTE, _NC_CHAR, _NC_INT, _NC_FLOAT, _NC_DOUBLE = 1, 2, 4, 5, 6
+_NC_DIMENSION, _NC_VARIABLE, _NC_ATTRIBUTE = 0x0A, 0x0B, 0x0C
+_NC_DT = {_NC_INT: ">i4", _NC_FLOAT: ">f4", _NC_DOUBLE: ">f8"}
+
+
+def _pad4(b):
+    return b + b"\0" * (-len(b) % 4)
+
+
+def _be32(v):
+    return int(v).to_bytes(4, "big")
+
+
+def _nc_name(s):
+    b = s.encode()
+    return _be32(len(b)) + _pad4(b)
+
+
+def _nc_atts(atts):
+    if not atts:
+        return _be32(0) + _be32(0)
+    out = _be32(_NC_ATTRIBUTE) + _be32(len(atts))
+    for k, v in atts.items():
+        if isinstance(v, (str, bytes)):
+            b = v.encode() if isinstance(v, str) else v
+            out += _nc_name(k) + _be32(_NC_CHAR) + _be32(len(b)) + _pad4(b)
+        else:
+            a = np.atleast_1d(np.asarray(v))
+            t = _NC_FLOAT if a.dtype == np.float32 else _NC_INT if a.dtype.kind in "iu" else _NC_DOUBLE
+            out += _nc_name(k) + _be32(t) + _be32(a.size) + _pad4(a.astype(_NC_DT[t]).tobytes())
+    return out
+
+
+def nc3_create(path, dims, variables, gatts=None):
+    """Lay out a NetCDF-3 file (64-bit offset variant, no record dimension).  dims: ordered
+    {name: length}; variables: list of (name, nc_type, dim names, attributes) in file order.  Every
+    variable but the last must stay below 4 GiB.  Returns {name: (offset, shape, big-endian dtype)};
+    the file has its final size, data all zero."""
+    dim_names = list(dims)
+    var_sizes = []
+    for name, t, vd, atts in variables:
+        n = int(np.prod([dims[d] for d in vd])) if vd else 1
+        var_sizes.append(n * np.dtype(_NC_DT[t]).itemsize)
+    if any(sz >= (1 << 32) - 4 for sz in var_sizes[:-1]):
+        raise ValueError("only the last variable of a classic NetCDF file may exceed 4 GiB")
+
+    def header(begins):
+        h = b"CDF\x02" + _be32(0)
+        h += _be32(_NC_DIMENSION) + _be32(len(dims))
+        for d in dim_names:
+            h += _nc_name(d) + _be32(dims[d])
+        h += _nc_atts(gatts or {})
+        h += _be32(_NC_VARIABLE) + _be32(len(variables))
+        for (name, t, vd, atts), sz, b in zip(variables, var_sizes, begins):
+            h += _nc_name(name) + _be32(len(vd)) + b"".join(_be32(dim_names.index(d)) for d in vd)
+            vsize = sz + (-sz % 4)
+            h += _nc_atts(atts) + _be32(t) + _be32(min(vsize, 0xFFFFFFFF)) + int(b).to_bytes(8, "big")
+        return h
+
+    hlen = len(header([0] * len(variables)))
+    begins, off = [], hlen
+    for sz in var_sizes:
+        begins.append(off)
+        off += sz + (-sz % 4)
+    with open(path, "wb") as f:
+        f.write(header(begins))
+        f.truncate(off)
+    return {name: (b, tuple(dims[d] for d in vd), np.dtype(_NC_DT[t]))
+            for (name, t, vd, atts), b in zip(variables, begins)}
+
+
+class BrickWriter:
+    """The result bricks of one splash.grid run, written row block by row block.  Same files, names,
+    variables and attributes as write_bricks(); `write(key, row0, block)` stores block [nl, nrows, ncol]
+    at grid rows row0..row0+nrows (NaN -> raster's FLT4S flag), close() flushes and unmaps."""
+
+    def __init__(self, outdir, keys, lon, lat, time_index, monthly_out):
+        z, zval, zunit, y0, y1 = output_time_axis(time_index, monthly_out)
+        lon, lat = np.asarray(lon, dtype=np.float64), np.asarray(lat, dtype=np.float64)
+        self.nl, self.shape = z.size, (lat.size, lon.size)
+        self.paths, self._maps = {}, {}
+        os.makedirs(outdir, exist_ok=True)
+        for key in keys:
+            if key not in BRICKS:
+                continue
+            tag, varname, unit, longname = BRICKS[key]
+            path = brick_path(outdir, key, monthly_out, y0, y1)
+            lay = nc3_create(
+                path, {"time": z.size, "lon": lon.size, "lat": lat.size},
+                [("lon", _NC_DOUBLE, ("lon",), {"units": "degrees_east", "long_name": "lon"}),
+                 ("lat", _NC_DOUBLE, ("lat",), {"units": "degrees_north", "long_name": "lat"}),
+                 ("time", _NC_INT, ("time",), {"units": zunit, "long_name": "time"}),
+                 (varname, _NC_FLOAT, ("time", "lat", "lon"),
+                  {"units": unit, "long_name": longname, "_FillValue": NA_FLT4S, "missing_value": NA_FLT4S})],
+                {"title": "SPLASH v2.0 " + longname})
+            for name, val in (("lon", lon), ("lat", lat), ("time", zval)):
+                o, shp, dt = lay[name]
+                m = np.memmap(path, dtype=dt, mode="r+", offset=o, shape=shp)
+                m[:] = val
+                m.flush()
+                del m
+            o, shp, dt = lay[varname]
+            self._maps[key] = np.memmap(path, dtype=dt, mode="r+", offset=o, shape=shp)
+            self.paths[key] = path
+
+    def write(self, key, row0, block):
+        m = self._maps.get(key)
+        if m is None:
+            return
+        b = np.asarray(block)
+        if b.ndim != 3 or b.shape[0] != self.nl or b.shape[2] != self.shape[1] or row0 + b.shape[1] > self.shape[0]:
+            raise ValueError(f"{key}: block {b.shape} at row {row0} does not fit a brick of {(self.nl,) + self.shape}")
+        m[:, row0:row0 + b.shape[1], :] = np.where(np.isnan(b), NA_FLT4S, b)
+
+    def close(self):
+        for m in self._maps.values():
+            m.flush()
+        self._maps = {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

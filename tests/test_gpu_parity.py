@@ -422,6 +422,83 @@ def test_splash_grid_writes_reference_named_bricks(api, oracle, tmp_path):
         assert np.allclose(f.variables["lat"][:], st["lat"].reshape(H, W)[:, 0])
 
 
+def test_splash_grid_end_to_end_from_a_dem_in_row_blocks(api, oracle, tmp_path):
+    """splash.grid with the reference's signature (rsplash_amd/grid.py, the twin of r/splash_hip.R): the
+    static rasters derived from the elevation raster alone (R/splash.grid.R:76-110), the grid cut into
+    row blocks, three of them in the library at a time (the receive loop of :359-400), the nine bricks
+    written block by block (:370-392) -- against ONE call over the whole grid with the same statics:
+    every series bit for bit, the files the float32 of it, the water-balance limbs equal (integer sums
+    over blocks).  NA cells in the DEM and the forcing; forcing read from a NetCDF file through a memory
+    map (big-endian float32, as raster's FLT4S files are)."""
+    from scipy.io import netcdf_file
+    from rsplash_amd import grid, io
+    H, W, nt = 23, 40, 730
+    d = _synth(oracle, H, W, nt, 1)
+    st = d["st"]
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:H, 0:W]
+    dem = 900 + 400 * np.sin(xx / 7.0) * np.cos(yy / 5.0) + 6.0 * yy + rng.uniform(0, 15, (H, W))
+    na = rng.random((H, W)) < 0.08
+    dem[na] = np.nan
+    geo = dict(ymax=46.5, xmin=7.0, yres=0.01, xres=0.01)
+    r3 = lambda a: a.reshape(nt, H, W).copy()
+    sw, tc, pn = (r3(d[k]).astype(np.float32) for k in ("sw", "tc", "pn"))
+    for a in (sw, tc, pn):
+        a[:, na] = np.nan
+    # the forcing goes through a NetCDF file and comes back as memory-mapped big-endian variables
+    fpath = str(tmp_path / "forcing.nc")
+    lay = io.nc3_create(fpath, {"time": nt, "lat": H, "lon": W},
+                        [(k, io._NC_FLOAT, ("time", "lat", "lon"), {}) for k in ("sw", "tc", "pn")])
+    for k, a in (("sw", sw), ("tc", tc), ("pn", pn)):
+        o, shp, dt = lay[k]
+        m = np.memmap(fpath, dtype=dt, mode="r+", offset=o, shape=shp)
+        m[:] = a
+        m.flush()
+        del m
+    f = netcdf_file(fpath, "r", mmap=True)
+    R = lambda v, z=None: grid.Raster(v, z=z, **geo)
+    elev = R(dem)
+    soil = R(st["soil"].reshape(6, H, W))
+    bricks = [R(f.variables[k], d["dates"]) for k in ("sw", "tc", "pn")]
+    basin = (xx // 14 + 3 * (yy // 12)).astype(np.int32)
+    statics = grid.grid_statics(elev)
+    assert statics["method"] == "top" and np.isnan(statics["lat"][na]).all()
+    assert np.isfinite(statics["slop"][~na]).all() and (statics["Au"][1][~na] >= 1).all()
+    kw = dict(sim_control=dict(monthly_out=True, inmem=True), statics=statics, want_diag=True, basin=basin)
+    seen = []
+    g = grid.splash_grid(*bricks, elev, soil, block_rows=4, inflight=3, progress=lambda i, n: seen.append((i, n)), **kw)
+    assert g["blocks"] == [(r, min(4, H - r)) for r in range(0, H, 4)] and seen[-1] == (6, 6)
+    one = api.splash_grid(sw, tc, pn, dem, soil.values, statics["lat"], statics["slop"], statics["asp"],
+                          statics["Au"], statics["resolution"], time_index=d["dates"],
+                          sim_control=dict(monthly_out=True), want_diag=True, basin=basin, n_basin=int(basin.max()) + 1)
+    ret = dict(wn="wn", ro="ro", pet="pet", aet="aet", snow="snow", bflow="bflow", cond="cond", netr="netrad", sm_lim="sm_lim")
+    for k, rk in ret.items():
+        assert g[rk].shape == (24, H, W)
+        assert np.array_equal(g[rk].view(np.int64), one[k].view(np.int64)), k
+        assert np.isnan(g[rk][:, na]).all() and np.isfinite(g[rk][:, ~na]).all(), k
+    assert np.array_equal(g["diag_acc"], one["diag_acc"])
+    assert np.array_equal(g["diag"]["aet"], one["diag"]["aet"])
+    # the same run to disk, daily, two blocks in flight, default block size (two blocks)
+    gd = grid.splash_grid(*bricks, elev, soil, outdir=str(tmp_path / "out"), tmpdir=str(tmp_path),
+                          sim_control=dict(monthly_out=False, inmem=False), statics=statics)
+    assert len(gd["blocks"]) == 2
+    oned = api.splash_grid(sw, tc, pn, dem, soil.values, statics["lat"], statics["slop"], statics["asp"],
+                           statics["Au"], statics["resolution"], time_index=d["dates"],
+                           sim_control=dict(monthly_out=False))
+    assert os.path.basename(gd["wn"]) == "SPLASH_v2.0_swc_daily_2001-2002.nc"
+    assert os.path.basename(gd["netrad"]) == "SPLASH_v2.0_netrad_daily_2001-2002.nc"
+    for k, rk in ret.items():
+        with netcdf_file(gd[rk], "r", mmap=False) as fo:
+            v = fo.variables[io.BRICKS[k][1]]
+            a = np.array(v[:])
+            assert a.shape == (nt, H, W) and a.dtype.itemsize == 4
+            want = np.where(np.isnan(oned[k]), io.NA_FLT4S, oned[k]).astype(np.float32)
+            assert np.array_equal(a, want), k
+            assert np.allclose(fo.variables["lat"][:], elev.lat()) and np.allclose(fo.variables["lon"][:], elev.lon())
+    del bricks
+    f.close()
+
+
 def test_splash_grid_na_cells_and_blocking(api, oracle):
     """NA cells (72 % of the reference's SA_cru example) come back NaN; results do not depend on
     how the grid is cut into launches"""
