@@ -7,6 +7,6 @@ set -e
 cd "$(dirname "$0")/.."
 cp rsplash_amd/librsplash_hip.so /tmp/librsplash_hip.product.so
 (cd rsplash_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function \
-    -DSPL_SITES -shared -o ../librsplash_hip.so splash_kernels.hip splash_capi.hip)
+    -DSPL_SITES -shared -o ../librsplash_hip.so splash_kernels.hip splash_statics.hip splash_capi.hip splash_grid_host.hip)
 python bench.py --rows 512 --steps 1 --warmup 0 --cpu-seconds 0 2>&1 >/dev/null | grep SITE | tail -40 || true
 cp /tmp/librsplash_hip.product.so rsplash_amd/librsplash_hip.so
