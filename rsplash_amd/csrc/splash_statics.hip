@@ -1,7 +1,7 @@
 // splash_statics.hip -- the kernels either side of the daily loop and the synthetic inputs:
 //   unSWC epilogue (f-4), terrain slope/aspect/latitude/resolution and ncellflow (f-2), sink fill, D8 flow
 //   accumulation and the multiple-flow-direction area (f-1), and the counter-based generator of the synthetic
-//   statics and forcing that bench.py and the parity tests share with the oracle.
+//   statics and forcing (bench.py and the parity tests generate the same values on the CPU).
 // The loop itself -- soil_hydro, snow threshold, spin-up, run_all, the module mirrors -- is splash_kernels.hip.
 #include <atomic>
 #include <cstdio>
