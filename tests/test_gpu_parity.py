@@ -467,7 +467,7 @@ def test_splash_grid_end_to_end_from_a_dem_in_row_blocks(api, oracle, tmp_path):
     # cells whose 3 x 3 window holds no flow code (an island inside NA cells) have no ncellin/ncellout
     # (R/upslope_area.R:140-165): NA statics make an NA cell, here as in the reference
     na = na | np.isnan(statics["Au"]).any(0)
-    assert (statics["Au"][1][~na] >= 1).all() and (~na).sum() > 0.8 * H * W
+    assert (statics["Au"][1][~na] >= 1).all() and (~na).sum() > 0.7 * H * W   # (the outer ring has no flow direction either)
     kw = dict(sim_control=dict(monthly_out=True, inmem=True), statics=statics, want_diag=True, basin=basin)
     seen = []
     g = grid.splash_grid(*bricks, elev, soil, block_rows=4, inflight=3, progress=lambda i, n: seen.append((i, n)), **kw)
