@@ -6,7 +6,7 @@ small size (page mapping per block, page-locked caller arrays, the library's own
 filled with a sentinel), monthly/daily outputs and basin maps, the
 results must equal the plain call BITWISE on
 every valid cell, NA cells must come back NaN, and the per-basin totals must be identical limbs.
-    python tools/fuzz_grid_run.py [n_cases=12]"""
+    python tools/fuzz_grid_run.py [n_cases=12] [rng_seed=20221130]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,7 +14,7 @@ import rsplash_amd.api as api
 from oracle.binding import Oracle
 o = Oracle()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-rng = np.random.default_rng(20221130)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20221130)
 bad = 0
 for case in range(n_cases):
     H, W = int(rng.integers(3, 20)), int(rng.integers(5, 90))

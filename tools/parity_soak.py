@@ -1,6 +1,6 @@
 """One-step and trajectory parity (oracle/parity.py) on many independent synthetic grids (GPU box):
 the rules the GPU tests apply to four fixed cases, over seeds they have not seen.
-    python tools/parity_soak.py [n_grids=12] [cells=8192] [days=730]"""
+    python tools/parity_soak.py [n_grids=12] [cells=8192] [days=730] [first_seed=911000]"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,10 +12,11 @@ from gpu_pipeline import device_pipeline
 ng = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 nt = int(sys.argv[3]) if len(sys.argv) > 3 else 730
+seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 911000
 o = Oracle()
 bad = 0
 for g in range(ng):
-    seed = 911000 + 104729 * g
+    seed = seed0 + 104729 * g
     p = device_pipeline(api, seed, n // 128, 128, 0, n, nt, 0 if g % 6 == 5 else 1)
     msg = []
     try:
