@@ -1123,6 +1123,64 @@ def test_minigrid_against_committed_golden(api, oracle, minigrid):
 
 
 # ---------------------------------------------------------------- error behaviour of the boundary
+def test_edge_shapes_all_na_one_cell_and_thirty_years_through_the_host_entry_point(api, oracle):
+    """Ragged and extreme shapes through splash_grid_run (what R binds): a grid of NA cells only (no
+    launch, NaN everywhere, no error), one valid cell among NA cells, one cell, a width that is no
+    multiple of the wavefront in several launches, and a 30-year series (10 957 days with the real
+    leap days: month bookkeeping, the year table, 32-bit products of nt and ncell) against the oracle."""
+    d = _synth(oracle, 3, 37, 400, 1)
+    st = d["st"]
+    n = 3 * 37
+    args = lambda sw, tc, pn, elev: (sw, tc, pn, elev, st["soil"], st["lat"], st["slop"], st["asp"], st["au"], st["resolution"])
+    kw = dict(time_index=d["dates"], sim_control=dict(monthly_out=False), want_diag=True)
+    # every cell NA
+    nan_f = np.full_like(d["sw"], np.nan)
+    g = api.splash_grid(*args(nan_f, nan_f, nan_f, np.full(n, np.nan)), **kw)
+    for k in api.OUT_NAMES:
+        assert g[k].shape == (400, n) and np.isnan(g[k]).all(), k
+    assert np.isnan(g["state_end"]).all() and (g["diag_cells"] == 0).all()
+    full = api.splash_grid(*args(d["sw"], d["tc"], d["pn"], st["elev"]), **kw)
+    # one valid cell among NA cells == that cell of the full grid, bit for bit
+    keep = 53
+    sw, tc, pn, elev = d["sw"].copy(), d["tc"].copy(), d["pn"].copy(), st["elev"].copy()
+    m = np.ones(n, bool)
+    m[keep] = False
+    for a in (sw, tc, pn):
+        a[:, m] = np.nan
+    elev[m] = np.nan
+    one = api.splash_grid(*args(sw, tc, pn, elev), **kw)
+    for k in api.OUT_NAMES:
+        assert np.isnan(one[k][:, m]).all() and np.array_equal(one[k][:, keep], full[k][:, keep]), k
+    assert (one["diag_cells"] == 1).all()
+    # ncell = 1 as a grid, and as a point: the same numbers
+    c1 = api.splash_grid(d["sw"][:, keep:keep + 1], d["tc"][:, keep:keep + 1], d["pn"][:, keep:keep + 1],
+                         st["elev"][keep:keep + 1], st["soil"][:, keep:keep + 1], st["lat"][keep:keep + 1],
+                         st["slop"][keep:keep + 1], st["asp"][keep:keep + 1], st["au"][:, keep:keep + 1],
+                         st["resolution"][keep:keep + 1], **kw)
+    for k in api.OUT_NAMES:
+        assert np.array_equal(c1[k][:, 0], full[k][:, keep]), k
+    # 111 cells in launches of 40: the last one ragged
+    blk = api.splash_grid(*args(d["sw"], d["tc"], d["pn"], st["elev"]), max_cells_per_launch=40, **kw)
+    for k in api.OUT_NAMES:
+        assert np.array_equal(blk[k], full[k]), k
+    assert np.array_equal(blk["diag_acc"], full["diag_acc"])
+    # thirty years, monthly and daily
+    H, W, nt = 2, 24, 10957
+    d = _synth(oracle, H, W, nt, 1, seed=606)
+    st = d["st"]
+    assert str(d["dates"][-1]) == "2030-12-31" and d["nm"] == 360
+    for monthly in (True, False):
+        g = api.splash_grid(d["sw"], d["tc"], d["pn"], st["elev"], st["soil"], st["lat"], st["slop"], st["asp"],
+                            st["au"], st["resolution"], time_index=d["dates"], sim_control=dict(monthly_out=monthly))
+        o, aux = oracle.grid(d["doy"], d["year"], d["month"], d["mid"], d["nm"], d["sw"], d["tc"], d["pn"], st["lat"],
+                             st["elev"], st["slop"], st["asp"], st["soil"], st["au"], st["resolution"], monthly_out=monthly)
+        assert g["wn"].shape == ((360 if monthly else nt), H * W)
+        r = assert_whole_pipeline(oracle, g, o, aux, st, d["doy"], d["year"], f"30 years[{monthly}]",
+                                  monthly_mid=d["mid"] if monthly else None)
+        r.pop("ok")
+        print(r)
+
+
 def test_boundary_rejects_bad_arguments(api, oracle, bourne):
     """errors are codes + messages (never a crash, never a silent NaN grid): too-short series
     (R/splash.point.R:141-144 needs 365 days), malformed Au, mismatched time axis, bad leading
