@@ -1437,6 +1437,9 @@ def test_read_back_never_addresses_a_slot_beyond_the_cache():
     import subprocess, sys, tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     chk = os.path.join(root, "rsplash_amd", "librsplash_hip_check.so")
+    if not os.path.exists(chk):
+        import rsplash_amd
+        rsplash_amd.build_library()     # `make all` builds the product and the checking library
     assert os.path.exists(chk), "librsplash_hip_check.so is built by rsplash_amd.build_library() (make all)"
     code = r'''
 import sys, ctypes as C, numpy as np, torch
