@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPLASH_ABI_VERSION 4
+#define SPLASH_ABI_VERSION 5
 
 enum {
     SPLASH_OK = 0,
@@ -312,6 +312,25 @@ typedef struct {
     /* optional single-precision transport of the forcing (the reference's rasters are FLT4S:
      * widening is lossless; arithmetic stays FP64).  When sw_in is NULL these are used instead. */
     const float *sw_in_f32, *tc_f32, *pn_f32; /* [nt][ncell] */
+    /* (ABI 5) A long series in time chunks: continuing a run instead of starting one.  The module's
+     * run_all takes the state to start from (wn_last, snow_last, qin_last, td_last, nds_last,
+     * src/SPLASH.h:93-97); splash.point always hands it the end of its own spin-up
+     * (R/splash.point.R:158-172).  A caller whose series does not fit host memory in one piece runs
+     * the first chunk as usual (spin-up on its first 365 days) and every later chunk with
+     *   state0 [5][ncell] = splash_grid_out.state_end of the chunk before (wn, snow, qin, td, nd),
+     *   ai0    [ncell]    = the aridity index of the run's spin-up (splash_grid_out.aux row 1 of the
+     *                       first chunk; it is soil_info[12] of every run_all call, :150),
+     *   tt     [ncell]    = the snowfall threshold (below);
+     * such a call runs no spin-up (nt may be any length >= 1) and starts run_all from state0.  Chunks
+     * that begin on the first day of a month give the monthly outputs of the undivided call.
+     * tt: the snowfall threshold Tt = max(tc[p_snow >= 0.5]) is a property of the WHOLE series
+     * (R/splash.point.R:120-122).  When tt is given (with or without state0) it is used instead of the
+     * threshold of this call's tc: the maximum over the chunks' thresholds (splash_snow_threshold_run on
+     * each chunk; NaN if any is NaN) is the threshold of the whole series, and with it the chunked run
+     * equals the undivided one bit for bit.  state0 and ai0 come together and need tt. */
+    const double* tt;
+    const double* state0;
+    const double* ai0;
 } splash_grid_in;
 
 typedef struct {
@@ -364,6 +383,12 @@ int splash_grid_run(const splash_grid_in* in, const splash_opts* opt, const spla
  * on the same device share its memory: give each a splash_opts.mem_fraction.  Inside ONE call the
  * blocks are pipelined already (transfers of neighbouring blocks overlap the kernels, and the
  * spin-up's long tail runs once per call): a caller that can hand over a large block should. */
+/* (ABI 5) K2 on host buffers: Tt [ncell] of the tc series given (exactly one of tc / tc_f32, [nt][ncell]);
+ * -Inf where no day qualifies, NaN where tc has a gap (R's max() with NA).  The threshold of a series
+ * processed in time chunks is the maximum of the chunks' thresholds (NaN if any is NaN). */
+int splash_snow_threshold_run(size_t ncell, int nt, const double* tc, const float* tc_f32,
+                              const double* lat, const double* elev, double* tt, char* err, size_t errlen);
+
 typedef struct splash_grid_job splash_grid_job;
 int splash_grid_submit(const splash_grid_in* in, const splash_opts* opt, const splash_grid_out* out,
                        splash_grid_job** job, char* err, size_t errlen);

@@ -22,7 +22,8 @@ class GridIn(C.Structure):
                 ("sw_in", _dp), ("tc", _dp), ("pn", _dp), ("lat", _dp), ("elev", _dp),
                 ("slop", _dp), ("asp", _dp), ("resolution", _dp), ("soil", _dp), ("au", _dp),
                 ("basin", _ip), ("n_basin", C.c_int),
-                ("sw_in_f32", _fp), ("tc_f32", _fp), ("pn_f32", _fp)]
+                ("sw_in_f32", _fp), ("tc_f32", _fp), ("pn_f32", _fp),
+                ("tt", _dp), ("state0", _dp), ("ai0", _dp)]          # ABI 5
 
 
 class Opts(C.Structure):
@@ -118,6 +119,7 @@ def _load():
     L.splash_unswc_run.argtypes = [C.c_size_t, C.c_int, _dp, _dp, C.c_double, _dp, _dp, _dp,
                                    C.c_char_p, C.c_size_t]
     L.splash_dev_math_probe.argtypes = [C.c_size_t, _dp, _dp, _dp]
+    L.splash_snow_threshold_run.argtypes = [C.c_size_t, C.c_int, _dp, _fp, _dp, _dp, _dp, C.c_char_p, C.c_size_t]
     L.splash_grid_submit.argtypes = [C.POINTER(GridIn), C.POINTER(Opts), C.POINTER(GridOut),
                                      C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
     L.splash_grid_wait.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
@@ -154,7 +156,7 @@ SYMBOLS = (
     "splash_dev_sinkfill", "splash_dev_flow_accumulation", "splash_dev_mfd_area", "splash_static_rasters_run",
     "splash_dev_run_all", "splash_dev_synth_statics", "splash_dev_synth_forcing",
     "splash_dev_evap_batch", "splash_dev_math_probe", "splash_dev_unswc", "splash_unswc_run",
-    "splash_grid_run", "splash_grid_submit", "splash_grid_wait", "splash_point_run", "splash_mod_spin_up",
+    "splash_snow_threshold_run", "splash_grid_run", "splash_grid_submit", "splash_grid_wait", "splash_point_run", "splash_mod_spin_up",
     "splash_mod_run_all", "splash_mod_run_one_year", "splash_mod_moist_surf", "splash_mod_inf_GA",
 )
 

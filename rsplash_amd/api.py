@@ -113,7 +113,7 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
                 time_index=None, sim_control=None, outputs=OUT_NAMES, device=0,
                 max_cells_per_launch=0, want_aux=False, want_diag=False, outdir=None, lon=None,
                 basin=None, n_basin=0, devices=None, out=None, want_state=True, submit=False,
-                mem_fraction=0.0, out_dtype=np.float64):
+                mem_fraction=0.0, out_dtype=np.float64, tt=None, state0=None, ai0=None):
     """R/splash.grid.R:28 on arrays.  sw_in/tc/pn: [nt, ncell] (or [nt, H, W]) daily rasters;
     elev/lat/slop/asp: [ncell]; soil: [6, ncell]; Au: [3, ncell] (area, ncellin, ncellout) or
     None.  The static rasters the reference derives with raster/GDAL/TauDEM (lat, slope, aspect,
@@ -134,6 +134,10 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     out_dtype=np.float32 (or a dict name -> dtype): single-precision transport of the results (splash_grid_out.out_f32): every
     value is rounded to the nearest float on the device -- what the reference's FLT4S bricks hold,
     R/splash.grid.R:186-216 -- which halves the device->host bytes; the arithmetic is FP64 either way.
+    tt, state0, ai0 (ABI 5): a long series in time chunks.  tt [ncell]: the snowfall threshold of the WHOLE
+    series (the maximum of snow_threshold() over the chunks), used instead of this call's own; state0
+    [5, ncell] = "state_end" of the chunk before and ai0 [ncell] = aux["AI"] of the first chunk: the call
+    continues that run -- no spin-up, any number of days -- and equals the undivided call bit for bit.
     submit=True: splash_grid_submit -- the call runs on its own host thread and streams; a GridJob
     comes back at once and its wait() returns what this function would have (a host loop over row
     blocks keeps two or more in flight, each with its mem_fraction of the device's free memory)."""
@@ -170,6 +174,10 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
                       au[1] if au else None)
     if f32:
         gin.sw_in_f32, gin.tc_f32, gin.pn_f32 = f[0][1], f[1][1], f[2][1]
+    cont = None
+    if tt is not None or state0 is not None or ai0 is not None:
+        cont = [None if x is None else flat(x, lead) for x, lead in ((tt, ()), (state0, (NSTATE,)), (ai0, ()))]
+        gin.tt, gin.state0, gin.ai0 = (None if c is None else c[1] for c in cont)
     nbas = 1
     bas = None
     if basin is not None:
@@ -222,7 +230,7 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
         rc = lib.splash_grid_submit(C.byref(gin), C.byref(opt), C.byref(gout), C.byref(job), err, 512)
         if rc:
             raise SplashError(f"splash_grid_submit failed ({rc}): {err.value.decode()}")
-        keep = (f, st, so, au, ia, gin, opt, gout, dv, res, state_end, aux, diag, bas, acc)
+        keep = (f, st, so, au, ia, gin, opt, gout, dv, res, state_end, aux, diag, bas, acc, cont)
         return GridJob(job, keep, lambda: _grid_results(res, shp, lat, lon, outdir, time_index, monthly, want_state,
                                                          state_end, want_aux, aux, want_diag, diag, acc, basin))
     rc = lib.splash_grid_run(C.byref(gin), C.byref(opt), C.byref(gout), err, 512)
@@ -230,6 +238,26 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
         raise SplashError(f"splash_grid_run failed ({rc}): {err.value.decode()}")
     return _grid_results(res, shp, lat, lon, outdir, time_index, monthly, want_state, state_end, want_aux, aux,
                          want_diag, diag, acc, basin)
+
+
+def snow_threshold(tc, lat, elev):
+    """K2 on host arrays (splash_snow_threshold_run): Tt [ncell] = max(tc[p_snow >= 0.5]) of the series
+    tc [nt, ...] (R/splash.point.R:120-122); -inf where no day qualifies, NaN where tc has a gap.  The
+    threshold of a series processed in time chunks is np.maximum over the chunks' thresholds."""
+    f32 = getattr(tc, "dtype", None) == np.float32
+    a = np.ascontiguousarray(np.asarray(tc, dtype=np.float32 if f32 else np.float64))
+    nt, shp = a.shape[0], a.shape[1:]
+    n = int(np.prod(shp))
+    la, ll = _d(np.broadcast_to(np.asarray(lat, dtype=np.float64), shp).reshape(n))
+    ea, el = _d(np.broadcast_to(np.asarray(elev, dtype=np.float64), shp).reshape(n))
+    out = np.empty(n)
+    err = C.create_string_buffer(256)
+    rc = lib.splash_snow_threshold_run(n, nt, None if f32 else a.ctypes.data_as(_dp),
+                                       a.ctypes.data_as(C.POINTER(C.c_float)) if f32 else None, ll, el,
+                                       out.ctypes.data_as(_dp), err, 256)
+    if rc:
+        raise SplashError(f"splash_snow_threshold_run failed ({rc}): {err.value.decode()}")
+    return out.reshape(shp)
 
 
 class GridJob:

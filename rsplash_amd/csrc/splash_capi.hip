@@ -1120,6 +1120,45 @@ extern "C" int splash_unswc_run(size_t ncell, int nt, const double* wn, const do
     return SPLASH_OK;
 }
 
+// K2 on host buffers (ABI 5): the snowfall threshold of a tc series, for callers that process a long
+// series in time chunks -- the threshold of the whole series is the maximum of the chunks' (R/splash.point.R:120-122).
+extern "C" int splash_snow_threshold_run(size_t ncell, int nt, const double* tc, const float* tc_f32,
+                                         const double* lat, const double* elev, double* tt, char* err, size_t errlen)
+{
+    if (!lat || !elev || !tt || ((tc != nullptr) == (tc_f32 != nullptr)) || nt < 1)
+        return fail(SPLASH_EINVAL, err, errlen,
+                    "snow_threshold_run: NULL argument, nt < 1, or not exactly one of tc / tc_f32");
+    if (int rc = enter_device(err, errlen)) return rc;
+    if (ncell == 0) return SPLASH_OK;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b), err, errlen);
+    free_b += pool_idle_bytes(0);
+    const size_t per_cell = (size_t)nt * (tc ? 8 : 12) + 3 * 8;
+    size_t nb = std::min<size_t>(ncell, std::max<size_t>(256, (size_t)((double)free_b * 0.5 / (double)per_cell)));
+    nb = std::min(nb, kMaxCellsPerLaunch);
+    DevBuf d_tc, d_f32, d_par, d_tt;
+    HIP_TRY(d_tc.alloc((size_t)nt * nb * 8), err, errlen);
+    if (tc_f32) HIP_TRY(d_f32.alloc((size_t)nt * nb * 4), err, errlen);
+    HIP_TRY(d_par.alloc(2 * nb * 8), err, errlen); // rows P_LAT, P_ELV: all the kernel reads
+    HIP_TRY(d_tt.alloc(nb * 8), err, errlen);
+    static_assert(P_LAT == 0 && P_ELV == 1, "snow_threshold_run hands the kernel a two-row parameter block");
+    for (size_t c0 = 0; c0 < ncell; c0 += nb) {
+        const size_t n = std::min(nb, ncell - c0);
+        if (tc) {
+            HIP_TRY(hipMemcpy2D(d_tc.p, n * 8, tc + c0, ncell * 8, n * 8, (size_t)nt, hipMemcpyHostToDevice), err, errlen);
+        } else {
+            HIP_TRY(hipMemcpy2D(d_f32.p, n * 4, tc_f32 + c0, ncell * 4, n * 4, (size_t)nt, hipMemcpyHostToDevice), err, errlen);
+            HIP_TRY(launch_widen_f32(d_f32.as<float>(), (size_t)nt * n, d_tc.as<double>(), nullptr), err, errlen);
+        }
+        HIP_TRY(hipMemcpy(d_par.as<double>(), lat + c0, n * 8, hipMemcpyHostToDevice), err, errlen);
+        HIP_TRY(hipMemcpy(d_par.as<double>() + n, elev + c0, n * 8, hipMemcpyHostToDevice), err, errlen);
+        HIP_TRY(launch_snow_threshold(n, nt, d_tc.as<double>(), n, d_par.as<double>(), n, d_tt.as<double>(), nullptr),
+                err, errlen);
+        HIP_TRY(hipMemcpy(tt + c0, d_tt.p, n * 8, hipMemcpyDeviceToHost), err, errlen);
+    }
+    return SPLASH_OK;
+}
+
 // static rasters on host buffers: R/splash.grid.R:96-110 + upslope_area() (R/upslope_area.R:12-58)
 extern "C" int splash_static_rasters_run(int H, int W, const double* elev, double ymax, double yres,
                                          double xres, int na_to_zero, double degree,

@@ -111,6 +111,7 @@ struct GridPlan {
     size_t max_cells;
     bool want_diag;
     double mem_fraction; // share of the device's free memory one worker may plan with
+    bool resume;         // (ABI 5) in->state0: no spin-up, run_all starts from the caller's state
 };
 
 inline void put_value(const GridPlan& P, int k, size_t at, double v)
@@ -407,11 +408,28 @@ int Worker::run_block(Lane& L, size_t k)
     double* Tt = L.d_tt.as<double>();
     LANE_RC(splash_dev_soil_hydro(nb, S, S + nb, S + 2 * nb, S + 3 * nb, S + 4 * nb, S + 5 * nb,
                                   in->au ? S + 11 * nb : nullptr, par, s));
-    LANE_RC(splash_dev_snow_threshold(nb, nt, dtc, nb, par, nb, Tt, s));
+    if (in->tt) { // the threshold of the WHOLE series, from the caller (time chunks: include/splash_hip.h)
+        for (size_t j = 0; j < nb; j++) L.hsmall[j] = in->tt[idx[j]];
+        LANE_TRY(hipMemcpyAsync(Tt, L.hsmall.data(), nb * 8, hipMemcpyHostToDevice, s)); // (pageable: returns when
+    } else {                                                                              //  the source may be reused)
+        LANE_RC(splash_dev_snow_threshold(nb, nt, dtc, nb, par, nb, Tt, s));
+    }
     int* dpass = out->aux ? L.d_pass.as<int>() : nullptr;
-    LANE_RC(splash_dev_spin_up_begin(cal, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, dpass, L.d_swork.p, s));
     const unsigned char* d_mask = nullptr;
     const uint32_t *d_cells = nullptr, *d_ncells = nullptr;
+    if (P.resume) {
+        // continuing a run: the caller's state and the aridity index of the run's spin-up stand where the
+        // spin-up's results would (cellout := AI, R/splash.point.R:150); nothing is left for the pool
+        for (int kk = 0; kk < 5; kk++)
+            for (size_t j = 0; j < nb; j++) L.hsmall[(size_t)kk * nb + j] = in->state0[(size_t)kk * N + idx[j]];
+        LANE_TRY(hipMemcpyAsync(state, L.hsmall.data(), 5 * nb * 8, hipMemcpyHostToDevice, s));
+        for (size_t j = 0; j < nb; j++) L.hsmall[j] = in->ai0[idx[j]];
+        LANE_TRY(hipMemcpyAsync(par + (size_t)P_CELLOUT * nb, L.hsmall.data(), nb * 8, hipMemcpyHostToDevice, s));
+        LANE_TRY(hipMemsetAsync(L.d_res.p, 0, 64, s));
+        if (dpass) LANE_TRY(hipMemsetAsync(dpass, 0, 2 * nb * sizeof(int), s));
+        LANE_TRY(hipEventRecord(L.ev_gather.e, s));
+    } else {
+    LANE_RC(splash_dev_spin_up_begin(cal, nb, dsw, dtc, dpn, nb, Tt, par, nb, state, nb, dpass, L.d_swork.p, s));
     (void)splash_dev_spin_up_pending(L.d_swork.p, nb, &d_mask, &d_cells, &d_ncells);
     {   // the block's stragglers move to the pool
         size_t o_wl_b, o_meta, o_ai, o_cnt, p_wl_b, p_meta, p_ai, p_cnt;
@@ -451,6 +469,7 @@ int Worker::run_block(Lane& L, size_t k)
         g.res = L.d_res.as<uint32_t>();
         LANE_TRY(launch_pool_gather(g, s));
         LANE_TRY(hipEventRecord(L.ev_gather.e, s));
+    }
     }
     note(blocks_gathered, false); // the worker's thread starts the tail once every block is here
     // the previous block's results must have left d_out before run_all writes it again
@@ -790,6 +809,8 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
         pcap = std::min(pcap, (want + 255) & ~(size_t)255);
         pcap = (pcap + 255) & ~(size_t)255;
         if (kn.pool_cap) pcap = kn.pool_cap; // tests: force the overflow path
+        const bool spin = !P.resume; // a continued run has no spin-up: no workspace, a token pool
+        if (!spin) pcap = 256;
         const size_t pool_per_slot = (size_t)nt * 3 * 8 + (size_t)nt_out * std::max(n_out, 1) * 8 +
                                      (SPLASH_NPAR + SPLASH_NSTATE + 1) * 8 + 8 + 2 * 4 + 4;
         const double pool_bytes = (double)pcap * (double)pool_per_slot + (double)splash_dev_spin_up_work_size(pcap);
@@ -808,8 +829,10 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
         if (P.max_cells) nb_max = std::min(nb_max, P.max_cells);
         auto lanes_for = [&](size_t nb) { return (int)std::min<size_t>((size_t)n_lanes, (want + nb - 1) / nb); };
         auto need = [&](size_t nb) {
-            return (double)lanes_for(nb) * ((double)nb * (double)per_cell + (double)splash_dev_spin_up_work_size(nb) +
-                                            (double)Worker::late_slots(nb) * nt_out * std::max(n_out, 1) * 8);
+            return (double)lanes_for(nb) * ((double)nb * (double)per_cell +
+                                            (spin ? (double)splash_dev_spin_up_work_size(nb) +
+                                                        (double)Worker::late_slots(nb) * nt_out * std::max(n_out, 1) * 8
+                                                  : 0.0));
         };
         if (need(nb_max) > budget) { // largest block that fits (bisection; need() grows with nb once the
             size_t lo = 0, hi = nb_max;  // lane count has reached its cap, which it has wherever it matters)
@@ -849,11 +872,11 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
             HIP_TRY(L.d_stat.alloc((size_t)14 * nb_max * 8), err, errlen);
             HIP_TRY(L.d_tt.alloc(nb_max * 8), err, errlen);
             HIP_TRY(L.d_pass.alloc(2 * nb_max * sizeof(int)), err, errlen);
-            HIP_TRY(L.d_swork.alloc(splash_dev_spin_up_work_size(nb_max)), err, errlen);
+            HIP_TRY(L.d_swork.alloc(spin ? splash_dev_spin_up_work_size(nb_max) : 64), err, errlen);
             HIP_TRY(L.d_res.alloc(64), err, errlen);
             if (P.want_diag && in->basin) HIP_TRY(L.d_basin.alloc(nb_max * sizeof(int32_t)), err, errlen);
             L.hstat.resize((size_t)14 * nb_max);
-            if (P.out->state_end || P.out->aux) L.hsmall.resize(5 * nb_max);
+            if (P.out->state_end || P.out->aux || in->tt || P.resume) L.hsmall.resize(5 * nb_max);
             if (P.out->aux) L.hpass.resize(2 * nb_max);
             if (in->basin && P.want_diag) L.hbasin.resize(nb_max);
             if (!P.dense) {
@@ -912,7 +935,10 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
         return fail(SPLASH_EINVAL, err, errlen,
                     "grid_run: NULL input array (forcing: all three series as double, or all "
                     "three as float with the double pointers NULL)");
-    if (in->nt < 365)
+    if ((in->state0 != nullptr) != (in->ai0 != nullptr) || (in->state0 && !in->tt))
+        return fail(SPLASH_EINVAL, err, errlen,
+                    "grid_run: continuing a run needs state0, ai0 and tt together (include/splash_hip.h, ABI 5)");
+    if (in->state0 ? in->nt < 1 : in->nt < 365)
         return fail(SPLASH_EINVAL, err, errlen,
                     "grid_run: %d days given, the spin-up needs the first 365 "
                     "(R/splash.point.R:141-144)", in->nt);
@@ -943,6 +969,7 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
     P.N = in->ncell;
     P.nt = in->nt;
     P.monthly = opt ? opt->monthly_out : 0;
+    P.resume = in->state0 != nullptr;
     P.max_cells = opt ? opt->max_cells_per_launch : 0;
     P.mem_fraction = (opt && opt->mem_fraction > 0 && opt->mem_fraction <= 1) ? opt->mem_fraction : 0.0;
     P.n_basin = in->basin ? in->n_basin : 1;
@@ -985,6 +1012,9 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
             if (in->au)
                 for (int k = 0; k < 3 && !bad; k++)
                     if (isnan_d(in->au[(size_t)k * N + c])) bad = true;
+            // a continued run: a cell that was NA in the chunk before (NaN column water) stays NA
+            // (td alone may be NaN in a valid cell: the sticky drainage time of flat terrain)
+            if (in->state0 && isnan_d(in->state0[c])) bad = true;
             return bad;
         };
         // a few threads over contiguous ranges, lists concatenated in order (16.7 M cells: 0.12 s on one)

@@ -63,10 +63,10 @@ class Raster:
     def lon(self):
         return self.xmin + self.xres * (np.arange(self.ncol) + 0.5)
 
-    def rows(self, r0, r1):
-        """getValues(x, row, nrows): rows [r0, r1) as a C-contiguous float array"""
+    def rows(self, r0, r1, t0=None, t1=None):
+        """getValues(x, row, nrows): rows [r0, r1) (of layers [t0, t1)) as a C-contiguous float array"""
         v = self.values
-        a = v[r0:r1] if np.ndim(v) == 2 else v[:, r0:r1]
+        a = v[r0:r1] if np.ndim(v) == 2 else v[t0:t1, r0:r1]
         a = np.asarray(a)
         if a.dtype not in (np.float32, np.float64) or not a.dtype.isnative:
             a = a.astype(np.float32 if a.dtype.itemsize == 4 and a.dtype.kind == "f" else np.float64)
@@ -116,9 +116,19 @@ def grid_statics(elev, degree=1.0, method=None):
                 Au=np.stack([s[area_key], s["ncellin"], s["ncellout"]]), method=method)
 
 
+def year_chunks(ztime, chunk_years):
+    """[(t0, t1)] covering the series once, each chunk `chunk_years` whole calendar years (the last one
+    what is left): a chunk starts on a 1 January, so the monthly outputs of the chunks are the months of
+    the undivided run"""
+    y = np.asarray(ztime, dtype="datetime64[Y]").astype(int)
+    starts = np.flatnonzero(np.r_[True, y[1:] != y[:-1]])
+    cuts = list(starts[::max(1, int(chunk_years))]) + [len(y)]
+    return [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:])]
+
+
 def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control=None, *,
                 devices=None, inflight=2, block_rows=None, statics=None, out_dtype=np.float64,
-                want_diag=False, basin=None, n_basin=0, progress=None):
+                want_diag=False, basin=None, n_basin=0, progress=None, chunk_years=None):
     """R/splash.grid.R:28.  sw_in, tc, pn: Raster bricks [nl, H, W] with layer dates (`z`, taken from
     pn like getZ(pn), :144); elev: Raster [H, W]; soil: Raster [6, H, W] (sand, clay, OM, gravel, bulk
     density, depth).  sim_control = dict(monthly_out=True, inmem=False) as the reference's default.
@@ -129,7 +139,13 @@ def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control
     `tmpdir` is accepted for the signature's sake (the reference parks intermediate rasters there; nothing
     is parked here).  devices: HIP ordinals every block is split over inside the library; inflight:
     blocks in the library at a time; block_rows: rows per block (default: ~2 GB of forcing per block, at
-    least two blocks)."""
+    least two blocks).
+    chunk_years: process the series in time chunks of that many calendar years (a 30-year series of a
+    large grid does not fit host memory even one row block at a time): per row block a pre-pass takes the
+    snowfall threshold of the whole series (the maximum of the chunks'), the first chunk runs with the
+    spin-up, every later one continues from the state the one before ended in (splash_grid_in.state0 /
+    ai0 / tt, ABI 5) while the results of the one before are being written -- bit for bit the undivided
+    run."""
     ctl = dict(monthly_out=True, inmem=False)
     ctl.update(sim_control or {})
     monthly, inmem = bool(ctl["monthly_out"]), bool(ctl["inmem"])
@@ -174,6 +190,66 @@ def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control
             mem_fraction=0.8 / inflight, want_state=False, out_dtype=out_dtype, want_diag=want_diag,
             basin=None if basin is None else cut(np.asarray(basin).reshape(H, W)), n_basin=n_basin)
 
+    def store(res, r0, nr, t0_out, m0):
+        nonlocal acc_total
+        for k in keys:
+            if inmem:
+                mats[k][t0_out:t0_out + res[k].shape[0], r0:r0 + nr, :] = res[k]
+            else:
+                writer.write(k, r0, res[k], t0_out)
+        if want_diag:
+            a = res["diag_acc"]
+            if acc_total is None:
+                acc_total = np.zeros((a.shape[0], nm_total, a.shape[2]), np.int64)
+            acc_total[:, m0:m0 + a.shape[1]] += a
+
+    nm_total = int(api.month_ids(*api.time_fields(ztime)[1:])[-1]) + 1
+    if chunk_years:
+        # time chunks: per row block, threshold pre-pass, then the chunks in order, each continuing the one before
+        tcs = year_chunks(ztime, chunk_years)
+        mid_all = api.month_ids(*api.time_fields(ztime)[1:])
+        jobs = []
+        try:
+            for i, (r0, nr) in enumerate(bs):
+                r1 = r0 + nr
+                cut = lambda a: np.ascontiguousarray(np.asarray(a)[..., r0:r1, :])
+                st_b = {k: cut(st[k]) for k in ("lat", "slop", "asp", "Au", "resolution")}
+                ev, so = elev.rows(r0, r1), soil.rows(r0, r1)
+                tt = None
+                for t0, t1 in tcs:   # Tt = max(tc[p_snow >= 0.5]) over the WHOLE series (R/splash.point.R:120-122)
+                    tk = api.snow_threshold(tc.rows(r0, r1, t0, t1), st_b["lat"], ev)
+                    tt = tk if tt is None else np.maximum(tt, tk)
+                bas = None if basin is None else cut(np.asarray(basin).reshape(H, W))
+                state = ai = None
+                prev = None   # (job, t0_out, m0) of the chunk in the library
+                for t0, t1 in tcs:
+                    if prev is not None:   # the chunk before must have ended: its state starts this one
+                        res_p = prev[0].wait()
+                        jobs.remove(prev[0])
+                        state = res_p["state_end"]
+                        ai = res_p["aux"]["AI"] if ai is None else ai
+                    job = api.splash_grid(
+                        sw_in.rows(r0, r1, t0, t1), tc.rows(r0, r1, t0, t1), pn.rows(r0, r1, t0, t1), ev, so,
+                        st_b["lat"], st_b["slop"], st_b["asp"], st_b["Au"], st_b["resolution"],
+                        time_index=ztime[t0:t1], sim_control=dict(monthly_out=monthly), devices=devices, submit=True,
+                        mem_fraction=0.8, want_state=True, want_aux=True, out_dtype=out_dtype, want_diag=want_diag,
+                        basin=bas, n_basin=n_basin, tt=tt, state0=state, ai0=ai)
+                    jobs.append(job)
+                    if prev is not None:   # written while this chunk computes
+                        store(res_p, r0, nr, prev[1], prev[2])
+                    prev = (job, int(mid_all[t0]) if monthly else t0, int(mid_all[t0]))
+                res_p = prev[0].wait()
+                jobs.remove(prev[0])
+                store(res_p, r0, nr, prev[1], prev[2])
+                if progress:
+                    progress(i + 1, len(bs))
+        finally:
+            for j in jobs:
+                j.close()
+            if writer:
+                writer.close()
+        return _returned(inmem, mats, writer, st, bs, want_diag, acc_total, basin)
+
     # the receive loop of R/splash.grid.R:359-400: collect block i, hand the free slot block i + inflight,
     # write block i while the others compute
     jobs = [None] * len(bs)
@@ -185,13 +261,7 @@ def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control
             jobs[i] = None
             if i + inflight < len(bs):
                 jobs[i + inflight] = submit(i + inflight)
-            for k in keys:
-                if inmem:
-                    mats[k][:, r0:r0 + nr, :] = res[k]
-                else:
-                    writer.write(k, r0, res[k])
-            if want_diag:
-                acc_total = res["diag_acc"].copy() if acc_total is None else acc_total + res["diag_acc"]
+            store(res, r0, nr, 0, 0)
             if progress:
                 progress(i + 1, len(bs))
     finally:
@@ -200,6 +270,10 @@ def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control
                 j.close()
         if writer:
             writer.close()
+    return _returned(inmem, mats, writer, st, bs, want_diag, acc_total, basin)
+
+
+def _returned(inmem, mats, writer, st, bs, want_diag, acc_total, basin):
     ret_names = dict(wn="wn", ro="ro", pet="pet", aet="aet", snow="snow", bflow="bflow", cond="cond",
                      netr="netrad", sm_lim="sm_lim")     # R/splash.grid.R:449
     src = mats if inmem else writer.paths

@@ -199,14 +199,16 @@ class BrickWriter:
             self._maps[key] = np.memmap(path, dtype=dt, mode="r+", offset=o, shape=shp)
             self.paths[key] = path
 
-    def write(self, key, row0, block):
+    def write(self, key, row0, block, t0=0):
+        """block [nl_b, nrows, ncol] -> layers t0..t0+nl_b, rows row0..row0+nrows (t0 > 0: a later time
+        chunk of a series processed in chunks)"""
         m = self._maps.get(key)
         if m is None:
             return
         b = np.asarray(block)
-        if b.ndim != 3 or b.shape[0] != self.nl or b.shape[2] != self.shape[1] or row0 + b.shape[1] > self.shape[0]:
-            raise ValueError(f"{key}: block {b.shape} at row {row0} does not fit a brick of {(self.nl,) + self.shape}")
-        m[:, row0:row0 + b.shape[1], :] = np.where(np.isnan(b), NA_FLT4S, b)
+        if (b.ndim != 3 or t0 < 0 or t0 + b.shape[0] > self.nl or b.shape[2] != self.shape[1] or row0 + b.shape[1] > self.shape[0]):
+            raise ValueError(f"{key}: block {b.shape} at layer {t0}, row {row0} does not fit a brick of {(self.nl,) + self.shape}")
+        m[t0:t0 + b.shape[0], row0:row0 + b.shape[1], :] = np.where(np.isnan(b), NA_FLT4S, b)
 
     def close(self):
         for m in self._maps.values():

@@ -506,6 +506,92 @@ def test_splash_grid_end_to_end_from_a_dem_in_row_blocks(api, oracle, tmp_path):
         pass
 
 
+def test_time_chunks_continue_a_run_bit_for_bit(api, oracle, tmp_path):
+    """ABI 5: a series processed in time chunks.  The module's run_all starts from the state it is given
+    (wn_last ... nds_last, src/SPLASH.h:93-97); splash_grid_in.state0 / ai0 / tt expose that at the block
+    level: chunk 1 with the spin-up and the threshold of the WHOLE series (the maximum of the chunks'
+    thresholds, R/splash.point.R:120-122), every later chunk from the state the one before ended in ->
+    every series, the final state and the water-balance limbs of the undivided call, bit for bit; and
+    rsplash_amd.grid.splash_grid(chunk_years=1) does the same through row blocks and brick files."""
+    from scipy.io import netcdf_file
+    from rsplash_amd import grid, io
+    H, W, nt = 6, 20, 1096                       # 2001-2003 and 1 January 2004: the last chunk is ONE day
+    d = _synth(oracle, H, W, nt, 1, seed=31337)
+    st = d["st"]
+    n = H * W
+    sw, tc, pn = d["sw"].copy(), d["tc"].copy(), d["pn"].copy()
+    elev = st["elev"].copy()
+    na = np.zeros(n, bool)
+    na[[7, 63]] = True
+    for a in (sw, tc, pn):
+        a[:, na] = np.nan
+    elev[na] = np.nan
+    stat = (elev, st["soil"], st["lat"], st["slop"], st["asp"], st["au"], st["resolution"])
+    for monthly in (False, True):
+        kw = dict(sim_control=dict(monthly_out=monthly), want_diag=True, want_aux=True)
+        one = api.splash_grid(sw, tc, pn, *stat, time_index=d["dates"], **kw)
+        cuts = [(0, 365), (365, 730), (730, 1095), (1095, 1096)]
+        tts = [api.snow_threshold(tc[a:b], st["lat"], elev) for a, b in cuts]
+        tt = tts[0]
+        for t in tts[1:]:
+            tt = np.maximum(tt, t)
+        ok = ~na
+        assert np.array_equal(tt[ok], one["aux"]["Tt"][ok])      # the whole series' threshold, from its pieces
+        assert not np.array_equal(tts[1][ok], tt[ok])            # (and no single chunk has it)
+        state = ai = None
+        parts, accs = [], []
+        for a, b in cuts:
+            r = api.splash_grid(sw[a:b], tc[a:b], pn[a:b], *stat, time_index=d["dates"][a:b], tt=tt,
+                                state0=state, ai0=ai, **kw)
+            state = r["state_end"]
+            ai = r["aux"]["AI"] if ai is None else ai
+            parts.append(r)
+            accs.append(r["diag_acc"])
+        for k in api.OUT_NAMES:
+            got = np.concatenate([p[k] for p in parts])
+            assert got.shape == one[k].shape, k
+            assert np.array_equal(got[:, ok].view(np.int64), one[k][:, ok].view(np.int64)), (monthly, k)
+            assert np.isnan(got[:, na]).all(), k
+        assert np.array_equal(state[:, ok].view(np.int64), one["state_end"][:, ok].view(np.int64))
+        assert np.array_equal(np.concatenate(accs, axis=1), one["diag_acc"])
+        assert (parts[1]["aux"]["passes2"][ok] == 0).all() and np.array_equal(parts[2]["aux"]["AI"][ok], ai[ok])
+    # refusals: the three come together
+    with pytest.raises(api.SplashError, match="state0, ai0 and tt"):
+        api.splash_grid(sw[:10], tc[:10], pn[:10], *stat, time_index=d["dates"][:10], state0=state)
+    with pytest.raises(api.SplashError, match="365"):
+        api.splash_grid(sw[:10], tc[:10], pn[:10], *stat, time_index=d["dates"][:10], tt=tt)
+    # the block loop with time chunks: three whole years, rows in blocks of 4, bricks on disk
+    nt3 = 1095
+    geo = dict(ymax=46.5, xmin=7.0, yres=0.01, xres=0.01)
+    R = lambda v, z=None: grid.Raster(v, z=z, **geo)
+    r3 = lambda a: a[:nt3].reshape(nt3, H, W)
+    statics = dict(lat=st["lat"].reshape(H, W), slop=st["slop"].reshape(H, W), asp=st["asp"].reshape(H, W),
+                   Au=st["au"].reshape(3, H, W), resolution=st["resolution"].reshape(H, W))
+    bricks = [R(r3(x), d["dates"][:nt3]) for x in (sw, tc, pn)]
+    ref = api.splash_grid(r3(sw), r3(tc), r3(pn), elev.reshape(H, W), st["soil"].reshape(6, H, W), statics["lat"],
+                          statics["slop"], statics["asp"], statics["Au"], statics["resolution"],
+                          time_index=d["dates"][:nt3], sim_control=dict(monthly_out=True), want_diag=True)
+    g = grid.splash_grid(*bricks, R(elev.reshape(H, W)), R(st["soil"].reshape(6, H, W)), outdir=str(tmp_path),
+                         sim_control=dict(monthly_out=True, inmem=False), statics=statics, block_rows=4,
+                         chunk_years=1, want_diag=True)
+    assert grid.year_chunks(d["dates"][:nt3], 1) == [(0, 365), (365, 730), (730, 1095)]
+    assert grid.year_chunks(d["dates"], 2) == [(0, 730), (730, 1096)]
+    assert np.array_equal(g["diag_acc"], ref["diag_acc"])
+    for k, rk in dict(wn="wn", aet="aet", snow="snow", netr="netrad").items():
+        with netcdf_file(g[rk], "r", mmap=False) as fo:
+            a = np.array(fo.variables[io.BRICKS[k][1]][:])
+            want = np.where(np.isnan(ref[k]), io.NA_FLT4S, ref[k]).astype(np.float32)
+            assert a.shape == (36, H, W) and np.array_equal(a, want), k
+    gm = grid.splash_grid(*bricks, R(elev.reshape(H, W)), R(st["soil"].reshape(6, H, W)),
+                          sim_control=dict(monthly_out=False, inmem=True), statics=statics, block_rows=3, chunk_years=2)
+    refd = api.splash_grid(r3(sw), r3(tc), r3(pn), elev.reshape(H, W), st["soil"].reshape(6, H, W), statics["lat"],
+                           statics["slop"], statics["asp"], statics["Au"], statics["resolution"],
+                           time_index=d["dates"][:nt3], sim_control=dict(monthly_out=False))
+    okg = ~na.reshape(H, W)
+    for k, rk in dict(wn="wn", ro="ro", pet="pet", bflow="bflow", sm_lim="sm_lim").items():
+        assert np.array_equal(gm[rk][:, okg].view(np.int64), refd[k][:, okg].view(np.int64)), k
+
+
 def test_splash_grid_na_cells_and_blocking(api, oracle):
     """NA cells (72 % of the reference's SA_cru example) come back NaN; results do not depend on
     how the grid is cut into launches"""
