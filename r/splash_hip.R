@@ -48,6 +48,21 @@ splash.point <- function(sw_in, tc, pn, lat, elev, slop = 0, asp = 0, soil_data,
 }
 .splash_grid_collect <- function(handle) .Call("C_splash_grid_wait", handle)
 
+# A series too long for host memory, in time chunks (ABI 5).  The module's run_all starts from the state it is
+# given (src/SPLASH.h:93-97); .splash_grid_chunk is that for a row block: `tt` = the snowfall threshold of the
+# WHOLE series, do.call(pmax, lapply(chunks, function(ch) .splash_snow_threshold(tc_of(ch), lat, elev)))
+# (R/splash.point.R:120-122: max over all days); the first chunk runs the spin-up (state0 = ai0 = NULL), every
+# later one continues from res$state_end of the chunk before with ai0 = aux[, 2] of the FIRST chunk.  Chunks of
+# whole calendar years give the monthly outputs of the undivided run, bit for bit (tested on the Python twin,
+# rsplash_amd/grid.py: chunk_years).
+.splash_snow_threshold <- function(tc, lat, elev) .Call("C_splash_snow_threshold", tc, as.numeric(lat), as.numeric(elev))
+.splash_grid_chunk <- function(sw_in, tc, pn, stat, soil, Au, ztime, monthly_out, tt, state0 = NULL, ai0 = NULL,
+                               devices = 0L) {
+  tf <- .time_fields(ztime)
+  .Call("C_splash_grid_chunk", sw_in, tc, pn, stat, soil, Au, tf$doy, tf$year, tf$month, monthly_out,
+        as.integer(devices), as.numeric(tt), state0, ai0)
+}
+
 # file stem, NetCDF variable, unit and long name of the nine result bricks, in the order
 # .splash_grid_collect returns them (names as R/splash.grid.R:190-216 and :449)
 .splash_outputs <- data.frame(

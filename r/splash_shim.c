@@ -157,6 +157,60 @@ SEXP C_splash_grid_wait(SEXP ptr)
     return res;
 }
 
+/* A long series in time chunks (ABI 5: splash_grid_in.tt / state0 / ai0).  The module's run_all takes the
+ * state to start from (src/SPLASH.h:93-97); this is that, for a block.  tt: numeric(ncell), the snowfall
+ * threshold of the WHOLE series (pmax over C_splash_snow_threshold of every chunk; R/splash.point.R:120-122);
+ * state0: NULL for the first chunk (it runs the spin-up), else the [ncell x 5] "state_end" of the chunk
+ * before; ai0: NULL, else the aridity index the first chunk returned (column 2 of its "aux").
+ * Returns the nine result matrices plus state_end [ncell x 5] and aux [ncell x 4] (Tt, AI, passes1, passes2). */
+SEXP C_splash_grid_chunk(SEXP sw_in, SEXP tc, SEXP pn, SEXP stat, SEXP soil, SEXP au, SEXP doy,
+                         SEXP year, SEXP month, SEXP monthly, SEXP devices, SEXP tt, SEXP state0, SEXP ai0)
+{
+    splash_grid_in in;
+    splash_opts opt;
+    splash_grid_out out;
+    SEXP res9 = grid_call_setup(sw_in, tc, pn, stat, soil, au, doy, year, month, monthly, devices, &in, &opt, &out);
+    const size_t ncell = in.ncell;
+    if (!isReal(tt) || (size_t)XLENGTH(tt) != ncell) error("tt must be numeric(ncell)");
+    if (isNull(state0) != isNull(ai0)) error("state0 and ai0 come together");
+    if (!isNull(state0) && (!isReal(state0) || (size_t)XLENGTH(state0) != 5 * ncell)) error("state0 must be [ncell x 5]");
+    if (!isNull(ai0) && (!isReal(ai0) || (size_t)XLENGTH(ai0) != ncell)) error("ai0 must be numeric(ncell)");
+    in.tt = REAL(tt);
+    in.state0 = isNull(state0) ? NULL : REAL(state0); /* [ncell x 5] column-major == [5][ncell] */
+    in.ai0 = isNull(ai0) ? NULL : REAL(ai0);
+    static const char* names[] = {"wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr",
+                                  "sm_lim", "state_end", "aux", ""};
+    SEXP res = PROTECT(mkNamed(VECSXP, names));
+    for (int k = 0; k < SPLASH_NOUT; k++) SET_VECTOR_ELT(res, k, VECTOR_ELT(res9, k));
+    SEXP se = PROTECT(allocMatrix(REALSXP, (int)ncell, 5));
+    SEXP ax = PROTECT(allocMatrix(REALSXP, (int)ncell, 4));
+    SET_VECTOR_ELT(res, SPLASH_NOUT, se);
+    SET_VECTOR_ELT(res, SPLASH_NOUT + 1, ax);
+    out.state_end = REAL(se);
+    out.aux = REAL(ax);
+    char err[512];
+    int rc = splash_grid_run(&in, &opt, &out, err, sizeof err);
+    UNPROTECT(4);
+    if (rc != SPLASH_OK) error("splash_grid_run failed (%d): %s", rc, err);
+    return res;
+}
+
+/* the snowfall threshold of one chunk of tc ([ncell x nt] matrix): numeric(ncell) */
+SEXP C_splash_snow_threshold(SEXP tc, SEXP lat, SEXP elev)
+{
+    SEXP dim = getAttrib(tc, R_DimSymbol);
+    if (isNull(dim) || LENGTH(dim) != 2 || !isReal(tc)) error("tc must be a numeric [ncell x nt] matrix");
+    const size_t ncell = (size_t)INTEGER(dim)[0];
+    const int nt = INTEGER(dim)[1];
+    if ((size_t)XLENGTH(lat) != ncell || (size_t)XLENGTH(elev) != ncell) error("lat and elev must be numeric(ncell)");
+    SEXP res = PROTECT(allocVector(REALSXP, (R_xlen_t)ncell));
+    char err[512];
+    int rc = splash_snow_threshold_run(ncell, nt, REAL(tc), NULL, REAL(lat), REAL(elev), REAL(res), err, sizeof err);
+    UNPROTECT(1);
+    if (rc != SPLASH_OK) error("splash_snow_threshold_run failed (%d): %s", rc, err);
+    return res;
+}
+
 /* splash.point: the same pipeline for one site (numeric vectors of length nt) */
 SEXP C_splash_point_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP lat, SEXP elev, SEXP slop, SEXP asp,
                         SEXP soil_data, SEXP Au, SEXP resolution, SEXP doy, SEXP year, SEXP month,
@@ -256,6 +310,8 @@ static const R_CallMethodDef CallEntries[] = {
     {"C_splash_grid_run", (DL_FUNC)&C_splash_grid_run, 11},
     {"C_splash_grid_submit", (DL_FUNC)&C_splash_grid_submit, 12},
     {"C_splash_grid_wait", (DL_FUNC)&C_splash_grid_wait, 1},
+    {"C_splash_grid_chunk", (DL_FUNC)&C_splash_grid_chunk, 14},
+    {"C_splash_snow_threshold", (DL_FUNC)&C_splash_snow_threshold, 3},
     {"C_splash_point_run", (DL_FUNC)&C_splash_point_run, 14},
     {"C_splash_unswc_run", (DL_FUNC)&C_splash_unswc_run, 3},
     {"C_splash_static_rasters", (DL_FUNC)&C_splash_static_rasters, 5},
