@@ -1,6 +1,7 @@
 """Randomised invariants of the host-buffer entry point (splash_grid_run through api.splash_grid), GPU box:
 for random grid shapes, NA masks, launch blockings, device lists {0,0}/{0,0,0}, pipeline lanes (1-4),
-straggler pools too small for a block (finished in place), calls in flight side by side
+straggler pools too small for a block (finished in place), a series in two time chunks (ABI 5: continued from the
+first chunk's state), calls in flight side by side
 (splash_grid_submit/_wait), single-precision transport of forcing and of results, the large-call paths at
 small size (page mapping per block, page-locked caller arrays, the library's own blocking; outputs handed in
 filled with a sentinel), monthly/daily outputs and basin maps, the
@@ -95,6 +96,23 @@ for case in range(n_cases):
         for k in g["diag"]:
             if not np.array_equal(np.asarray(g["diag"][k]).view(np.int64), np.asarray(ref["diag"][k]).view(np.int64)):
                 msgs.append(f"{tag}: basin totals of {k} differ")
+    if nt > 366:  # round 5 (ABI 5): the series in two time chunks, cut at a random month start after the first year
+        starts = np.flatnonzero(np.r_[False, mid[1:] != mid[:-1]])
+        cut = int(rng.choice(starts[starts >= 365]))
+        tt = np.maximum(api.snow_threshold(tcm[:cut], st["lat"], elev), api.snow_threshold(tcm[cut:], st["lat"], elev))
+        blk = dict(max_cells_per_launch=int(rng.integers(64, 400)))
+        kwc = dict(kw, want_aux=True)
+        a = api.splash_grid(swm[:cut], tcm[:cut], pnm[:cut], *args, **dict(kwc, time_index=dates[:cut]), tt=tt, **blk)
+        b = api.splash_grid(swm[cut:], tcm[cut:], pnm[cut:], *args, **dict(kwc, time_index=dates[cut:]), tt=tt,
+                            state0=a["state_end"], ai0=a["aux"]["AI"], **blk)
+        for k in names:
+            got = np.concatenate([a[k], b[k]])
+            if got.shape != ref[k].shape or not np.array_equal(got[:, ~mask].view(np.int64), ref[k][:, ~mask].view(np.int64)):
+                msgs.append(f"two time chunks (cut at day {cut}): {k} differs")
+        if not np.array_equal(np.concatenate([a["diag_acc"], b["diag_acc"]], axis=1), ref["diag_acc"]):
+            msgs.append("two time chunks: water-balance limbs differ")
+        if not np.array_equal(b["state_end"][:, ~mask].view(np.int64), ref["state_end"][:, ~mask].view(np.int64)):
+            msgs.append("two time chunks: final state differs")
     g32 = api.splash_grid(swm.astype(np.float32), tcm.astype(np.float32), pnm.astype(np.float32), *args, **kw)
     for k in names:  # the synthetic forcing is float-representable: single-precision transport is lossless
         if not np.array_equal(g32[k][:, ~mask].view(np.int64), ref[k][:, ~mask].view(np.int64)):
