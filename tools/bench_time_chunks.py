@@ -51,7 +51,12 @@ print(f"{H}x{W} cells x {nt} days generated and copied to the host in {time.perf
 kw = dict(sim_control=dict(monthly_out=monthly), want_aux=True)
 args = lambda a, b: (host["sw"][a:b], host["tc"][a:b], host["pn"][a:b], *stat)
 
-# ---- the chunked run (twice: the first pays the buffer allocations)
+# ---- the chunked run (twice: the first pays the buffer allocations).  The chunks' results go straight into slices of
+# caller-allocated whole-series arrays (what an R caller's bricks or allocMatrix are), touched once beforehand.
+mid = api.month_ids(year, month)
+nl = int(mid[-1]) + 1 if monthly else nt
+full = {k: np.zeros((nl, n)) for k in api.OUT_NAMES}
+lay = lambda a, b: (int(mid[a]), int(mid[b - 1]) + 1) if monthly else (a, b)
 for rep in range(2):
     t_all = time.perf_counter()
     tt = None
@@ -63,7 +68,9 @@ for rep in range(2):
     parts, secs = [], []
     for a, b in cuts:
         t0 = time.perf_counter()
-        r = api.splash_grid(*args(a, b), time_index=dates[a:b], tt=tt, state0=state, ai0=ai, **kw)
+        l0, l1 = lay(a, b)
+        r = api.splash_grid(*args(a, b), time_index=dates[a:b], tt=tt, state0=state, ai0=ai,
+                            out={k: full[k][l0:l1] for k in api.OUT_NAMES}, **kw)
         secs.append(time.perf_counter() - t0)
         state, ai = r["state_end"], (r["aux"]["AI"] if ai is None else ai)
         parts.append(r)
@@ -77,7 +84,7 @@ one = api.splash_grid(*args(0, nt), time_index=dates, **kw)
 t_one = time.perf_counter() - t0
 differing = values = 0
 for k in api.OUT_NAMES:
-    got = np.concatenate([p[k] for p in parts])
+    got = full[k]
     differing += int((got.view(np.int64) != one[k].view(np.int64)).sum())
     values += got.size
 differing += int((state.view(np.int64) != one["state_end"].view(np.int64)).sum())
