@@ -1132,7 +1132,9 @@ extern "C" int splash_snow_threshold_run(size_t ncell, int nt, const double* tc,
     if (ncell == 0) return SPLASH_OK;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b), err, errlen);
-    free_b += pool_idle_bytes(0);
+    int cur_dev = 0;
+    HIP_TRY(hipGetDevice(&cur_dev), err, errlen);
+    free_b += pool_idle_bytes(cur_dev);
     const size_t per_cell = (size_t)nt * (tc ? 8 : 12) + 3 * 8;
     size_t nb = std::min<size_t>(ncell, std::max<size_t>(256, (size_t)((double)free_b * 0.5 / (double)per_cell)));
     nb = std::min(nb, kMaxCellsPerLaunch);
