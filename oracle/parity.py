@@ -502,3 +502,119 @@ def assert_whole_pipeline(oracle, g, ref, aux, statics, doy, year, name="", name
                 reference_disagrees_with_itself=self_dis,
                 grazing_cell_days=int(graz.sum()), max_rel_err=worst, ok=~bad_cell, profile=prof,
                 worst=worst_rows)
+
+
+def spinup_summary(oracle, state0, ai, passes2, aux, statics=None, forcing=None, max_flip_frac=0.05,
+                   rtol_ai=1e-9):
+    """The spin-up's RESULT against the oracle's brute-force loop (src/SPLASH.cpp:1594-1749 twice, with the
+    aridity index in between, R/splash.point.R:141-152): the product ends a cell that never meets the 1 mm rule
+    by exact-cycle detection and extrapolates the snow age; the oracle iterates all 1000 passes.
+
+    state0 [5, n] (wn, snow, qin, td, nd), ai [n], passes2 [n] (or None): the product's; aux: the oracle's
+    orc_cell_aux records of the same cells (Oracle.grid).  Rules (per cell):
+      wn, snow, qin   |x - ref| <= 1e-5 |ref| + 1e-9
+      td              the same, and the same NaN / inf pattern (the sticky drainage time of flat terrain); not
+                      compared in a cell whose run met a noise-level drainage denominator (aux['fragile'] > 0: the
+                      drainage time of such a day is rounding noise in the reference itself)
+      nd              EXACTLY equal (an integer count of days; the detector adds 365 per skipped pass)
+      aridity index   relative rtol_ai (it is formed by spin-up #1's first pass alone)
+      passes          equal
+    Set aside (counted, bounded like assert_whole_pipeline's): a cell whose year holds a grazing-sun day (statics given:
+    0 < hs < HS_LIM_DEG on one of the 365 spin-up days -- the reference's own radiation of that day is rounding
+    noise and every pass of the spin-up goes through it).
+    A cell that breaks a rule is classified: a cell in which the oracle met a critical event (aux['critical'] > 0:
+    the sticky infinite drainage time the reference itself takes or not depending on the last bit of pow(),
+    DESIGN.md 3.2) may differ, at most `max_flip_frac` of them (or 3); any other cell only if two other legal
+    builds of the reference's own statements disagree on it too (needs statics and forcing = (doy, year, month,
+    mid, nm, sw, tc, pn)); at most MAX_SELF_DISAGREEMENTS of those.
+    Returns a dict of plain numbers with 'violations' (list of str)."""
+    from oracle.binding import HS_LIM_DEG, grazing_mask
+    ref = np.asarray(aux["state0"]).T  # [5, n]
+    n = ref.shape[1]
+    graz = np.zeros(n, bool)
+    if statics is not None and forcing is not None:
+        year0 = int(forcing[1][0])
+        graz = grazing_mask(oracle, statics["lat"], statics["slop"], statics["asp"] - 180.0, np.arange(1, 366),
+                            np.full(365, year0), hs_deg=HS_LIM_DEG).any(0)
+    fragile = np.asarray(aux["fragile"]) > 0
+    bad = np.zeros(n, bool)
+    why = {}
+    worst = {}
+    for k, name in enumerate(("wn", "snow", "qin", "td")):
+        a, f = np.asarray(state0[k]), ref[k]
+        b = _bad(a, f)
+        if name == "td":
+            b &= ~fragile
+        with np.errstate(invalid="ignore", divide="ignore"):
+            e = np.where(np.isfinite(f) & (f != 0) & np.isfinite(a), np.maximum(np.abs(a - f) - ATOL, 0.0) / np.abs(f), 0.0)
+        if name == "td":
+            e = np.where(fragile, 0.0, e)
+        worst[name] = e
+        why[name] = b
+        bad |= b
+    nd_bad = ~((np.asarray(state0[4]) == ref[4]) | (np.isnan(state0[4]) & np.isnan(ref[4])))
+    why["nd"] = nd_bad
+    bad |= nd_bad
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ai_ref = np.asarray(aux["AI"])
+        ai_bad = ~((np.abs(ai - ai_ref) <= rtol_ai * np.abs(ai_ref)) | (ai == ai_ref) | (np.isnan(ai) & np.isnan(ai_ref)))
+    why["AI"] = ai_bad
+    bad |= ai_bad
+    passes_equal = None
+    if passes2 is not None:
+        pdiff = np.asarray(passes2).astype(np.int64) != np.asarray(aux["passes2"]).astype(np.int64)
+        passes_equal = int((~pdiff).sum())
+        why["passes"] = pdiff
+        bad |= pdiff
+    flagged = np.asarray(aux["critical"]) > 0
+    capped = np.asarray(aux["passes2"]) >= 1000
+    viol = []
+    bad_g = bad & graz          # set aside
+    bad &= ~graz
+    if graz.mean() > 2e-2:
+        viol.append(f"{int(graz.sum())} of {n} cells hold a grazing-sun day")
+    flips = bad & flagged
+    if flips.sum() > max(3, max_flip_frac * flagged.sum()):
+        viol.append(f"{int(flips.sum())} of {int(flagged.sum())} critical-event cells end the spin-up differently")
+    stray = bad & ~flagged
+    excused = 0
+    if stray.any():
+        cells = np.where(stray)[0]
+        if statics is not None and forcing is not None and len(cells) <= MAX_SELF_DISAGREEMENTS:
+            ex = np.zeros(len(cells), bool)
+            doy, year, month, mid, nm, sw, tc, pn = forcing
+            for i, c in enumerate(cells):
+                sl = slice(int(c), int(c) + 1)
+                st1 = {k: (v[:, sl] if np.ndim(v) == 2 else v[sl]) for k, v in statics.items()}
+                for oo in reference_variants().values():
+                    _, a2 = oo.grid(doy, year, month, mid, nm, np.ascontiguousarray(sw[:, sl]),
+                                    np.ascontiguousarray(tc[:, sl]), np.ascontiguousarray(pn[:, sl]), st1["lat"],
+                                    st1["elev"], st1["slop"], st1["asp"], st1["soil"], st1["au"], st1["resolution"],
+                                    n_threads=1)
+                    r2 = np.asarray(a2["state0"][0])
+                    differs = _bad(r2[:3], ref[:3, c]).any() or (not fragile[c] and _bad(r2[3:4], ref[3:4, c]).any()) or \
+                        not (r2[4] == ref[4, c] or (r2[4] != r2[4] and ref[4, c] != ref[4, c])) or \
+                        int(a2["passes2"][0]) != int(aux["passes2"][c])
+                    ex[i] |= bool(differs)
+            stray[cells[ex]] = False
+            excused = int(ex.sum())
+        if stray.any():
+            c = int(np.where(stray)[0][0])
+            broken = [k for k, v in why.items() if v[c]]
+            viol.append(f"{int(stray.sum())} cells end the spin-up out of tolerance without a critical event "
+                        f"(rules broken, cells: { {k: int((v & stray).sum()) for k, v in why.items()} }); first: cell {c} "
+                        f"breaks {broken}: product {[float(state0[k][c]) for k in range(5)]} AI {float(ai[c])!r} ref "
+                        f"{[float(ref[k][c]) for k in range(5)]} AI {float(ai_ref[c])!r} passes "
+                        f"{None if passes2 is None else int(passes2[c])}/{int(aux['passes2'][c])} fragile {int(aux['fragile'][c])}")
+    keep = ~bad & ~graz
+    return dict(cells=int(n), capped=int(capped.sum()), capped_within_tolerance=int((capped & keep).sum()),
+                passes_equal=passes_equal, critical_event_cells=int(flagged.sum()),
+                critical_event_cells_that_differ=int(flips.sum()), excused=excused,
+                grazing_cells=int(graz.sum()), grazing_cells_that_differ=int(bad_g.sum()),
+                nd_equal=int((~nd_bad).sum()),
+                max_rel_state={k: float(v[keep].max()) if keep.any() else 0.0 for k, v in worst.items()},
+                max_rel_state_capped=float(max((v[capped & keep].max() if (capped & keep).any() else 0.0)
+                                               for v in worst.values())),
+                max_rel_ai=float(np.nanmax(np.where(keep & (ai_ref != 0), np.abs(ai - ai_ref) / np.abs(ai_ref), 0.0)))
+                if keep.any() else 0.0,
+                excuse_builds=variants_status(), violations=viol)

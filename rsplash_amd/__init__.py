@@ -5,6 +5,6 @@ include/splash_hip.h).  This package is the host-side mirror of the reference's 
 that path (splash.point / splash.grid / the SPLASH Rcpp module) over ctypes; it contains no
 numerical fallback: importing `rsplash_amd.api` without the built library raises.
 """
-from .build import build_library, library_path  # noqa: F401
+from .build import build_check_library, build_library, check_library_path, library_path  # noqa: F401
 
-__all__ = ["build_library", "library_path"]
+__all__ = ["build_library", "library_path", "build_check_library", "check_library_path"]

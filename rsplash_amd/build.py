@@ -22,3 +22,15 @@ def build_library(force=False, verbose=False):
     if not os.path.exists(library_path()):
         raise RuntimeError("librsplash_hip.so was not produced by " + " ".join(cmd))
     return library_path()
+
+
+def check_library_path():
+    return os.path.join(_HERE, "librsplash_hip_check.so")
+
+
+def build_check_library(verbose=False):
+    """The checking build (the same sources with -DSPL_CHECK_SLOTS: every access to the spin-up's record cache
+    reports its slot); loaded by one GPU test only.  `make check`."""
+    subprocess.check_call(["make", "-j4", "-C", os.path.join(_HERE, "csrc"), "check"],
+                          stdout=None if verbose else subprocess.DEVNULL)
+    return check_library_path()

@@ -60,6 +60,7 @@ namespace {
 std::mutex g_knobs_mu;
 splash::host::Knobs g_knobs;
 bool g_knobs_read = false;
+thread_local const splash::host::Knobs* t_knobs = nullptr; // a call's own copy (KnobScope), or NULL
 
 size_t env_size(const char* name, size_t dflt)
 {
@@ -83,6 +84,7 @@ void knobs_read_locked()
     k.no_nd_skip = getenv("SPLASH_HIP_NO_ND_SKIP") != nullptr;
     k.no_block_phase1 = getenv("SPLASH_HIP_NO_BLOCK_PHASE1") != nullptr;
     k.no_solo_tail = getenv("SPLASH_HIP_NO_SOLO_TAIL") != nullptr;
+    k.no_uniform_tail = getenv("SPLASH_HIP_NO_UNIFORM_TAIL") != nullptr;
     if (const char* e = getenv("SPLASH_HIP_TAIL_STAGES")) {
         int b0 = 0, b1 = 0;
         if (sscanf(e, "%d,%d", &b0, &b1) == 2) {
@@ -116,12 +118,17 @@ void knobs_read_locked()
 
 void splash::host::knobs_refresh()
 {
+    if (t_knobs) return; // a thread working for a call in flight: the call keeps its knobs, and never calls getenv
     std::lock_guard<std::mutex> lk(g_knobs_mu);
     knobs_read_locked();
 }
 
+splash::host::KnobScope::KnobScope(const Knobs& k) : mine_(k), prev_(t_knobs) { t_knobs = &mine_; }
+splash::host::KnobScope::~KnobScope() { t_knobs = prev_; }
+
 splash::host::Knobs splash::host::knobs()
 {
+    if (t_knobs) return *t_knobs;
     std::lock_guard<std::mutex> lk(g_knobs_mu);
     if (!g_knobs_read) knobs_read_locked(); // (a library-internal thread never gets here first: every
                                             //  entry point that starts one has refreshed)
@@ -703,7 +710,19 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
                     a.no_queue = last ? 1 : 0; // (the budgets cover the 1000-pass cap: nothing is left after the last stage)
                     a.wl_out = last ? wl[ph & 1] : lists[st + 1];
                     a.n_out = last ? cnt + ph : counts[st + 1];
+                    // Round 6: every stage is a PAIR of launches over the same list, of which exactly one works --
+                    // the list's length is known on the device only.  More than 1 024 jobs: the general spread
+                    // kernel (several jobs to a wavefront).  At most 1 024 -- the last stage of a big grid, every
+                    // stage of a small one --: ONE job per wavefront, the other lanes repeating it, so every branch
+                    // of the day step is wave-uniform and the SOLO variant says so (k_spin_phase, wave_pred).
+                    a.solo_split = kn.no_uniform_tail ? 0 : 1;
                     HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+                    a.solo_split = 0;
+                    if (!kn.no_uniform_tail) {
+                        a.solo = 1;
+                        HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
+                        a.solo = 0;
+                    }
                     prev = st + 1;
                 }
                 a.spread = 0;
@@ -739,6 +758,7 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
                                   double* cellpar, size_t ldp, double* state, size_t lds,
                                   int* passes, void* work, void* stream)
 {
+    knobs_refresh(); // the caller's thread (a no-op on a lane or pool thread: KnobScope); spin_phases() itself never refreshes
     return spin_phases(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, passes, work,
                        stream, 0, kSpinPhases);
 }
@@ -749,6 +769,7 @@ extern "C" int splash_dev_spin_up_begin(const splash_calendar* cal, size_t ncell
                                         double* state, size_t lds, int* passes, void* work,
                                         void* stream)
 {
+    knobs_refresh(); // the caller's thread (a no-op on a lane or pool thread: KnobScope); spin_phases() itself never refreshes
     return spin_phases(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, passes, work,
                        stream, 0, kSpinPhases - 1);
 }
@@ -759,6 +780,7 @@ extern "C" int splash_dev_spin_up_finish(const splash_calendar* cal, size_t ncel
                                          double* state, size_t lds, int* passes, void* work,
                                          void* stream)
 {
+    knobs_refresh(); // the caller's thread (a no-op on a lane or pool thread: KnobScope); spin_phases() itself never refreshes
     return spin_phases(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, passes, work,
                        stream, kSpinPhases - 1, kSpinPhases);
 }

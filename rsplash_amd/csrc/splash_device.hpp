@@ -71,6 +71,20 @@ constexpr double kFluidity = 35187037.0;
 #define SPL_MAX(a, b) (((a) < (b)) ? (b) : (a))
 #define SPL_MIN(a, b) (((b) < (a)) ? (b) : (a))
 
+// Predicate of one of the day step's LARGE branches.  UNI = false: the lane's own predicate (a wavefront executes the
+// union of its lanes' branches under execution masks).  UNI = true: the caller guarantees that all 64 lanes of the
+// wavefront hold the SAME cell (the last spread stage of the spin-up's tail, one job per wavefront, k_spin_phase
+// SOLO), so the predicate is wave-uniform; saying so -- a ballot compared with zero is a scalar value -- lets the
+// compiler emit s_cmp + s_cbranch_scc instead of v_cmp -> s_and_saveexec -> s_cbranch_execz ... s_or exec: no
+// execution-mask bookkeeping around ~10 blocks of a day step on which a lone wavefront pays for every instruction.
+// The arithmetic inside the blocks is untouched (same statements in the same basic blocks: same bits).
+template <bool UNI>
+__device__ __forceinline__ bool wave_pred(bool p)
+{
+    if constexpr (UNI) return __builtin_amdgcn_ballot_w64(p) != 0ull;
+    else return p;
+}
+
 struct State {
     double wn, snow, qin, td, nd;
 };
@@ -827,6 +841,7 @@ __device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d,
     T.warm = (tc >= 3.0);
 }
 
+template <bool UNI = false>
 __device__ __forceinline__ void evap_update(const CellConst& c, const DayTerms& T, const ViscTerms& V,
                                             double sw, double snow, double nd, Etr& o)
 {
@@ -834,7 +849,7 @@ __device__ __forceinline__ void evap_update(const CellConst& c, const DayTerms& 
     const double sw_s = sw > 1.0 ? 1.0 : sw; // :92
     const double alb_v = kAlbSw - 0.17 * sw_s; // :215
     double alb = alb_v;                        // snow-free: sfc = 0 => alb = alb_v exactly
-    if (snow > 0.0 || isnan(snow)) {           // :208-219
+    if (wave_pred<UNI>(snow > 0.0 || isnan(snow))) { // :208-219
         const double max_alb_snw = (1.0 - 0.443700) + (0.443700 * fexp(-0.895189 * nd));
         const double sfc = snow * frcp(140.0 + snow);
         alb = alb_v * (1.0 - sfc) + sfc * max_alb_snw;
@@ -951,18 +966,19 @@ __device__ __forceinline__ double moist_surf(const CellConst& c, double wn)
     // underflows for quite ordinary Theta), which sends theta to theta_r there
     const double psi = c.bpr * fexp(-L * c.inv_lambda);
     const double head_ratio = (psi + 10.0) * c.inv_bpr;
-    double theta_BC = c.dtheta * fexp(-c.lambda * flog(head_ratio)) + c.theta_r;
-    if (wn < c.RES) { // theta_mean < theta_r
-        theta_BC = c.theta_r;
-    } else if (isnan(theta_BC)) {
-        theta_BC = c.theta_s;
-    }
-    return theta_BC;
+    double theta_bc0 = c.dtheta * fexp(-c.lambda * flog(head_ratio)) + c.theta_r;
+    asm volatile("" : "+v"(theta_bc0)); // (finished before the selects below: no execution-mask branch around its tail)
+    // (if / else-if chains of this file are written as nested conditional expressions over finished values: the
+    //  three-way merge of an else-if is not if-converted by the compiler, which then emits execution-mask branches --
+    //  s_and_saveexec, s_cbranch_execz, s_or -- around one v_cndmask's worth of work, in every kernel)
+    return (wn < c.RES) ? c.theta_r                       // theta_mean < theta_r
+                        : (isnan(theta_bc0) ? c.theta_s : theta_bc0);
 }
 
 // src/SPLASH.cpp:1963-2023 with tdur = 6 h (call at :1268).  The surface moisture (moist_surf,
 // :1265) only enters when the rain rate exceeds the conductivity, so it is evaluated inside that
 // branch (two logs and two exps saved on every other cell-day).
+template <bool UNI = false>
 __device__ __forceinline__ double inf_GA(const CellConst& c, double wn, double Ksat, double P)
 {
     const double tdur = 6.0;
@@ -971,12 +987,12 @@ __device__ __forceinline__ double inf_GA(const CellConst& c, double wn, double K
 #if defined(SPL_ABLATE) && SPL_ABLATE == 11
     if (false) {
 #else
-    if (!(r <= Ksat)) {
+    if (wave_pred<UNI>(!(r <= Ksat))) {
 #endif
         SPL_SITE();
         const double theta_i = moist_surf(c, wn);
         const double delta_theta = (c.theta_s - theta_i);
-        if (delta_theta <= 0.0) {
+        if (wave_pred<UNI>(delta_theta <= 0.0)) {
             I = Ksat * tdur;
         } else {
             const double hd = c.h_f * delta_theta;
@@ -1007,6 +1023,7 @@ __device__ __forceinline__ double inf_GA(const CellConst& c, double wn, double K
 //     relative accuracy -- not its size -- sets the drainage time.  (Past |psi_m| ~ 1e11*depth
 //     the reference's own difference is rounding noise of fl(psi_m + depth*1000): DESIGN.md
 //     "Conditioning"; the parity tests set such cell-days aside.)
+template <bool UNI = false>
 __device__ __forceinline__ double transmittance_uns(const CellConst& c, double Ksat_visc,
                                                     double sm, double& Acs_out)
 {
@@ -1018,22 +1035,22 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
     const double L = flog<kLogFinite>(Theta); // sm <= SAT: Theta <= 1
     const double P = fexp(-L * c.inv_lambda); // Theta^(-1/lambda) in [1, +inf]
     const double psi_m = c.bub * P;           // bub / Theta^(1/lambda)
-    double wtd = ((c.bub - psi_m) * 1.0e-3);
-    bool clamped = false;
-    if (wtd < 0.0 || isnan(wtd)) {
-        wtd = 0.01;
-        clamped = true;
-    } else if (wtd > c.depth) {
-        wtd = c.depth;
-        clamped = true;
-    }
+    const double wtd0 = ((c.bub - psi_m) * 1.0e-3);
+    const bool wtd_low = (wtd0 < 0.0 || isnan(wtd0));
+    const bool wtd_high = !wtd_low && (wtd0 > c.depth);
+    const bool clamped = wtd_low || wtd_high;
+    const double wtd = wtd_low ? 0.01 : (wtd_high ? c.depth : wtd0);
     Acs_out = (c.depth - wtd) * c.so_cellout;
     const double w1000 = wtd * 1000.0;
     // A = Theta^((3*lambda+1)/lambda) = Theta^3 * Theta^(1/lambda) = Theta^3 / P: a reciprocal instead
     // of a second exponential (P = +inf for Theta = 0 gives A = 0, like the reference's pow(-0, e))
-    const double A = (P < 1.0e300) ? (Theta * Theta * Theta) * frcp(P) : 0.0;
+    // (the quotient is a finished value before the select: otherwise the compiler sinks the reciprocal into an
+    //  execution-mask branch; frcp(+inf) is NaN and is not selected)
+    double a_fin = (Theta * Theta * Theta) * frcp(P);
+    asm volatile("" : "+v"(a_fin));
+    const double A = (P < 1.0e300) ? a_fin : 0.0;
     double diff; // A - B
-    if (!clamped) {
+    if (wave_pred<UNI>(!clamped)) {
         diff = A - 1.0; // bub/(psi_m + wtd*1000) is 1 +- 1 ulp: B = 1 to 1e-16
     } else {
         // u = wtd*1000/psi_m, with the increment taken as the reference forms it: fl(psi_m +
@@ -1045,10 +1062,12 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
         const double xs = psi_m + w1000;
         const double u = (xs - psi_m) * frcp(psi_m); // in (-1, 0] for a dry column (NaN if psi_m = -inf:
                                                       // T_uns then falls to the guard below, = 0)
-        const double l1p = (fabs(u) < 1.0e-5) ? u * (1.0 - u * (0.5 - u * (1.0 / 3.0)))
-                                              : flog<kLogPositive>(1.0 + u); // 1 + u in (0, 2] or NaN
+        double l1p, em1;
+        if (wave_pred<UNI>(fabs(u) < 1.0e-5)) l1p = u * (1.0 - u * (0.5 - u * (1.0 / 3.0)));
+        else l1p = flog<kLogPositive>(1.0 + u); // 1 + u in (0, 2] or NaN
         const double z = -c.e3l1 * l1p;
-        const double em1 = (fabs(z) < 1.0e-5) ? z * (1.0 + z * (0.5 + z * (1.0 / 6.0))) : fexp(z) - 1.0;
+        if (wave_pred<UNI>(fabs(z) < 1.0e-5)) em1 = z * (1.0 + z * (0.5 + z * (1.0 / 6.0)));
+        else em1 = fexp(z) - 1.0;
         diff = -A * em1;
     }
     double T_uns = (Ksat_visc * c.tu_all) * diff;
@@ -1062,6 +1081,7 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
 // day_update(): the water balance given the day's state-independent terms (computed by day_terms()
 // or read back from the spin-up's cache), what follows from the day's viscosity (visc_terms()) and
 // the day's rain and snowfall.
+template <bool UNI = false>
 __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K, const ViscTerms& V,
                                            double pn, double snowfall, State& st, DayOut& o)
 {
@@ -1069,12 +1089,8 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
     double snow = st.snow, qin = st.qin, td = st.td, nd = st.nd;
 
     // :1042-1048
-    double sw = (wn - c.RES) * c.inv_wr;
-    if (sw < 0.0 || isnan(sw)) {
-        sw = 0.0;
-    } else if (sw > 1.0) {
-        sw = 1.0;
-    }
+    const double sw0 = (wn - c.RES) * c.inv_wr;
+    const double sw = (sw0 < 0.0 || isnan(sw0)) ? 0.0 : ((sw0 > 1.0) ? 1.0 : sw0);
     // :1225-1231
     if (snowfall > 0.0) {
         nd = 0.0;
@@ -1084,14 +1100,14 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
     snow += snowfall;
 
     Etr ev;
-    evap_update(c, K, V, sw, snow, nd, ev);       // :1235
+    evap_update<UNI>(c, K, V, sw, snow, nd, ev);  // :1235
     snow -= ev.snowmelt;                          // :1240
     const double snowmelt = ev.snowmelt - ev.sublimation; // :1243
 
     // :1260-1272
     const double Ksat_visc = V.kv;
     const double inflow = pn + ev.cond + snowmelt;
-    const double infi = inf_GA(c, wn, Ksat_visc, inflow);
+    const double infi = inf_GA<UNI>(c, wn, Ksat_visc, inflow);
     const double ro_h_arg = inflow - infi;
     const double ro_h = SPL_MAX(ro_h_arg, 0.0);
     double R = infi - ev.aet;
@@ -1108,50 +1124,44 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
     double q_in_o = 0.0;
     double Kb = 0.0;
     bool have_kb = false;
-    if (!((td <= 0.0) || (qin <= 0.0))) {
+    if (wave_pred<UNI>(!((td <= 0.0) || (qin <= 0.0)))) {
         Kb = fexp(lkb_arg);
         have_kb = true;
         q_in_o = qin * Kb;
     }
     // :1377-1397
-    double sm = wn + q_in_o + R;
-    double ro_d = 0.0;
-    if (sm > c.SAT) {
-        ro_d = (sm - c.SAT);
-        sm = c.SAT;
-        if (R > 0) {
-            R -= ro_d;
-        }
-    } else if (sm < c.RES) {
-        sm = c.RES;
-        ro_d = 0.0;
+    const double sm0 = wn + q_in_o + R;
+    const bool over0 = sm0 > c.SAT;
+    const double ro_d0 = sm0 - c.SAT;
+    double ro_d = over0 ? ro_d0 : 0.0;
+    {
+        const double R_less = R - ro_d0;
+        R = (over0 && R > 0) ? R_less : R;
     }
+    double sm = over0 ? c.SAT : ((sm0 < c.RES) ? c.RES : sm0);
 
     // :1406-1457 transmittance after recharge
     double Acs_out;
     SPL_SITE();
-    const double T_uns1 = transmittance_uns(c, Ksat_visc, sm, Acs_out);
+    const double T_uns1 = transmittance_uns<UNI>(c, Ksat_visc, sm, Acs_out);
     const double sm1 = sm;
     double T_uns = T_uns1, T_sat;
 #if defined(SPL_ABLATE) && SPL_ABLATE == 12
     if (false) {
 #else
-    if (c.deep) { // depth >= 2.0: vertical drainage corrections :1433-1450
+    if (wave_pred<UNI>(c.deep)) { // depth >= 2.0: vertical drainage corrections :1433-1450
 #endif
         SPL_SITE();
         // :984-990 clamp of the start-of-day volumetric content, :1267 theta_m
         // (both quotients with the reference's rounding: the exponent 3 + 2/lambda reaches 1e4, so
         // an ulp of the base is 1e-12 of Kunsat -- see rel_saturation)
-        double theta_i = div_cr(wn, c.d1000, c.inv_d1000);
-        if (theta_i >= c.theta_s) {
-            theta_i = c.theta_s - 0.001;
-        } else if (theta_i <= c.theta_r) {
-            // (formed here: hoisted out of the day loop the sum would be one more live register,
-            // i.e. a spill to scratch memory, whose reload waits on the vector-memory counter)
-            double tr = c.theta_r;
-            asm volatile("" : "+v"(tr));
-            theta_i = tr + 0.001;
-        }
+        const double theta_i0 = div_cr(wn, c.d1000, c.inv_d1000);
+        // (tr + 0.001 is formed here: hoisted out of the day loop the sum would be one more live register,
+        // i.e. a spill to scratch memory, whose reload waits on the vector-memory counter)
+        double tr = c.theta_r;
+        asm volatile("" : "+v"(tr));
+        const double theta_i = (theta_i0 >= c.theta_s) ? c.theta_s - 0.001
+                                                       : ((theta_i0 <= c.theta_r) ? tr + 0.001 : theta_i0);
         const double theta_m = SPL_MAX(c.wm_th, theta_i);
         const double Kunsat = Ksat_visc * fpow(div_cr(theta_m, c.theta_s, c.inv_theta_s), c.kun_exp); // :1275
         T_uns += Kunsat * 24.0;
@@ -1165,7 +1175,7 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
     double t_drain = 0.0;
     double q_in_f = 0.0;
     td -= 1.0;
-    if ((R > 0.0) && (sm > c.Wmax)) {
+    if (wave_pred<UNI>((R > 0.0) && (sm > c.Wmax))) {
         SPL_SITE();
         // log(Kb) with Kb = exp(lkb_arg) (:1326, :1470): the round trip returns lkb_arg up to the
         // rounding of Kb, an ABSOLUTE 1e-16, i.e. relative 1e-16/|lkb_arg|.  Above 1e-7 that is
@@ -1175,7 +1185,7 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
         // and an underflowing Kb, go the reference's way.
         const double ax = fabs(lkb_arg);
         double lkb = lkb_arg;
-        if (!(ax == 0.0 || (ax >= 1.0e-7 && ax <= 700.0))) {
+        if (wave_pred<UNI>(!(ax == 0.0 || (ax >= 1.0e-7 && ax <= 700.0)))) {
             if (!have_kb) Kb = fexp(lkb_arg);
             lkb = flog(Kb);
         }
@@ -1193,12 +1203,12 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
     const double tdrain_out = SPL_MAX(td_arg, 0.0);
 
     // :1488-1506
-    sm += (q_in_f);
-    if (sm > c.SAT) {
-        ro_d += (sm - c.SAT);
-        sm = c.SAT;
-    } else if (sm < c.RES) {
-        sm = c.RES;
+    {
+        const double sm_in = sm + (q_in_f);
+        const bool over1 = sm_in > c.SAT;
+        const double ro_more = ro_d + (sm_in - c.SAT);
+        ro_d = over1 ? ro_more : ro_d;
+        sm = over1 ? c.SAT : ((sm_in < c.RES) ? c.RES : sm_in);
     }
     const double ro = ro_d + ro_h;
 
@@ -1208,19 +1218,17 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
 #if defined(SPL_ABLATE) && SPL_ABLATE == 13
     if (false) {
 #else
-    if (sm != sm1) {
+    if (wave_pred<UNI>(sm != sm1)) {
 #endif
         SPL_SITE();
-        T_uns2 = transmittance_uns(c, Ksat_visc, sm, Acs2);
+        T_uns2 = transmittance_uns<UNI>(c, Ksat_visc, sm, Acs2);
     }
     const double T2 = (Ksat_visc * 24.0 * (Acs2 * c.inv_Ai) + T_uns2) * hyd_grad_out;
 
     // :1552-1567
-    sm -= (T2);
-    if (sm > c.SAT) {
-        sm = c.SAT;
-    } else if (sm < c.RES) {
-        sm = c.RES;
+    {
+        const double sm_out = sm - (T2);
+        sm = (sm_out > c.SAT) ? c.SAT : ((sm_out < c.RES) ? c.RES : sm_out);
     }
     // :1574
     const double mx = SPL_MAX(q_in_o, q_in_f);

@@ -24,8 +24,12 @@
 using namespace splash;
 using namespace splash::host;
 
-// (Environment knobs: splash::host::knobs(), sampled at every call's entry on the caller's thread --
-// tests flip them inside one process; no thread of this file calls getenv.)
+// (Environment knobs: sampled ONCE per call, on the caller's thread, when the call enters the library -- tests flip
+// them inside one process.  The snapshot travels with the call: GridPlan::kn, installed by a KnobScope on every
+// thread that works for it (the job thread of splash_grid_submit, per-device workers, lanes, delivery helpers), so
+// that the public splash_dev_* stages a lane calls find the call's knobs instead of reading the environment again
+// -- round 6, ADVICE r05: round 5's snapshot was re-read by those stages on the lanes' threads.  No thread of this
+// file calls getenv, and a job in flight keeps the knobs it was submitted with.)
 
 // Mapping the caller's (typically freshly allocated) result arrays before the device->host copies
 // reach them: columns [c0, c0+ncols) of every row of the [nrows][N] arrays of `esz`-byte elements, on a
@@ -45,15 +49,14 @@ using namespace splash::host;
 #define MADV_POPULATE_WRITE 23
 #endif
 
-static void prefault_outputs(void* const* bufs, const int* esz, int nbuf, size_t N, size_t c0, size_t ncols,
-                             size_t nrows)
+static void prefault_outputs(const Knobs& kn, void* const* bufs, const int* esz, int nbuf, size_t N, size_t c0,
+                             size_t ncols, size_t nrows, size_t block_bytes)
 {
-    const Knobs kn = knobs();
     const int mode = kn.prefault_mode;
     if (mode == PREFAULT_OFF || ncols == 0 || nrows == 0) return;
     size_t bytes = 0;
     for (int k = 0; k < nbuf; k++) bytes += bufs[k] ? ncols * nrows * (size_t)esz[k] : 0;
-    if (bytes < kn.prefault_min_bytes) return; // small: not worth threads
+    if (block_bytes < kn.prefault_min_bytes) return; // small: not worth threads (the whole block's bytes decide)
     if (const size_t ms = kn.prefault_delay_ms) // test aid: let the other lanes deliver first
         std::this_thread::sleep_for(std::chrono::milliseconds(ms));
     const size_t page = (size_t)sysconf(_SC_PAGESIZE);
@@ -112,7 +115,29 @@ struct GridPlan {
     bool want_diag;
     double mem_fraction; // share of the device's free memory one worker may plan with
     bool resume;         // (ABI 5) in->state0: no spin-up, run_all starts from the caller's state
+    Knobs kn;            // the environment knobs of the call: sampled once, on the caller's thread, when the call
+                         // entered the library; every thread that works for the call installs them (KnobScope)
 };
+
+// maximal runs of consecutive grid cells in idx[0, nb) (idx ascending): fn(j0, len) -- the dense fast paths copy
+// columns [idx[j0], idx[j0] + len) of the caller's arrays with one strided copy per run.  One run when the block
+// is one contiguous range (a one-device call on a grid without NA cells); with several devices a worker's list
+// is a round-robin deal of chunks, and a block holds a few of them.
+template <class F>
+void for_runs(const size_t* idx, size_t nb, F fn)
+{
+    if (nb == 0) return;
+    if (idx[nb - 1] - idx[0] == nb - 1) { // ascending and gap-free
+        fn((size_t)0, nb);
+        return;
+    }
+    size_t j0 = 0;
+    for (size_t j = 1; j <= nb; j++)
+        if (j == nb || idx[j] != idx[j - 1] + 1) {
+            fn(j0, j - j0);
+            j0 = j;
+        }
+}
 
 inline void put_value(const GridPlan& P, int k, size_t at, double v)
 {
@@ -226,7 +251,8 @@ struct Lane {
 struct Worker {
     const GridPlan& P;
     int device;
-    size_t v0, v1, nb_max;
+    const size_t* widx; // the worker's valid cells (grid cell of its j-th cell), ascending
+    size_t nwv, nb_max; // how many; cells per block
     splash_calendar* cal = nullptr;
     bool f32;
     Pool pool;
@@ -247,14 +273,15 @@ struct Worker {
     std::vector<int> ppass_h;
     double t_pool[3] = {0, 0, 0};
 
-    Worker(const GridPlan& P_, int dev, size_t a, size_t b) : P(P_), device(dev), v0(a), v1(b), nb_max(0)
+    Worker(const GridPlan& P_, int dev, const size_t* cells, size_t ncells)
+        : P(P_), device(dev), widx(cells), nwv(ncells), nb_max(0)
     {
         f32 = (P.in->sw_in == nullptr);
-        trace = knobs().trace;
+        trace = P.kn.trace;
     }
     ~Worker() { splash_calendar_destroy(cal); }
 
-    size_t nblocks() const { return (v1 - v0 + nb_max - 1) / nb_max; }
+    size_t nblocks() const { return (nwv + nb_max - 1) / nb_max; }
     // slots of a lane's buffer for late cells finished in place (late_fallback): part of the sizing
     static size_t late_slots(size_t nb) { return std::min<size_t>(nb, (size_t)1 << 14); }
     int lane_fail(Lane& L, int code, const char* what, hipError_t e)
@@ -292,6 +319,7 @@ struct Worker {
 
 int Worker::run_lane(int li)
 {
+    KnobScope knobs_of_the_call(P.kn); // this thread calls public stages (splash_dev_*): no getenv here
     Lane& L = lanes[li];
     if (hipSetDevice(device) != hipSuccess) {
         lane_fail(L, SPLASH_ENODEV, "hipSetDevice", hipErrorInvalidDevice);
@@ -336,9 +364,11 @@ int Worker::run_block(Lane& L, size_t k)
     const int nt = P.nt, nt_out = P.nt_out;
     hipStream_t s = L.st.s;
     const double t_a = now_s();
-    const size_t b0 = v0 + k * nb_max, nb = std::min(nb_max, v1 - b0);
-    const size_t* idx = P.idx + b0; // idx[j] = grid cell of the block's j-th cell
-    const size_t c0 = idx[0];       // dense: the block is cells [c0, c0+nb)
+    const size_t b0 = k * nb_max, nb = std::min(nb_max, nwv - b0); // cells [b0, b0+nb) of the worker's list
+    const size_t* idx = widx + b0;  // idx[j] = grid cell of the block's j-th cell
+    // dense: the block is a few runs of consecutive grid cells (one, when one device works on the grid)
+    std::vector<std::pair<size_t, size_t>> runs;
+    if (P.dense) for_runs(idx, nb, [&](size_t j0, size_t len) { runs.emplace_back(j0, len); });
     double* F = L.d_force.as<double>();
     double* ddst[3] = {F, F + (size_t)nt * nb, F + (size_t)2 * nt * nb};
     double *dsw = ddst[0], *dtc = ddst[1], *dpn = ddst[2];
@@ -348,8 +378,9 @@ int Worker::run_block(Lane& L, size_t k)
         if (!f32) {
             const double* hsrc = v == 0 ? in->sw_in : (v == 1 ? in->tc : in->pn);
             if (P.dense) {
-                LANE_TRY(hipMemcpy2DAsync(ddst[v], nb * 8, hsrc + c0, N * 8, nb * 8, (size_t)nt,
-                                          hipMemcpyHostToDevice, s));
+                for (const auto& r : runs)
+                    LANE_TRY(hipMemcpy2DAsync(ddst[v] + r.first, nb * 8, hsrc + idx[r.first], N * 8, r.second * 8,
+                                              (size_t)nt, hipMemcpyHostToDevice, s));
             } else {
                 double* stg = L.stage.data();
                 parallel_rows((size_t)nt, nb * 8, [=](size_t t) {
@@ -362,8 +393,9 @@ int Worker::run_block(Lane& L, size_t k)
         } else { // single-precision transport, widened on the device (lossless for FLT4S rasters)
             const float* hsrc = v == 0 ? in->sw_in_f32 : (v == 1 ? in->tc_f32 : in->pn_f32);
             if (P.dense) {
-                LANE_TRY(hipMemcpy2DAsync(L.d_f32.p, nb * 4, hsrc + c0, N * 4, nb * 4, (size_t)nt,
-                                          hipMemcpyHostToDevice, s));
+                for (const auto& r : runs)
+                    LANE_TRY(hipMemcpy2DAsync(L.d_f32.as<float>() + r.first, nb * 4, hsrc + idx[r.first], N * 4,
+                                              r.second * 4, (size_t)nt, hipMemcpyHostToDevice, s));
             } else {
                 float* stg = L.stage32.data();
                 parallel_rows((size_t)nt, nb * 4, [=](size_t t) {
@@ -408,10 +440,13 @@ int Worker::run_block(Lane& L, size_t k)
     double* Tt = L.d_tt.as<double>();
     LANE_RC(splash_dev_soil_hydro(nb, S, S + nb, S + 2 * nb, S + 3 * nb, S + 4 * nb, S + 5 * nb,
                                   in->au ? S + 11 * nb : nullptr, par, s));
+    // (hsmall holds 7 rows: the three small uploads of a block -- tt, state0, ai0 -- have DISJOINT regions, so that
+    //  none is refilled while a copy out of it may still be in flight, whatever the runtime does with a pageable
+    //  source)
     if (in->tt) { // the threshold of the WHOLE series, from the caller (time chunks: include/splash_hip.h)
         for (size_t j = 0; j < nb; j++) L.hsmall[j] = in->tt[idx[j]];
-        LANE_TRY(hipMemcpyAsync(Tt, L.hsmall.data(), nb * 8, hipMemcpyHostToDevice, s)); // (pageable: returns when
-    } else {                                                                              //  the source may be reused)
+        LANE_TRY(hipMemcpyAsync(Tt, L.hsmall.data(), nb * 8, hipMemcpyHostToDevice, s));
+    } else {
         LANE_RC(splash_dev_snow_threshold(nb, nt, dtc, nb, par, nb, Tt, s));
     }
     int* dpass = out->aux ? L.d_pass.as<int>() : nullptr;
@@ -420,11 +455,12 @@ int Worker::run_block(Lane& L, size_t k)
     if (P.resume) {
         // continuing a run: the caller's state and the aridity index of the run's spin-up stand where the
         // spin-up's results would (cellout := AI, R/splash.point.R:150); nothing is left for the pool
+        double* const h_state = L.hsmall.data() + nb_max, * const h_ai = L.hsmall.data() + 6 * nb_max;
         for (int kk = 0; kk < 5; kk++)
-            for (size_t j = 0; j < nb; j++) L.hsmall[(size_t)kk * nb + j] = in->state0[(size_t)kk * N + idx[j]];
-        LANE_TRY(hipMemcpyAsync(state, L.hsmall.data(), 5 * nb * 8, hipMemcpyHostToDevice, s));
-        for (size_t j = 0; j < nb; j++) L.hsmall[j] = in->ai0[idx[j]];
-        LANE_TRY(hipMemcpyAsync(par + (size_t)P_CELLOUT * nb, L.hsmall.data(), nb * 8, hipMemcpyHostToDevice, s));
+            for (size_t j = 0; j < nb; j++) h_state[(size_t)kk * nb + j] = in->state0[(size_t)kk * N + idx[j]];
+        LANE_TRY(hipMemcpyAsync(state, h_state, 5 * nb * 8, hipMemcpyHostToDevice, s));
+        for (size_t j = 0; j < nb; j++) h_ai[j] = in->ai0[idx[j]];
+        LANE_TRY(hipMemcpyAsync(par + (size_t)P_CELLOUT * nb, h_ai, nb * 8, hipMemcpyHostToDevice, s));
         LANE_TRY(hipMemsetAsync(L.d_res.p, 0, 64, s));
         if (dpass) LANE_TRY(hipMemsetAsync(dpass, 0, 2 * nb * sizeof(int), s));
         LANE_TRY(hipEventRecord(L.ev_gather.e, s));
@@ -451,7 +487,7 @@ int Worker::run_block(Lane& L, size_t k)
         g.passes = dpass;
         g.ntotal = nb;
         g.basin = with_basin ? L.d_basin.as<int>() : nullptr;
-        g.origin0 = (uint64_t)(b0 - v0);
+        g.origin0 = (uint64_t)b0; // position in the worker's list
         g.cap = pool.cap;
         g.p_sw = pool.sw();
         g.p_tc = pool.sw() + (size_t)nt * pool.cap;
@@ -498,10 +534,14 @@ int Worker::run_block(Lane& L, size_t k)
     // neighbouring block's results at this moment, and a page-touching write outside the block's own
     // columns would race with them (see prefault_outputs).
     if (P.dense) {
-        if (knobs().test_prefault_whole_range) // fault injection for the regression test ONLY: the
-            prefault_outputs(P.dst, P.esz, SPLASH_NOUT, N, P.idx[v0], v1 - v0, (size_t)nt_out); // range of the first version
+        size_t blk_bytes = 0; // the block's share of the result arrays decides whether mapping pays, not a run's
+        for (int kk = 0; kk < SPLASH_NOUT; kk++) blk_bytes += P.dst[kk] ? nb * (size_t)nt_out * (size_t)P.esz[kk] : 0;
+        if (P.kn.test_prefault_whole_range) // fault injection for the regression test ONLY: the range of the
+            prefault_outputs(P.kn, P.dst, P.esz, SPLASH_NOUT, N, widx[0], widx[nwv - 1] - widx[0] + 1, (size_t)nt_out, // first version
+                             (size_t)-1);
         else
-            prefault_outputs(P.dst, P.esz, SPLASH_NOUT, N, c0, nb, (size_t)nt_out);
+            for (const auto& r : runs)
+                prefault_outputs(P.kn, P.dst, P.esz, SPLASH_NOUT, N, idx[r.first], r.second, (size_t)nt_out, blk_bytes);
     }
     const double t_c = now_s();
     LANE_TRY(hipStreamSynchronize(s));
@@ -533,6 +573,7 @@ int Worker::run_block(Lane& L, size_t k)
     } else {
         L.d2h_rc = SPLASH_OK;
         L.d2h = std::thread([this, &L, b0, nb, dout] {
+            KnobScope knobs_of_the_call(P.kn);
             (void)hipSetDevice(device);
             L.d2h_rc = deliver(L, b0, nb, dout);
         });
@@ -554,8 +595,7 @@ int Worker::deliver(Lane& L, size_t b0, size_t nb, splash_dev_out dout)
 {
     const size_t N = P.N;
     const int nt_out = P.nt_out;
-    const size_t* idx = P.idx + b0;
-    const size_t c0 = idx[0];
+    const size_t* idx = widx + b0;
     const double t0 = now_s();
     for (int kk = 0; kk < SPLASH_NOUT; kk++) {
         if (!P.dst[kk]) continue;
@@ -564,9 +604,13 @@ int Worker::deliver(Lane& L, size_t b0, size_t nb, splash_dev_out dout)
         const char* dsrc = e8 == 8 ? (const char*)dout.out[kk]
                                    : (const char*)L.d_o32.p + (size_t)(dout.out[kk] - L.d_out.as<double>()) * 4;
         char* const dsth = (char*)P.dst[kk];
-        hipError_t e;
+        hipError_t e = hipSuccess;
         if (P.dense) {
-            e = hipMemcpy2D(dsth + c0 * e8, N * e8, dsrc, nb * e8, nb * e8, (size_t)nt_out, hipMemcpyDeviceToHost);
+            for_runs(idx, nb, [&](size_t j0, size_t len) {
+                if (e == hipSuccess)
+                    e = hipMemcpy2D(dsth + idx[j0] * e8, N * e8, dsrc + j0 * e8, nb * e8, len * e8, (size_t)nt_out,
+                                    hipMemcpyDeviceToHost);
+            });
         } else {
             char* stg = L.stage_out.data();
             e = hipMemcpy(stg, dsrc, (size_t)nt_out * nb * e8, hipMemcpyDeviceToHost);
@@ -599,7 +643,7 @@ int Worker::late_fallback(Lane& L, size_t b0, size_t nb, const splash_dev_out& d
     const splash_grid_out* out = P.out;
     const size_t N = P.N;
     const int nt = P.nt, nt_out = P.nt_out, n_out = P.n_out;
-    const size_t* idx = P.idx + b0;
+    const size_t* idx = widx + b0;
     hipStream_t s = L.st.s;
     double* F = L.d_force.as<double>();
     double *dsw = F, *dtc = F + (size_t)nt * nb, *dpn = F + (size_t)2 * nt * nb;
@@ -734,7 +778,7 @@ void Worker::patch_pool()
     const splash_grid_out* out = P.out;
     const size_t N = P.N, np = n_pool;
     const int nt_out = P.nt_out;
-    const size_t* idx = P.idx + v0;
+    const size_t* idx = widx;
     const uint64_t* org = origin.data();
     int q = 0;
     for (int k = 0; k < SPLASH_NOUT; k++) {
@@ -765,21 +809,21 @@ void Worker::patch_pool()
     t_pool[2] = now_s() - t0;
 }
 
-// Valid cells [v0, v1) on `device`, in HBM-sized blocks dealt to the lanes.  `share` = workers using
-// this device (they split its free memory).  acc: this worker's host copy of the exact diagnostic
-// limbs (summed by the caller).
-int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, int64_t* acc,
+// The valid cells cells[0, ncells) (grid cell ids, ascending) on `device`, in HBM-sized blocks dealt to the lanes.
+// `share` = workers using this device (they split its free memory).  acc: this worker's host copy of the exact
+// diagnostic limbs (summed by the caller).
+int grid_worker(const GridPlan& P, int device, int share, const size_t* cells, size_t ncells, int64_t* acc,
                 char* err, size_t errlen)
 {
     const splash_grid_in* in = P.in;
     const int nt = P.nt, nt_out = P.nt_out, n_out = P.n_out;
     HIP_TRY(hipSetDevice(device), err, errlen);
-    if (v1 <= v0) return SPLASH_OK;
-    Worker W(P, device, v0, v1);
+    if (ncells == 0) return SPLASH_OK;
+    Worker W(P, device, cells, ncells);
     if (int rc = splash_calendar_create(nt, in->doy, in->year, in->month, &W.cal, err, errlen)) return rc;
     const bool f32 = W.f32;
     const double t_w0 = now_s();
-    const size_t want = v1 - v0;
+    const size_t want = ncells;
     // Lanes: two keep the link and the GPU busy when the results are the bulk of the traffic (daily outputs in
     // double precision: device->host is the bottleneck and a third lane only adds blocks); a call whose results are
     // light -- monthly outputs, or daily ones in single precision -- is bound by its kernels, and a third lane
@@ -789,7 +833,7 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
     for (int k = 0; k < SPLASH_NOUT; k++) out_bytes_cell += P.dst[k] ? (size_t)nt_out * (size_t)P.esz[k] : 0;
     const size_t in_bytes_cell = (size_t)nt * 3 * (f32 ? 4 : 8);
     int n_lanes = out_bytes_cell <= 2 * in_bytes_cell ? 3 : 2;
-    const Knobs kn = knobs();
+    const Knobs& kn = P.kn;
     if (kn.lanes > 0) n_lanes = kn.lanes;
     const size_t acc_bytes = splash_dev_diag_acc_size(P.n_basin, P.nmonth);
     {
@@ -876,7 +920,7 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
             HIP_TRY(L.d_res.alloc(64), err, errlen);
             if (P.want_diag && in->basin) HIP_TRY(L.d_basin.alloc(nb_max * sizeof(int32_t)), err, errlen);
             L.hstat.resize((size_t)14 * nb_max);
-            if (P.out->state_end || P.out->aux || in->tt || P.resume) L.hsmall.resize(5 * nb_max);
+            if (P.out->state_end || P.out->aux || in->tt || P.resume) L.hsmall.resize(7 * nb_max);
             if (P.out->aux) L.hpass.resize(2 * nb_max);
             if (in->basin && P.want_diag) L.hbasin.resize(nb_max);
             if (!P.dense) {
@@ -924,8 +968,9 @@ int grid_worker(const GridPlan& P, int device, int share, size_t v0, size_t v1, 
 // the call itself, on whatever thread runs it (the caller's, or the job thread of splash_grid_submit:
 // the environment knobs were sampled by the entry point, on the caller's thread)
 static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const splash_grid_out* out, char* err,
-                         size_t errlen)
+                         size_t errlen, const Knobs& kn_call)
 {
+    KnobScope knobs_of_the_call(kn_call); // (the job thread of splash_grid_submit: no getenv, the submitter's knobs)
     if (!in || !out) return fail(SPLASH_EINVAL, err, errlen, "grid_run: NULL in/out");
     const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     const bool f64 = in->sw_in && in->tc && in->pn;
@@ -964,6 +1009,7 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
                         ndev_present);
 
     GridPlan P{};
+    P.kn = kn_call;
     P.in = in;
     P.out = out;
     P.N = in->ncell;
@@ -1057,19 +1103,37 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
     if (P.nv == 0) return SPLASH_OK;
 
     const double t_scan = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    // contiguous ranges of equal valid-cell count, one per worker (cells are independent: the
-    // split changes nothing in the results, totals included -- they are exact integer sums)
+    // One worker per listed device.  Round 6: the valid cells are cut into CHUNKS that are dealt round-robin
+    // (worker w owns chunks w, w + nw, ...), not into one contiguous range per worker: cells are in raster order, so
+    // a contiguous range is a latitude band, the day step costs ~5 % more at low latitudes and the spin-up's pass
+    // counts vary with climate -- the equatorial worker would finish last (what bench.py's ranks avoid the same way:
+    // rsplash_amd/dist.py::row_blocks_round_robin).  About sixteen chunks per worker, 256 cells at least, 2^17 at
+    // most; a worker's list keeps the raster order, so its blocks stay a few runs of consecutive cells (for_runs).
+    // Cells are independent: the split changes nothing in the results, totals included -- exact integer sums.
     const int nw = (int)devs.size();
+    std::vector<std::vector<size_t>> wcells(nw > 1 ? nw : 0);
+    if (nw > 1) {
+        size_t chunk = (P.nv + (size_t)nw * 16 - 1) / ((size_t)nw * 16);
+        chunk = std::min<size_t>(std::max<size_t>(chunk, 1), (size_t)1 << 17);
+        chunk = (chunk + 255) & ~(size_t)255;
+        for (int w = 0; w < nw; w++) wcells[w].reserve(P.nv / nw + chunk);
+        size_t j = 0;
+        for (size_t v0 = 0; v0 < P.nv; v0 += chunk, j++) {
+            std::vector<size_t>& dst = wcells[j % (size_t)nw];
+            dst.insert(dst.end(), P.idx + v0, P.idx + std::min(P.nv, v0 + chunk));
+        }
+    }
     std::vector<std::vector<int64_t>> acc(nw);
     std::vector<int> rcs(nw, 0);
     std::vector<std::string> msgs(nw);
     auto run = [&](int w) {
-        const size_t v0 = P.nv * (size_t)w / nw, v1 = P.nv * (size_t)(w + 1) / nw;
+        KnobScope knobs_of_the_call(P.kn);
         int share = 0;
         for (int d : devs) share += (d == devs[w]);
         if (P.want_diag) acc[w].assign(n_rec * SPLASH_DIAG_REC, 0);
         char buf[512] = "";
-        rcs[w] = grid_worker(P, devs[w], share, v0, v1, acc[w].data(), buf, sizeof buf);
+        rcs[w] = nw > 1 ? grid_worker(P, devs[w], share, wcells[w].data(), wcells[w].size(), acc[w].data(), buf, sizeof buf)
+                        : grid_worker(P, devs[w], share, P.idx, P.nv, acc[w].data(), buf, sizeof buf);
         msgs[w] = buf;
     };
     // Large result arrays (daily outputs: tens of GB) are page-locked while the first blocks load and
@@ -1094,7 +1158,7 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
         for (int k = 0; k < SPLASH_NOUT; k++) total += P.dst[k] ? elems_each * (size_t)P.esz[k] : 0;
         // SPLASH_HIP_REGISTER_MIN_BYTES: result bytes from which registering pays (tests set 0 to run the
         // path on small grids); SPLASH_HIP_NO_REGISTER=1 disables it
-        const Knobs kn = knobs();
+        const Knobs& kn = P.kn;
         if (!kn.no_register && P.dense && total >= kn.register_min_bytes) {
             const int dev0 = devs[0];
             // the forcing too (both directions must be page-locked for the copies to overlap), first:
@@ -1133,7 +1197,7 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
         if (out->diag_acc) std::copy(total.begin(), total.end(), out->diag_acc);
         if (out->diag) splash_diag_finalize_host(total.data(), P.n_basin, P.nmonth, out->diag, nullptr);
     }
-    if (knobs().trace) {
+    if (P.kn.trace) {
         const double t_end = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
         fprintf(stderr, "[splash] grid_run: NA scan %.3f s, workers %.3f s, total %.3f s\n", t_scan - t_enter,
                 t_end - t_scan, t_end - t_enter);
@@ -1145,7 +1209,7 @@ extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
                                const splash_grid_out* out, char* err, size_t errlen)
 {
     knobs_refresh();
-    return grid_run_impl(in, opt, out, err, errlen);
+    return grid_run_impl(in, opt, out, err, errlen, knobs());
 }
 
 struct splash_grid_job {
@@ -1157,6 +1221,7 @@ struct splash_grid_job {
     std::thread th;
     int rc = SPLASH_OK;
     char msg[512] = "";
+    Knobs kn; // the submitter's knobs at submit time: the job keeps them whatever the environment does meanwhile
 };
 
 extern "C" int splash_grid_submit(const splash_grid_in* in, const splash_opts* opt, const splash_grid_out* out,
@@ -1176,7 +1241,8 @@ extern "C" int splash_grid_submit(const splash_grid_in* in, const splash_opts* o
         }
     }
     try {
-        j->th = std::thread([j] { j->rc = grid_run_impl(&j->in, j->has_opt ? &j->opt : nullptr, &j->out, j->msg, sizeof j->msg); });
+        j->kn = knobs();
+        j->th = std::thread([j] { j->rc = grid_run_impl(&j->in, j->has_opt ? &j->opt : nullptr, &j->out, j->msg, sizeof j->msg, j->kn); });
     } catch (...) {
         delete j;
         return fail(SPLASH_ENOMEM, err, errlen, "grid_submit: could not start a host thread");

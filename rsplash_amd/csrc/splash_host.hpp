@@ -31,7 +31,11 @@ int enter_device(char* err, size_t errlen); // knobs_refresh() + need_device(): 
 // ever called on the thread that ENTERS the library (knobs_refresh(), first statement of the public
 // entry points that start work): lane, pool and helper threads read the snapshot, so no thread of
 // the library reads the environment while the caller's thread may be changing it between calls.
-// A job in flight (splash_grid_submit) sees the snapshot of the latest entry.
+// A call (or a job in flight, splash_grid_submit) KEEPS the knobs it started with: the entry point copies the
+// snapshot, and every thread that works for the call -- the job thread, per-device workers, lanes, delivery
+// helpers -- installs that copy with a KnobScope; under a scope knobs() returns the copy and knobs_refresh() (which
+// the public splash_dev_* stages call when a lane uses them) is a no-op (round 6, ADVICE r05: those stages
+// re-read the environment on lane threads, the very race the snapshot was introduced against).
 struct Knobs {
     bool no_pool = false;              // SPLASH_HIP_NO_POOL
     long spin_cache_cap = 0;           // SPLASH_HIP_SPIN_CACHE_CAP (frozen at the first entry: the workspace layout depends on it)
@@ -39,6 +43,7 @@ struct Knobs {
     bool no_nd_skip = false;           // SPLASH_HIP_NO_ND_SKIP
     bool no_block_phase1 = false;      // SPLASH_HIP_NO_BLOCK_PHASE1
     bool no_solo_tail = false;         // SPLASH_HIP_NO_SOLO_TAIL
+    bool no_uniform_tail = false;      // SPLASH_HIP_NO_UNIFORM_TAIL (A/B, tests: no wave-uniform variant for one-job wavefronts)
     int tail_stage[2] = {-1, -1};      // SPLASH_HIP_TAIL_STAGES="a,b"
     int tail_lds_pad = 57344;          // SPLASH_HIP_TAIL_LDS_PAD
     int prefault_mode = 0;             // SPLASH_HIP_PREFAULT (populate | touch | off)
@@ -56,8 +61,19 @@ struct Knobs {
     size_t register_min_bytes = (size_t)8 << 30; // SPLASH_HIP_REGISTER_MIN_BYTES
 };
 enum { PREFAULT_POPULATE = 0, PREFAULT_TOUCH = 1, PREFAULT_OFF = 2 };
-void knobs_refresh(); // the calling thread of a public entry point
-Knobs knobs();        // the snapshot (any thread)
+void knobs_refresh(); // the calling thread of a public entry point (no-op under a KnobScope)
+Knobs knobs();        // the snapshot (any thread); the scope's copy under a KnobScope
+// installs `k` as the calling thread's knobs for the scope's lifetime (nests: the previous one comes back)
+class KnobScope {
+public:
+    explicit KnobScope(const Knobs& k);
+    ~KnobScope();
+    KnobScope(const KnobScope&) = delete;
+    KnobScope& operator=(const KnobScope&) = delete;
+private:
+    Knobs mine_;
+    const Knobs* prev_;
+};
 
 // device buffers of the host-buffer entry points are kept between calls (splash_capi.hip)
 hipError_t pool_alloc(void** out, size_t bytes);

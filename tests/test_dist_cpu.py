@@ -160,6 +160,9 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     coll = d.pop("collective")
+    # the per-rank table of the line (`ranks`: cells, ms per step, tail seconds ... of EVERY rank)
+    # is put together by one sum all-reduce of a table each rank fills one line of: rehearsed with pretend figures
+    assert d.pop("ranks") == {"cells": [100, 200, 300], "rank": [0, 1, 2]}
     assert d == {"dryrun": True, "n_gpus": 3, "sum_of_ranks": 6.0}
     # the line says what the process group itself saw, not just WORLD_SIZE from the environment
     assert coll["backend"] == "gloo" and coll["world_size"] == 3 and coll["bytes"] == 8

@@ -5,8 +5,6 @@
 #   gpurun -- 'bash tools/site_profile.sh > gpurun_out/sites.txt'
 set -e
 cd "$(dirname "$0")/.."
-cp rsplash_amd/librsplash_hip.so /tmp/librsplash_hip.product.so
-(cd rsplash_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function \
-    -DSPL_SITES -shared -o ../librsplash_hip.so splash_kernels.hip splash_statics.hip splash_capi.hip splash_grid_host.hip)
-python bench.py --rows 512 --steps 1 --warmup 0 --cpu-seconds 0 2>&1 >/dev/null | grep SITE | tail -40 || true
-cp /tmp/librsplash_hip.product.so rsplash_amd/librsplash_hip.so
+# (the Makefile's own source list: `make variant`; the product library is not touched)
+make -s -C rsplash_amd/csrc variant NAME=sites EXTRA=-DSPL_SITES
+SPLASH_HIP_LIBRARY=$PWD/gpurun_ab/lib_sites.so python bench.py --rows 512 --steps 1 --warmup 0 --cpu-seconds 0 2>&1 >/dev/null | grep SITE | tail -40 || true
