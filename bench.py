@@ -254,22 +254,41 @@ def base_line(ctx, value, steps, warmup, dt, workload, extra_cfg):
             "config": cfg}
 
 
+def kernel_sources_sha16():
+    """sha256 (first 16 hex digits) of the kernels' sources: the PMC figures of profiles/traffic.json carry the hash of
+    the sources they were measured on, so a stale constant shows in the line"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "rsplash_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "rsplash_amd", "csrc", "*.hpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def roofline(avg_launch_s, units_per_launch, key, kernel):
     achieved = ALG_BYTES_PER_CELL_DAY * units_per_launch / avg_launch_s / 1e9
     traffic = valu_busy = None
+    stamp = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             valu_busy = tj.get(key, {}).get("valu_busy_frac")
+            stamp = tj.get(key, {}).get("kernel_sources_sha16")
         except Exception:
             traffic = None
+    now = kernel_sources_sha16()
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_measured_on_these_kernel_sources": None if traffic is None else bool(stamp == now),
+            "kernel_sources_sha16": now,
             "traffic_source": None if traffic is None else
             "profiles/traffic.json: separate rocprofv3 --pmc passes of this command on an earlier run "
-            "(tools/pmc_fetch.sh), not measured in this run; so is valu_busy_frac",
+            "(tools/profile_round.sh), not measured in this run; so is valu_busy_frac.  The file carries the hash of "
+            "the kernel sources it was measured on (traffic_measured_on_these_kernel_sources)",
             "frac_of_measured_copy_rate": achieved / HBM_COPY_GBS, "kernel": kernel,
             "avg_launch_ms": avg_launch_s * 1e3, "units_per_launch": units_per_launch,
             "alg_bytes_per_unit": ALG_BYTES_PER_CELL_DAY, "valu_busy_frac": valu_busy,
@@ -494,7 +513,7 @@ def run_resident(ctx):
     # rank 0 (at any N): CPU baseline on a bounded sample of ITS cells + the parity figures of the same
     # sample; the other ranks wait at the barrier so that the group is torn down together
     if rank == 0 and args.cpu_seconds > 0:
-        cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp, W, chunks, Htot)
+        cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp, W, chunks, Htot, par0_cellout)
     if world > 1:
         ctx["dist"].barrier()
     cal.close()
@@ -511,7 +530,7 @@ def sample_bands(n, W, cells_wanted, nbands=8):
     return [(int(round(i * (rows - rb) / (nbands - 1))) * W, rb * W) for i in range(nbands)]
 
 
-def cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp, W, chunks, Htot):
+def cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp, W, chunks, Htot, par0_cellout):
     """CPU baseline (the oracle's transient loop on the host cores) on a bounded sample of the same
     workload, and the parity figures of the GPU results on that sample (rank 0 only).  The sample is
     eight bands of whole rows spread over the rank's rows -- every latitude band of the grid, not its
@@ -652,10 +671,8 @@ def cpu_leg(ctx, line, cal, dates, sw, tc, pn, par, Tt, state0, n, nt, bn, sp, W
     # count the passes of spin-up #1); its state and aridity index must be the grid run's, bit for bit
     cat = lambda x: torch.cat([x[..., c0:c0 + nc] for c0, nc in sel], dim=-1).contiguous()
     d_sw, d_tc, d_pn, d_Tt = cat(sw), cat(tc), cat(pn), cat(Tt)
-    d_st = {k: torch.tensor(v, **f64) for k, v in st_h.items()}
-    d_par = torch.empty(api.NPAR, ns3, **f64)
-    api.dev_soil_hydro(ns3, d_st["lat"], d_st["elev"], d_st["slop"], d_st["asp"], d_st["resolution"], d_st["soil"],
-                       d_st["au"], d_par, sp)
+    d_par = cat(par).clone()                 # the grid run's own cell parameters (the device generator's statics) ...
+    d_par[15] = cat(par0_cellout)            # ... with ncellout as it was before the spin-up wrote the aridity index there
     d_state = torch.empty(api.NSTATE, ns3, **f64)
     d_pass = torch.zeros(2, ns3, dtype=torch.int32, device=ctx["dev"])
     d_work = torch.empty(api.spin_up_work_size(ns3), dtype=torch.uint8, device=ctx["dev"])

@@ -25,7 +25,9 @@ inline void check(int rc, const char* what)
 
 class SPLASH {
   public:
-    SPLASH(double lat, double elv) : lat_(lat), elv_(elv) {} // src/SPLASH.cpp:90
+    // src/SPLASH.cpp:90.  backend (ABI 6): SPLASH_BACKEND_HIP (default) or SPLASH_BACKEND_HOST -- where this object's
+    // methods compute; the library keeps the choice per calling thread and every method sets it first.
+    SPLASH(double lat, double elv, int backend = SPLASH_BACKEND_HIP) : lat_(lat), elv_(elv), backend_(backend) {}
 
     // src/SPLASH.cpp:1594 -> sm, snow, qin, tdrain, ro, snwage, pet (:1748)
     List spin_up(int n, int y, std::vector<double>& sw_in, std::vector<double>& tair,
@@ -33,6 +35,7 @@ class SPLASH {
                  std::vector<double>& soil_info) const
     {
         static const char* names[7] = {"sm", "snow", "qin", "tdrain", "ro", "snwage", "pet"};
+        enter();
         List out;
         double* p[7];
         for (int k = 0; k < 7; k++) p[k] = series(out, names[k], (size_t)n);
@@ -52,6 +55,7 @@ class SPLASH {
                  double nds_last) const
     {
         const int nt = (int)sw_in.size();
+        enter();
         List out;
         double* p[11];
         for (int k = 0; k < 11; k++) p[k] = series(out, kSeries[k], (size_t)nt);
@@ -70,6 +74,7 @@ class SPLASH {
                       std::vector<double>& soil_info, std::vector<double>& qin_vec,
                       std::vector<double>& td_vec, std::vector<double>& nds) const
     {
+        enter();
         List out;
         double* p[11];
         for (int k = 0; k < 11; k++) p[k] = series(out, kSeries[k], (size_t)n);
@@ -87,6 +92,7 @@ class SPLASH {
                       double lambda) const
     {
         double v = 0;
+        enter();
         check(splash_mod_moist_surf(depth, z, bub_p, wn, SAT, RES, lambda, &v), "SPLASH::moist_surf");
         return v;
     }
@@ -96,12 +102,17 @@ class SPLASH {
                   double P, double tdur, double slop) const
     {
         double v = 0;
+        enter();
         check(splash_mod_inf_GA(bub_press, theta_i, Ksat, theta_s, lambda, P, tdur, slop, &v),
               "SPLASH::inf_GA");
         return v;
     }
 
   private:
+    void enter() const
+    {
+        if (splash_mod_backend(backend_) < 0) check(SPLASH_EINVAL, "SPLASH: backend");
+    }
     static double* series(List& out, const char* name, size_t n)
     {
         std::vector<double>& v = out[name];
@@ -109,6 +120,7 @@ class SPLASH {
         return v.data();
     }
     double lat_, elv_;
+    int backend_;
     static constexpr const char* kSeries[11] = {"wn",   "ro",    "pet",  "aet",      "snow",  "cond",
                                                 "bflow", "netr", "qin_prev", "tdrain", "snwage"};
 };

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SPLASH_ABI_VERSION 5
+#define SPLASH_ABI_VERSION 6
 
 enum {
     SPLASH_OK = 0,
@@ -338,9 +338,11 @@ typedef struct {
     int device;         /* HIP device ordinal (used when n_devices <= 1 and devices == NULL) */
     size_t max_cells_per_launch; /* 0 = size blocks from free HBM */
     /* Multi-GPU inside one call (replaces the SOCK-cluster block scheduler of
-     * R/splash.grid.R:260-314, 359-400): the valid cells are cut into n_devices contiguous ranges
-     * of equal valid-cell count, one host thread + stream set per device.  devices == NULL means
-     * ordinals 0..n_devices-1; the same ordinal may appear more than once (two workers on one
+     * R/splash.grid.R:260-314, 359-400): the valid cells are cut into chunks (about sixteen per
+     * device, 256 cells at least) that are dealt round-robin to the listed devices -- every device
+     * sees every latitude band, so they finish together (round 6; a contiguous range per device left
+     * the low-latitude one behind) --, one host thread + stream set per device.  devices == NULL
+     * means ordinals 0..n_devices-1; the same ordinal may appear more than once (two workers on one
      * GPU).  Results are independent of the split, bit for bit, totals included. */
     int n_devices;
     const int* devices;
@@ -348,7 +350,17 @@ typedef struct {
      * caller that keeps several calls in flight on one device (splash_grid_submit) gives each its
      * share, e.g. 0.4 for two. */
     double mem_fraction;
+    /* (ABI 6) SPLASH_BACKEND_HIP (0, the default) or SPLASH_BACKEND_HOST: the same day step -- the
+     * product's own device functions compiled for the host, nothing else -- on CPU cores (one thread
+     * per few cells), for calls of one or a few cells: a single site is a chain of sequential day
+     * steps that one core steps through faster than a lone wavefront (BASELINE.json configs[0]: "CPU
+     * reference path (plumbing, no GPU)").  An explicit choice, never a fallback: with
+     * the default backend a machine without a HIP device gets SPLASH_ENODEV.  Host and device results
+     * agree to rounding (<= 1e-12 relative on the bundled sites), not to the bit. */
+    int backend;
 } splash_opts;
+#define SPLASH_BACKEND_HIP 0
+#define SPLASH_BACKEND_HOST 1
 
 typedef struct {
     double* out[SPLASH_NOUT]; /* caller-allocated [nt_out][ncell], NULL to skip */
@@ -402,7 +414,22 @@ int splash_point_run(int nt, const int* doy, const int* year, const int* month,
                      const double* au, int n_au, double resolution, int monthly_out,
                      double* const out[SPLASH_NOUT], char* err, size_t errlen);
 
+/* (ABI 6) the same with the backend chosen (SPLASH_BACKEND_HIP / SPLASH_BACKEND_HOST, see splash_opts.backend):
+ * what `splash.point(..., backend = "host")` of r/splash_hip.R binds.  splash_point_run IS this call with
+ * SPLASH_BACKEND_HIP. */
+int splash_point_run_backend(int backend, int nt, const int* doy, const int* year, const int* month,
+                             const double* sw_in, const double* tc, const double* pn, double lat,
+                             double elev, double slop, double asp, const double* soil_data /*[6]*/,
+                             const double* au, int n_au, double resolution, int monthly_out,
+                             double* const out[SPLASH_NOUT], char* err, size_t errlen);
+/* 1 when the host backend runs its build for cores with fused multiply-add (x86-64: AVX2 + FMA), 0 for the
+ * generic build; informational (timings) */
+int splash_host_backend_fma(void);
+
 /* ---------------------------------------------------------------- Rcpp-module mirrors ------ */
+/* (ABI 6) backend of the splash_mod_* calls of the CALLING THREAD (the reference's module object lives in
+ * one R process; SPLASH_BACKEND_HIP is the default): returns the previous setting, or SPLASH_EINVAL. */
+int splash_mod_backend(int backend);
 /* One-cell GPU evaluations with the argument lists of src/SPLASH.h:85-103 (host pointers).
  * soil_info has 12 (or 13) entries as built by R/splash.point.R:110-114. */
 int splash_mod_spin_up(double lat, double elv, int n, int y, const double* sw_in,

@@ -9,9 +9,13 @@
        month = as.integer(format(time_index, "%m")))   # :547
 }
 
+# backend = "hip" (default) or "host": a single site is a chain of sequential day steps that one CPU core steps
+# through faster than a lone wavefront; "host" runs the library's own day step compiled for the host
+# (include/splash_hip.h, ABI 6).  Never chosen for the caller: without a HIP device the default is an error.
 splash.point <- function(sw_in, tc, pn, lat, elev, slop = 0, asp = 0, soil_data, Au = 0,
                          resolution = 250, time_index = NULL, monthly_out = FALSE,
-                         ts_out = TRUE, verbose = TRUE) {
+                         ts_out = TRUE, verbose = TRUE, backend = c("hip", "host")) {
+  backend <- match(match.arg(backend), c("hip", "host")) - 1L
   if (class(tc)[1] %in% c("xts", "zoo", "ts")) time_index <- time(tc)
   if (is.null(time_index)) stop("time info missing")
   time.freq <- abs(as.numeric(time_index[1] - time_index[2], units = "days"))
@@ -19,7 +23,7 @@ splash.point <- function(sw_in, tc, pn, lat, elev, slop = 0, asp = 0, soil_data,
   tf <- .time_fields(time_index)
   result <- .Call("C_splash_point_run", as.numeric(sw_in), as.numeric(tc), as.numeric(pn),
                   lat, elev, slop, asp, as.numeric(soil_data), as.numeric(Au), resolution,
-                  tf$doy, tf$year, tf$month, monthly_out)
+                  tf$doy, tf$year, tf$month, monthly_out, backend)
   if (ts_out & !monthly_out) {
     result <- xts::xts(base::as.data.frame(result), time_index)
   } else if (ts_out & monthly_out) {

@@ -212,9 +212,11 @@ SEXP C_splash_snow_threshold(SEXP tc, SEXP lat, SEXP elev)
 }
 
 /* splash.point: the same pipeline for one site (numeric vectors of length nt) */
+/* backend: 0 = SPLASH_BACKEND_HIP (default), 1 = SPLASH_BACKEND_HOST -- the library's own day step compiled for
+ * the host, for a single site (ABI 6; include/splash_hip.h: splash_point_run_backend) */
 SEXP C_splash_point_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP lat, SEXP elev, SEXP slop, SEXP asp,
                         SEXP soil_data, SEXP Au, SEXP resolution, SEXP doy, SEXP year, SEXP month,
-                        SEXP monthly)
+                        SEXP monthly, SEXP backend)
 {
     const int nt = LENGTH(sw_in);
     if (LENGTH(tc) != nt || LENGTH(pn) != nt || LENGTH(doy) != nt) error("series lengths differ");
@@ -236,10 +238,10 @@ SEXP C_splash_point_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP lat, SEXP elev, SEXP 
         UNPROTECT(1);
     }
     char err[512];
-    int rc = splash_point_run(nt, INTEGER(doy), INTEGER(year), INTEGER(month), REAL(sw_in), REAL(tc),
-                              REAL(pn), asReal(lat), asReal(elev), asReal(slop), asReal(asp),
-                              REAL(soil_data), REAL(Au), LENGTH(Au), asReal(resolution), mo, outp,
-                              err, sizeof err);
+    int rc = splash_point_run_backend(asInteger(backend), nt, INTEGER(doy), INTEGER(year), INTEGER(month),
+                                      REAL(sw_in), REAL(tc), REAL(pn), asReal(lat), asReal(elev), asReal(slop),
+                                      asReal(asp), REAL(soil_data), REAL(Au), LENGTH(Au), asReal(resolution), mo,
+                                      outp, err, sizeof err);
     if (rc != SPLASH_OK) {
         UNPROTECT(1);
         error("splash_point_run failed (%d): %s", rc, err);
@@ -312,7 +314,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"C_splash_grid_wait", (DL_FUNC)&C_splash_grid_wait, 1},
     {"C_splash_grid_chunk", (DL_FUNC)&C_splash_grid_chunk, 14},
     {"C_splash_snow_threshold", (DL_FUNC)&C_splash_snow_threshold, 3},
-    {"C_splash_point_run", (DL_FUNC)&C_splash_point_run, 14},
+    {"C_splash_point_run", (DL_FUNC)&C_splash_point_run, 15},
     {"C_splash_unswc_run", (DL_FUNC)&C_splash_unswc_run, 3},
     {"C_splash_static_rasters", (DL_FUNC)&C_splash_static_rasters, 5},
     {NULL, NULL, 0}};

@@ -28,7 +28,7 @@ class GridIn(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("monthly_out", C.c_int), ("device", C.c_int), ("max_cells_per_launch", C.c_size_t),
-                ("n_devices", C.c_int), ("devices", _ip), ("mem_fraction", C.c_double)]
+                ("n_devices", C.c_int), ("devices", _ip), ("mem_fraction", C.c_double), ("backend", C.c_int)]
 
 
 class GridOut(C.Structure):
@@ -127,6 +127,8 @@ def _load():
                                   C.c_char_p, C.c_size_t]
     L.splash_point_run.argtypes = [C.c_int, _ip, _ip, _ip, _dp, _dp, _dp] + [C.c_double] * 4 + \
         [_dp, _dp, C.c_int, C.c_double, C.c_int, C.POINTER(_dp), C.c_char_p, C.c_size_t]
+    L.splash_point_run_backend.argtypes = [C.c_int] + L.splash_point_run.argtypes
+    L.splash_mod_backend.argtypes = [C.c_int]
     L.splash_mod_spin_up.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, _dp, _dp, _dp,
                                      C.c_double, C.c_double, _dp, _dp] + [_dp] * 7 + [_ip]
     L.splash_mod_run_all.argtypes = [C.c_double, C.c_double, C.c_int, _ip, _ip, _dp, _dp, _dp,
@@ -158,7 +160,17 @@ SYMBOLS = (
     "splash_dev_evap_batch", "splash_dev_math_probe", "splash_dev_unswc", "splash_unswc_run",
     "splash_snow_threshold_run", "splash_grid_run", "splash_grid_submit", "splash_grid_wait", "splash_point_run", "splash_mod_spin_up",
     "splash_mod_run_all", "splash_mod_run_one_year", "splash_mod_moist_surf", "splash_mod_inf_GA",
+    "splash_point_run_backend", "splash_host_backend_fma", "splash_mod_backend",
 )
+
+BACKENDS = {"hip": 0, "host": 1, 0: 0, 1: 1}   # SPLASH_BACKEND_HIP / SPLASH_BACKEND_HOST (include/splash_hip.h)
+
+
+def backend_code(b):
+    try:
+        return BACKENDS[b]
+    except KeyError:
+        raise ValueError(f"backend must be 'hip' (default) or 'host', not {b!r}") from None
 
 
 class SplashError(RuntimeError):

@@ -77,11 +77,14 @@ def month_ids(year, month):
 
 # ---------------------------------------------------------------------------- splash.point
 def splash_point(sw_in, tc, pn, lat, elev, slop=0.0, asp=0.0, soil_data=None, Au=0.0,
-                 resolution=250.0, time_index=None, monthly_out=False):
+                 resolution=250.0, time_index=None, monthly_out=False, backend="hip"):
     """R/splash.point.R:29.  Daily series in, dict of the 9 reference outputs out
     (wn, ro, pet, aet, snow, cond, bflow, netr, sm_lim).  `time_index`: dates of the series.
     Monthly inputs (R/splash.point.R:66-86) are not supported: their disaggregation draws from
-    an unseeded RNG in the reference."""
+    an unseeded RNG in the reference.
+    backend: "hip" (default: the GPU; no device = an error) or "host" -- the same day step, the library's own device
+    functions compiled for the host, on a CPU core (include/splash_hip.h, splash_opts.backend): a single site is a
+    chain of sequential day steps that one core steps through faster than a lone wavefront.  Never chosen for you."""
     if time_index is None:
         raise ValueError("time_index is required (dates of the daily series)")
     if soil_data is None or len(soil_data) != 6:
@@ -100,9 +103,9 @@ def splash_point(sw_in, tc, pn, lat, elev, slop=0.0, asp=0.0, soil_data=None, Au
     ptrs = (_dp * NOUT)(*[out[k].ctypes.data_as(_dp) for k in range(NOUT)])
     err = C.create_string_buffer(512)
     ia = [_i(x) for x in (doy, year, month)]
-    rc = lib.splash_point_run(nt, ia[0][1], ia[1][1], ia[2][1], f[0][1], f[1][1], f[2][1],
-                              float(lat), float(elev), float(slop), float(asp), sdp, aup, len(au),
-                              float(resolution), int(bool(monthly_out)), ptrs, err, 512)
+    rc = lib.splash_point_run_backend(_lib.backend_code(backend), nt, ia[0][1], ia[1][1], ia[2][1], f[0][1], f[1][1],
+                                      f[2][1], float(lat), float(elev), float(slop), float(asp), sdp, aup, len(au),
+                                      float(resolution), int(bool(monthly_out)), ptrs, err, 512)
     if rc:
         raise SplashError(f"splash_point_run failed ({rc}): {err.value.decode()}")
     return {k: out[i] for i, k in enumerate(OUT_NAMES)}
@@ -113,7 +116,7 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
                 time_index=None, sim_control=None, outputs=OUT_NAMES, device=0,
                 max_cells_per_launch=0, want_aux=False, want_diag=False, outdir=None, lon=None,
                 basin=None, n_basin=0, devices=None, out=None, want_state=True, submit=False,
-                mem_fraction=0.0, out_dtype=np.float64, tt=None, state0=None, ai0=None):
+                mem_fraction=0.0, out_dtype=np.float64, tt=None, state0=None, ai0=None, backend="hip"):
     """R/splash.grid.R:28 on arrays.  sw_in/tc/pn: [nt, ncell] (or [nt, H, W]) daily rasters;
     elev/lat/slop/asp: [ncell]; soil: [6, ncell]; Au: [3, ncell] (area, ncellin, ncellout) or
     None.  The static rasters the reference derives with raster/GDAL/TauDEM (lat, slope, aspect,
@@ -219,7 +222,8 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
         gout.diag = diag.ctypes.data_as(_dp)
         acc = np.zeros((nbas, nm, DIAG_REC), np.int64)
         gout.diag_acc = acc.ctypes.data_as(C.POINTER(C.c_int64))
-    opt = _lib.Opts(int(monthly), int(device), int(max_cells_per_launch), 0, None, float(mem_fraction))
+    opt = _lib.Opts(int(monthly), int(device), int(max_cells_per_launch), 0, None, float(mem_fraction),
+                    _lib.backend_code(backend))
     dv = None
     if devices is not None:
         dv = np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
@@ -372,11 +376,20 @@ def dev_unswc(ncell, nt, wn, ldw, soil, uns_depth, wn_z, wtd, theta, ldo, stream
 class SPLASH:
     """Mirror of the Rcpp class exposed by src/SPLASH.cpp:12-21 (`new(SPLASH, lat, elev)`)."""
 
-    def __init__(self, lat, elv):
+    def __init__(self, lat, elv, backend="hip"):
+        """backend: "hip" (default) or "host" -- where this object's methods compute (splash_mod_backend: the
+        library keeps the choice per calling thread; it is set before every call of this object)"""
         self.lat, self.elv = float(lat), float(elv)
+        self.backend = _lib.backend_code(backend)
+
+    def _enter(self):
+        rc = lib.splash_mod_backend(self.backend)
+        if rc < 0:
+            check(rc, "splash_mod_backend")
 
     def spin_up(self, n, y, sw_in, tair, pn, slop, asp, snowfall, soil_info):
         """src/SPLASH.cpp:1594 -> dict(sm, snow, qin, tdrain, ro, snwage, pet) (+ 'passes')."""
+        self._enter()
         a = [_d(x) for x in (sw_in, tair, pn, snowfall, soil_info)]
         names = ("sm", "snow", "qin", "tdrain", "ro", "snwage", "pet")
         out = {k: np.empty(n) for k in names}
@@ -391,6 +404,7 @@ class SPLASH:
     def run_all(self, doys, yrs, sw_in, tair, pn, wn_last, slop, asp, snow_last, snowfall,
                 soil_info, qin_last, td_last, nds_last):
         """src/SPLASH.cpp:1833 -> dict of the 11 series of :1913-1915."""
+        self._enter()
         nt = len(doys)
         d, dp_ = _i(doys)
         y, yp = _i(yrs)
@@ -409,6 +423,7 @@ class SPLASH:
     def run_one_year(self, n, y, sw_in, tair, pn, wn_vec, slop, asp, snow, snowfall, soil_info,
                      qin_vec, td_vec, nds):
         """src/SPLASH.cpp:1751 -> dict of the 11 series of :1827-1829, each [n]"""
+        self._enter()
         a = [_d(x) for x in (sw_in, tair, pn, wn_vec, snow, snowfall, soil_info, qin_vec, td_vec, nds)]
         names = ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "qin_prev", "tdrain",
                  "snwage")
@@ -421,16 +436,18 @@ class SPLASH:
         return out
 
     @staticmethod
-    def moist_surf(depth, z, bub_p, wn, SAT, RES, lam):
+    def moist_surf(depth, z, bub_p, wn, SAT, RES, lam, backend="hip"):
         """src/SPLASH.cpp:1921"""
+        check(min(lib.splash_mod_backend(_lib.backend_code(backend)), 0), "splash_mod_backend")
         v = C.c_double()
         check(lib.splash_mod_moist_surf(depth, z, bub_p, wn, SAT, RES, lam, C.byref(v)),
               "splash_mod_moist_surf")
         return v.value
 
     @staticmethod
-    def inf_GA(bub_press, theta_i, Ksat, theta_s, lam, P, tdur, slop):
+    def inf_GA(bub_press, theta_i, Ksat, theta_s, lam, P, tdur, slop, backend="hip"):
         """src/SPLASH.cpp:1963"""
+        check(min(lib.splash_mod_backend(_lib.backend_code(backend)), 0), "splash_mod_backend")
         v = C.c_double()
         check(lib.splash_mod_inf_GA(bub_press, theta_i, Ksat, theta_s, lam, P, tdur, slop,
                                     C.byref(v)), "splash_mod_inf_GA")

@@ -374,21 +374,19 @@ extern "C" int splash_orbit_day(int doy, int year, double* dr, double* sd, doubl
     return SPLASH_OK;
 }
 
-extern "C" int splash_calendar_create(int nt, const int* doy, const int* year, const int* month,
-                                      splash_calendar** out, char* err, size_t errlen)
+void splash::host::orbit_of_day(int doy, int year, double& dr, double& sd, double& cd) { orbit_day(doy, year, dr, sd, cd); }
+
+int splash::host::calendar_host(int nt, const int* doy, const int* year, const int* month, splash_calendar* cal,
+                                char* err, size_t errlen)
 {
-    if (!out || nt <= 0 || !doy || !year || !month)
+    if (nt <= 0 || !doy || !year || !month)
         return fail(SPLASH_EINVAL, err, errlen, "calendar: nt must be > 0 and doy/year/month given");
-    if (int rc = enter_device(err, errlen)) return rc;
-    auto* cal = new splash_calendar;
     cal->nt = nt;
     cal->host.resize(nt);
     int mid = 0;
     for (int t = 0; t < nt; t++) {
-        if (month[t] < 1 || month[t] > 12 || doy[t] < 1 || doy[t] > 366) {
-            delete cal;
+        if (month[t] < 1 || month[t] > 12 || doy[t] < 1 || doy[t] > 366)
             return fail(SPLASH_EINVAL, err, errlen, "calendar: bad doy/month at day %d", t);
-        }
         if (t > 0 && (month[t] != month[t - 1] || year[t] != year[t - 1])) mid++;
         DayRec& d = cal->host[t];
         orbit_day(doy[t], year[t], d.dr, d.sd, d.cd);
@@ -415,6 +413,20 @@ extern "C" int splash_calendar_create(int nt, const int* doy, const int* year, c
             orbit_day(i + 1, year[0], d.dr, d.sd, d.cd);
             d.doy = i + 1;
         }
+    }
+    return SPLASH_OK;
+}
+
+extern "C" int splash_calendar_create(int nt, const int* doy, const int* year, const int* month,
+                                      splash_calendar** out, char* err, size_t errlen)
+{
+    if (!out || nt <= 0 || !doy || !year || !month)
+        return fail(SPLASH_EINVAL, err, errlen, "calendar: nt must be > 0 and doy/year/month given");
+    if (int rc = enter_device(err, errlen)) return rc;
+    auto* cal = new splash_calendar;
+    if (int rc = calendar_host(nt, doy, year, month, cal, err, errlen)) {
+        delete cal;
+        return rc;
     }
     (void)hipGetDevice(&cal->device);
     const size_t nspin = cal->spin_host.size();
@@ -1075,13 +1087,15 @@ extern "C" int splash_dev_infiltration_probe(size_t n, const double* cellpar, co
     return SPLASH_OK;
 }
 
-extern "C" int splash_point_run(int nt, const int* doy, const int* year, const int* month,
-                                const double* sw_in, const double* tc, const double* pn, double lat,
-                                double elev, double slop, double asp, const double* soil_data,
-                                const double* au, int n_au, double resolution, int monthly_out,
-                                double* const outp[SPLASH_NOUT], char* err, size_t errlen)
+extern "C" int splash_point_run_backend(int backend, int nt, const int* doy, const int* year, const int* month,
+                                        const double* sw_in, const double* tc, const double* pn, double lat,
+                                        double elev, double slop, double asp, const double* soil_data,
+                                        const double* au, int n_au, double resolution, int monthly_out,
+                                        double* const outp[SPLASH_NOUT], char* err, size_t errlen)
 {
     if (!soil_data || !outp) return fail(SPLASH_EINVAL, err, errlen, "point_run: NULL argument");
+    if (backend != SPLASH_BACKEND_HIP && backend != SPLASH_BACKEND_HOST)
+        return fail(SPLASH_EINVAL, err, errlen, "point_run: unknown backend %d", backend);
     if (n_au != 0 && n_au != 1 && n_au != 3)
         return fail(SPLASH_EINVAL, err, errlen, "point_run: Au must have 1 or 3 values");
     // length(Au)==1 => ncellin = ncellout = 3 (R/splash.point.R:106-110)
@@ -1109,10 +1123,23 @@ extern "C" int splash_point_run(int nt, const int* doy, const int* year, const i
     in.au = au3;
     splash_opts opt{};
     opt.monthly_out = monthly_out;
+    opt.backend = backend;
     splash_grid_out o{};
     for (int k = 0; k < SPLASH_NOUT; k++) o.out[k] = outp[k];
     return splash_grid_run(&in, &opt, &o, err, errlen);
 }
+
+extern "C" int splash_point_run(int nt, const int* doy, const int* year, const int* month,
+                                const double* sw_in, const double* tc, const double* pn, double lat,
+                                double elev, double slop, double asp, const double* soil_data,
+                                const double* au, int n_au, double resolution, int monthly_out,
+                                double* const outp[SPLASH_NOUT], char* err, size_t errlen)
+{
+    return splash_point_run_backend(SPLASH_BACKEND_HIP, nt, doy, year, month, sw_in, tc, pn, lat, elev, slop, asp,
+                                    soil_data, au, n_au, resolution, monthly_out, outp, err, errlen);
+}
+
+extern "C" int splash_host_backend_fma(void) { return host_backend_fma() ? 1 : 0; }
 
 // unSWC for host buffers: wn [nt][ncell], soil [6][ncell] -> wn_z, wtd, theta [nt][ncell]
 extern "C" int splash_unswc_run(size_t ncell, int nt, const double* wn, const double* soil,
@@ -1297,6 +1324,17 @@ struct Upload {
 
 } // namespace
 
+// backend of the calling thread's splash_mod_* calls (ABI 6)
+static thread_local int t_mod_backend = SPLASH_BACKEND_HIP;
+extern "C" int splash_mod_backend(int backend)
+{
+    if (backend != SPLASH_BACKEND_HIP && backend != SPLASH_BACKEND_HOST)
+        return fail(SPLASH_EINVAL, nullptr, 0, "mod_backend: unknown backend %d", backend);
+    const int prev = t_mod_backend;
+    t_mod_backend = backend;
+    return prev;
+}
+
 // SPLASH::spin_up (src/SPLASH.cpp:1594-1749; R call at R/splash.point.R:148,152)
 extern "C" int splash_mod_spin_up(double lat, double elv, int n, int y, const double* sw_in,
                                   const double* tair, const double* pn, double slop, double asp,
@@ -1305,7 +1343,9 @@ extern "C" int splash_mod_spin_up(double lat, double elv, int n, int y, const do
                                   double* snwage, double* pet, int* passes)
 {
     REQ(n > 0 && sw_in && tair && pn && snowfall && soil_info, "mod_spin_up: bad argument");
-    if (int rc = enter_device(nullptr, 0)) return rc;
+    const bool on_host = t_mod_backend == SPLASH_BACKEND_HOST;
+    if (!on_host)
+        if (int rc = enter_device(nullptr, 0)) return rc;
     std::vector<DayRec> days(n);
     for (int i = 0; i < n; i++) {
         DayRec& d = days[i];
@@ -1319,6 +1359,12 @@ extern "C" int splash_mod_spin_up(double lat, double elv, int n, int y, const do
     }
     double par[SPLASH_NPAR];
     par_from_soil_info(lat, elv, slop, asp, soil_info, par);
+    if (on_host) { // the same device functions, compiled for the host (splash_host_backend.hip)
+        double* series[7] = {sm, snow, qin, tdrain, ro, snwage, pet}; // names of :1748
+        if (pet) std::fill(pet, pet + n, 0.0);
+        host_mod_spin_up(par, n, days.data(), sw_in, tair, pn, snowfall, series, passes);
+        return SPLASH_OK;
+    }
     Upload ud, up, usw, utc, upn, usf;
     int rc = 0;
     if ((rc = ud.put(days.data(), sizeof(DayRec) * n)) || (rc = up.put(par, sizeof par)) ||
@@ -1370,7 +1416,9 @@ extern "C" int splash_mod_run_all(double lat, double elv, int nt, const int* doy
 {
     REQ(nt > 0 && doys && yrs && sw_in && tair && pn && snowfall && soil_info,
         "mod_run_all: bad argument");
-    if (int rc = enter_device(nullptr, 0)) return rc;
+    const bool on_host = t_mod_backend == SPLASH_BACKEND_HOST;
+    if (!on_host)
+        if (int rc = enter_device(nullptr, 0)) return rc;
     std::vector<DayRec> days(nt);
     for (int i = 0; i < nt; i++) {
         DayRec& d = days[i];
@@ -1385,6 +1433,11 @@ extern "C" int splash_mod_run_all(double lat, double elv, int nt, const int* doy
     double par[SPLASH_NPAR];
     par_from_soil_info(lat, elv, slop, asp, soil_info, par);
     const double st0[5] = {wn_last, snow_last, qin_last, td_last, nds_last};
+    if (on_host) {
+        double* dsth[11] = {wn, ro, pet, aet, snow, cond, bflow, netr, qin_prev, tdrain, snwage};
+        host_mod_run_all(par, nt, days.data(), sw_in, tair, pn, snowfall, st0, dsth);
+        return SPLASH_OK;
+    }
     Upload ud, up, usw, utc, upn, usf, ust;
     int rc = 0;
     if ((rc = ud.put(days.data(), sizeof(DayRec) * nt)) || (rc = up.put(par, sizeof par)) ||
@@ -1449,6 +1502,10 @@ extern "C" int splash_mod_moist_surf(double depth, double z, double bub_p, doubl
                                      double RES, double lambda, double* theta)
 {
     REQ(theta, "mod_moist_surf: NULL result");
+    if (t_mod_backend == SPLASH_BACKEND_HOST) {
+        *theta = host_mod_moist_surf(depth, z, bub_p, wn, SAT, RES, lambda);
+        return SPLASH_OK;
+    }
     if (int rc = enter_device(nullptr, 0)) return rc;
     DevBuf d;
     HIP_TRY(d.alloc(8), nullptr, 0);
@@ -1463,6 +1520,10 @@ extern "C" int splash_mod_inf_GA(double bub_press, double theta_i, double Ksat, 
                                  double* infiltration)
 {
     REQ(infiltration, "mod_inf_GA: NULL result");
+    if (t_mod_backend == SPLASH_BACKEND_HOST) {
+        *infiltration = host_mod_inf_GA(bub_press, theta_i, Ksat, theta_s, lambda, P, tdur, slop);
+        return SPLASH_OK;
+    }
     if (int rc = enter_device(nullptr, 0)) return rc;
     DevBuf d;
     HIP_TRY(d.alloc(8), nullptr, 0);

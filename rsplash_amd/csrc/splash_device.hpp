@@ -23,7 +23,30 @@
 #include "splash_kernels.hpp"
 #include "splash_math.hpp"
 
+// The day step's functions compile for the device AND for the host (SPL_DEV = __host__ __device__): the host
+// backend of the one-cell entry points (splash_host_backend.hip, SPLASH_BACKEND_HOST; round 6) runs the product's
+// own arithmetic -- these very functions -- on a CPU core, where a lone wavefront has nothing to offer a single
+// site.  What is device-only inside them is switched on __HIP_DEVICE_COMPILE__: tables in LDS (host: the constant
+// arrays themselves), the register pins that keep values finished doubles across kernel variants (host: nothing;
+// host and device agree to rounding, not to the bit: another libm in cell_setup, IEEE divisions for the
+// reciprocal sequences), the wave-uniform predicate.
+#define SPL_DEV __host__ __device__ __forceinline__
+#define SPL_DEV_NOINL __host__ __device__ inline
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SPL_FIN(x) asm volatile("" : "+v"(x))            // x is a finished value in a register from here on
+#define SPL_FIN3(x, y, z) asm volatile("" : "+v"(x), "+v"(y), "+v"(z))
+#else
+#define SPL_FIN(x) ((void)0)
+#define SPL_FIN3(x, y, z) ((void)0)
+#endif
+
 namespace splash {
+
+// bit casts that work on both sides (the __double_as_longlong family is device-only)
+SPL_DEV unsigned long long d2u(double x) { return __builtin_bit_cast(unsigned long long, x); }
+SPL_DEV double u2d(unsigned long long x) { return __builtin_bit_cast(double, x); }
+SPL_DEV uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+SPL_DEV float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
 
 // ---- call-site counters: profiling build only (-DSPL_SITES, tools/site_profile.sh) ------------
 // How often each transcendental call site / rare branch of the day step runs inside k_run_all, per
@@ -79,10 +102,12 @@ constexpr double kFluidity = 35187037.0;
 // execution-mask bookkeeping around ~10 blocks of a day step on which a lone wavefront pays for every instruction.
 // The arithmetic inside the blocks is untouched (same statements in the same basic blocks: same bits).
 template <bool UNI>
-__device__ __forceinline__ bool wave_pred(bool p)
+SPL_DEV bool wave_pred(bool p)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (UNI) return __builtin_amdgcn_ballot_w64(p) != 0ull;
-    else return p;
+#endif
+    return p;
 }
 
 struct State {
@@ -132,14 +157,14 @@ struct CellConst {
 };
 
 // ---- small helpers -------------------------------------------------------------------------
-__device__ __forceinline__ double dsin_deg(double x) { return sin(x * kPir); }
+SPL_DEV double dsin_deg(double x) { return sin(x * kPir); }
 
 // src/EVAP.cpp:338-389 (Chen et al. 1977) in Horner form for the FP64 path (the evaluation-order
 // faithful form below is only needed where the result is rounded to float)
 struct DensityPolys { // temperature polynomials of Chen et al. (1977), src/EVAP.cpp:338-384
     double po1000, ko, ca, cb;
 };
-__device__ __forceinline__ DensityPolys density_polys(double tc)
+SPL_DEV DensityPolys density_polys(double tc)
 {
     double po = horner3(-(1.00659e-18), tc, (5.044070e-16), -(1.11663e-13), (1.471150e-11));
     po = horner5(po, tc, -(1.35439e-9), (1.022130e-7), -(9.08659e-6), (6.788260e-5), 0.99983952);
@@ -150,20 +175,20 @@ __device__ __forceinline__ DensityPolys density_polys(double tc)
     q.cb = horner4((4.3220e-12), tc, -(1.0100e-9), (8.69900e-8), -(5.8948e-6), (7.2061e-5));
     return q;
 }
-__device__ __forceinline__ double density_from_polys(const DensityPolys& q, double p)
+SPL_DEV double density_from_polys(const DensityPolys& q, double p)
 {
     const double pbar = (1.0e-5) * p;
     const double num = (q.ko + q.ca * pbar + q.cb * (pbar * pbar)); // ~2e4
     return num * frcp(num - pbar) * q.po1000;
 }
-__device__ __forceinline__ double density_h2o_fast(double tc, double p)
+SPL_DEV double density_h2o_fast(double tc, double p)
 {
     return density_from_polys(density_polys(tc), p);
 }
 
 // src/EVAP.cpp:338-389 (Chen et al. 1977).  Contraction is off so that the value later rounded
 // to float inside the viscosity routine is the same double the reference rounds.
-__device__ __forceinline__ double density_h2o(double tc, double p)
+SPL_DEV double density_h2o(double tc, double p)
 {
 #pragma clang fp contract(off)
     // products are evaluated left to right exactly as written in the reference
@@ -208,15 +233,19 @@ __device__ __forceinline__ double density_h2o(double tc, double p)
 // std::exp(float) in the reference resolves to this routine; it is NOT correctly rounded
 // (0.06 % of arguments differ from (float)exp((double)x)), so the algorithm itself is restated.
 // The table is 2^(i/32) correctly rounded to double, minus (i << 47).
-__device__ const uint64_t kExp2fTab[32] = {
-    0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,
-    0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,
-    0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,
-    0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,
-    0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
-    0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,
-    0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
-    0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL};
+#define SPL_EXP2F_TABLE \
+    0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL, \
+    0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL, \
+    0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL, \
+    0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL, \
+    0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL, \
+    0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL, \
+    0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL, \
+    0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL
+#if !defined(__HIP_DEVICE_COMPILE__)
+static const uint64_t kExp2fTabHost[32] = {SPL_EXP2F_TABLE};
+#endif
+__device__ const uint64_t kExp2fTab[32] = {SPL_EXP2F_TABLE};
 
 // The table is read from LDS, not from global memory: vector-memory loads return in order
 // (vmcnt), so a table load in the middle of the day step would make its s_waitcnt also wait for
@@ -238,7 +267,7 @@ __device__ __forceinline__ void lds_tables_init()
     __syncthreads();
 }
 
-__device__ __forceinline__ float expf_glibc(float x)
+SPL_DEV float expf_glibc(float x)
 {
     constexpr double N = 32.0;
     constexpr double InvLn2N = 0x1.71547652b82fep+0 * N;
@@ -256,12 +285,16 @@ __device__ __forceinline__ float expf_glibc(float x)
     }
     double z = InvLn2N * xd;
     double kd = z + Shift;
-    uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    uint64_t ki = (uint64_t)d2u(kd);
     kd -= Shift;
     double r = z - kd;
+#if defined(__HIP_DEVICE_COMPILE__)
     uint64_t t = s_exp2f_tab[ki & 31];
+#else
+    uint64_t t = kExp2fTabHost[ki & 31];
+#endif
     t += ki << 47;
-    double s = __longlong_as_double((long long)t);
+    double s = u2d(t);
     double zz = C0 * r + C1;
     double r2 = r * r;
     double y = C2 * r + 1.0;
@@ -272,7 +305,7 @@ __device__ __forceinline__ float expf_glibc(float x)
 
 // x^2..x^6 rounded once from a double-double product chain (error ~1e-32 relative before the
 // final rounding), i.e. correctly rounded except in astronomically rare ties.
-__device__ __forceinline__ void pow_int_cr(double x, double& p2, double& p3, double& p4, double& p5,
+SPL_DEV void pow_int_cr(double x, double& p2, double& p3, double& p4, double& p5,
                                            double& p6)
 {
 #pragma clang fp contract(off)
@@ -316,7 +349,7 @@ __device__ __forceinline__ void pow_int_cr(double x, double& p2, double& p3, dou
 constexpr uint32_t kViscR0 = 0x40436000u; // rbar = 3.05273...  (rho = 982.98: water at ~60.5 degC)
 constexpr uint32_t kViscNR = 0x00039000u; // up to rbar = 3.10840 (rho = 1000.9)
 
-__device__ __forceinline__ void visc_tbar_part(float tbar, float& mu0_out, float& ctbar_out)
+SPL_DEV void visc_tbar_part(float tbar, float& mu0_out, float& ctbar_out)
 {
 #pragma clang fp contract(off)
     float tbarx = (float)sqrt((double)tbar);                           // :417 pow(tbar,0.5)
@@ -329,7 +362,7 @@ __device__ __forceinline__ void visc_tbar_part(float tbar, float& mu0_out, float
     ctbar_out = (float)((1.0 / (double)tbar) - 1.0);                   // :439
 }
 
-__device__ __forceinline__ void visc_rbar_part(float rbar, float (&c)[6])
+SPL_DEV void visc_rbar_part(float rbar, float (&c)[6])
 {
 #pragma clang fp contract(off)
     // Table 3 of Huber et al. (:427-435); the literals are rounded to float as in the
@@ -368,7 +401,7 @@ __device__ __forceinline__ void visc_rbar_part(float rbar, float (&c)[6])
 #undef H
 }
 
-__device__ __forceinline__ float visc_combine(float rbar, float mu0, float ctbar, const float (&c)[6])
+SPL_DEV float visc_combine(float rbar, float mu0, float ctbar, const float (&c)[6])
 {
 #pragma clang fp contract(off)
     const float mu_ast = 1e-6f;
@@ -387,7 +420,7 @@ __device__ __forceinline__ float visc_combine(float rbar, float mu0, float ctbar
     return mu_bar * mu_ast;                                            // :459
 }
 
-__device__ __forceinline__ float viscosity_h2o(float tc, float p)
+SPL_DEV float viscosity_h2o(float tc, float p)
 {
 #pragma clang fp contract(off)
     const float tk_ast = 647.096f;
@@ -406,9 +439,9 @@ __device__ __forceinline__ float viscosity_h2o(float tc, float p)
 // approximation of the same real).  The two round alike unless v lies within 2^-43 relative of a
 // float rounding boundary (a midpoint of two adjacent floats: low 29 mantissa bits = 0x10000000);
 // then `risky` is raised and the caller falls back to the reference's own evaluation.
-__device__ __forceinline__ float to_float_checked(double v, bool& risky)
+SPL_DEV float to_float_checked(double v, bool& risky)
 {
-    const uint32_t lo = (uint32_t)(unsigned long long)__double_as_longlong(v) & 0x1FFFFFFFu;
+    const uint32_t lo = (uint32_t)d2u(v) & 0x1FFFFFFFu;
     risky |= (lo - (0x10000000u - 512u)) < 1024u;
     return (float)v;
 }
@@ -416,7 +449,7 @@ __device__ __forceinline__ float to_float_checked(double v, bool& risky)
 // visc_tbar_part() with reciprocal-based quotients and a fast square root, every rounding to float
 // checked (to_float_checked): ~60 instructions instead of three IEEE divisions, a correctly
 // rounded square root and two more divisions -- or instead of a 23 MB table whose gathers miss L2.
-__device__ __forceinline__ void visc_tbar_part_fast(float tbar, double t1, double t2, double t3,
+SPL_DEV void visc_tbar_part_fast(float tbar, double t1, double t2, double t3,
                                                     double r, float& mu0_out, float& ctbar_out,
                                                     bool& risky)
 {
@@ -447,7 +480,7 @@ struct DayPre {
     int mode;           // 0: tc < 0 (viscosity at tw = 0 is a cell constant)  1: tables  2: direct
 };
 
-__device__ __forceinline__ DayPre day_prefetch(const CellConst& c, double tc)
+SPL_DEV DayPre day_prefetch(const CellConst& c, double tc)
 {
 #pragma clang fp contract(off)
     DayPre q;
@@ -481,7 +514,7 @@ __device__ __forceinline__ DayPre day_prefetch(const CellConst& c, double tc)
         const double rr = frcp(den_rho * ttt);
         const float rho = to_float_checked(num * (rr * ttt) * dq.po1000, risky);
         const float rbar = to_float_checked((double)rho * (1.0 / 322.0), risky);          // :420
-        ir = __float_as_uint(rbar) - kViscR0;
+        ir = f2u(rbar) - kViscR0;
         risky |= (ir >= kViscNR);
         visc_tbar_part_fast(tbar, t1, t2, t3, rr * den_rho, q.mu0, q.ctbar, risky);
         q.mode = risky ? 2 : 1;
@@ -500,7 +533,7 @@ __device__ __forceinline__ DayPre day_prefetch(const CellConst& c, double tc)
 }
 
 // viscosity of the day [Pa s] from the prefetched pieces
-__device__ __forceinline__ double day_viscosity(const CellConst& c, const DayPre& q, double tc)
+SPL_DEV double day_viscosity(const CellConst& c, const DayPre& q, double tc)
 {
     double visc = c.visc0;
     if (q.mode == 1) {
@@ -509,8 +542,8 @@ __device__ __forceinline__ double day_viscosity(const CellConst& c, const DayPre
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             uint32_t w = q.cw[k];
-            asm volatile("" : "+v"(w)); // first touch of the gathered words: HERE, not at the load
-            cf[k] = __uint_as_float(w);
+            SPL_FIN(w); // first touch of the gathered words: HERE, not at the load
+            cf[k] = u2f(w);
         }
         visc = (double)visc_combine(q.rbar, q.mu0, q.ctbar, cf);
     } else if (q.mode == 2) {
@@ -521,7 +554,7 @@ __device__ __forceinline__ double day_viscosity(const CellConst& c, const DayPre
 }
 
 // src/EVAP.cpp:491-515
-__device__ __forceinline__ double specific_heat(double tc)
+SPL_DEV double specific_heat(double tc)
 {
     double cp;
     if (tc < 0) {
@@ -541,7 +574,7 @@ __device__ __forceinline__ double specific_heat(double tc)
 // cellout is passed separately because splash.point overwrites it with the aridity index
 // between the two spin-ups (R/splash.point.R:150).  Runs once per kernel per cell, so it uses
 // the library pow/exp/log throughout.
-__device__ inline void cell_setup(CellConst& c, const double* __restrict__ par, size_t ld,
+SPL_DEV_NOINL void cell_setup(CellConst& c, const double* __restrict__ par, size_t ld,
                                   size_t cell, double cellout, ViscTables vt = ViscTables{nullptr})
 {
     c.vt = vt;
@@ -665,7 +698,7 @@ struct Etr { // src/etr.h:44-56 (fields the water balance needs)
 // Branch-free: the argument is saturated with selects (NaN stays NaN, as in the reference's else
 // branch) and acos(+-1) = 0 / pi fall out of the same evaluation, so the three-way branch and its
 // exec-mask bookkeeping disappear.  (sin(180 deg) is 0 here and 1.2e-16 in the reference.)
-__device__ __forceinline__ void hour_angle(double cosv, bool at_one_is_zero, double& h,
+SPL_DEV void hour_angle(double cosv, bool at_one_is_zero, double& h,
                                            double& sinh_)
 {
     // saturation by max/min: one instruction each instead of compare + two selects.  A NaN cosine
@@ -684,7 +717,7 @@ __device__ __forceinline__ void hour_angle(double cosv, bool at_one_is_zero, dou
 }
 
 // two hour angles whose cosines saturate at >= 1 -> 0 (hn and hi of evap_update), see hour_angle()
-__device__ __forceinline__ void hour_angle2(double cos1, double cos2, double& h1, double& sinh1,
+SPL_DEV void hour_angle2(double cos1, double cos2, double& h1, double& sinh1,
                                             double& h2, double& sinh2)
 {
     const double x1 = fmin(fmax(cos1, -1.0), 1.0), x2 = fmin(fmax(cos2, -1.0), 1.0);
@@ -728,9 +761,9 @@ struct DayTerms {
 // cell constant: recomputed) and one word holding the viscosity's 32 bits and the flag
 constexpr int kNTermWords = 13;
 
-__device__ __forceinline__ void terms_fence(DayTerms& T)
+SPL_DEV void terms_fence(DayTerms& T)
 {
-#define SPL_PIN(x) asm volatile("" : "+v"(x))
+#define SPL_PIN(x) SPL_FIN(x)
     SPL_PIN(T.ru); SPL_PIN(T.rv); SPL_PIN(T.ruv); SPL_PIN(T.hs); SPL_PIN(T.sin_hs); SPL_PIN(T.xrw);
     SPL_PIN(T.rnl); SPL_PIN(T.s); SPL_PIN(T.g); SPL_PIN(T.econ); SPL_PIN(T.inv_econ); SPL_PIN(T.eetc);
     SPL_PIN(T.pw); SPL_PIN(T.visc);
@@ -745,7 +778,7 @@ __device__ __forceinline__ void terms_fence(DayTerms& T)
 struct ViscTerms {
     double ipk, kv, ikv24;
 };
-__device__ __forceinline__ ViscTerms visc_terms(const CellConst& c, const DayTerms& T)
+SPL_DEV ViscTerms visc_terms(const CellConst& c, const DayTerms& T)
 {
     ViscTerms v;
     const double r_v = frcp(T.visc * T.pw);
@@ -755,11 +788,11 @@ __device__ __forceinline__ ViscTerms visc_terms(const CellConst& c, const DayTer
     v.ikv24 = (T.visc * inv_pw) * c.inv_kv24c;
     // finished doubles, as when they come back from the tail's cache (a product that is later an
     // addend -- r - Ksat in inf_GA -- could otherwise be contracted into an FMA in one variant only)
-    asm volatile("" : "+v"(v.ipk), "+v"(v.kv), "+v"(v.ikv24));
+    SPL_FIN3(v.ipk, v.kv, v.ikv24);
     return v;
 }
 
-__device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d, const DayPre& pre,
+SPL_DEV void day_terms(const CellConst& c, const DayConst& d, const DayPre& pre,
                                           double sw_in, double tc, DayTerms& T)
 {
     // ----- SOLAR
@@ -842,7 +875,7 @@ __device__ __forceinline__ void day_terms(const CellConst& c, const DayConst& d,
 }
 
 template <bool UNI = false>
-__device__ __forceinline__ void evap_update(const CellConst& c, const DayTerms& T, const ViscTerms& V,
+SPL_DEV void evap_update(const CellConst& c, const DayTerms& T, const ViscTerms& V,
                                             double sw, double snow, double nd, Etr& o)
 {
     const double ru = T.ru, rv = T.rv, rnl = T.rnl, s = T.s, g = T.g, econ = T.econ;
@@ -918,7 +951,7 @@ __device__ __forceinline__ void evap_update(const CellConst& c, const DayTerms& 
 }
 
 // SOLAR + EVAP in one go (test hook k_evap_batch: src/EVAP.cpp:82-264 row by row)
-__device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, const DayPre& pre,
+SPL_DEV void evap_day(const CellConst& c, const DayConst& d, const DayPre& pre,
                                          double sw, double sw_in, double tc, double snow, double nd,
                                          Etr& o)
 {
@@ -932,7 +965,7 @@ __device__ __forceinline__ void evap_day(const CellConst& c, const DayConst& d, 
 // a / b correctly rounded, given y = RN(1/b) (an IEEE division done once per cell): q = a*y is
 // within an ulp, its exact residual r = a - b*q (one FMA) corrects it, and RN(q + r*y) is the
 // correctly rounded quotient (Markstein's division step).  Three issue slots.
-__device__ __forceinline__ double div_cr(double a, double b, double y)
+SPL_DEV double div_cr(double a, double b, double y)
 {
     const double q = a * y;
     const double r = fma(-b, q, a);
@@ -949,7 +982,7 @@ __device__ __forceinline__ double div_cr(double a, double b, double y)
 // agrees to 2-3 ulp only.  As in the reference, Theta is EXACTLY 0 at w == RES and EXACTLY 1 at
 // w == SAT (theta_r and theta_s are the same quotients), where its code is discontinuous
 // (Theta = 0 puts the water table at the column base, Theta = 1 at the surface).
-__device__ __forceinline__ double rel_saturation(const CellConst& c, double w)
+SPL_DEV double rel_saturation(const CellConst& c, double w)
 {
     const double th = div_cr(w, c.d1000, c.inv_d1000);
     return div_cr(th - c.theta_r, c.dtheta, c.inv_dtheta);
@@ -958,7 +991,7 @@ __device__ __forceinline__ double rel_saturation(const CellConst& c, double w)
 // src/SPLASH.cpp:1921-1961 with z = 10 cm (call at :1265): Brooks-Corey water content of the
 // top 10 cm.  With L = log(Theta):  psi = bpr*Theta^(-1/lambda),  (psi+z)/bpr =
 // Theta^(-1/lambda) + z/bpr,  theta = dtheta*((psi+z)/bpr)^(-lambda) + theta_r.
-__device__ __forceinline__ double moist_surf(const CellConst& c, double wn)
+SPL_DEV double moist_surf(const CellConst& c, double wn)
 {
     const double L = flog(rel_saturation(c, wn));
     // the potential itself is formed (not just its ratio to bpr) so that it overflows to -inf
@@ -966,8 +999,7 @@ __device__ __forceinline__ double moist_surf(const CellConst& c, double wn)
     // underflows for quite ordinary Theta), which sends theta to theta_r there
     const double psi = c.bpr * fexp(-L * c.inv_lambda);
     const double head_ratio = (psi + 10.0) * c.inv_bpr;
-    double theta_bc0 = c.dtheta * fexp(-c.lambda * flog(head_ratio)) + c.theta_r;
-    asm volatile("" : "+v"(theta_bc0)); // (finished before the selects below: no execution-mask branch around its tail)
+    const double theta_bc0 = c.dtheta * fexp(-c.lambda * flog(head_ratio)) + c.theta_r;
     // (if / else-if chains of this file are written as nested conditional expressions over finished values: the
     //  three-way merge of an else-if is not if-converted by the compiler, which then emits execution-mask branches --
     //  s_and_saveexec, s_cbranch_execz, s_or -- around one v_cndmask's worth of work, in every kernel)
@@ -979,7 +1011,7 @@ __device__ __forceinline__ double moist_surf(const CellConst& c, double wn)
 // :1265) only enters when the rain rate exceeds the conductivity, so it is evaluated inside that
 // branch (two logs and two exps saved on every other cell-day).
 template <bool UNI = false>
-__device__ __forceinline__ double inf_GA(const CellConst& c, double wn, double Ksat, double P)
+SPL_DEV double inf_GA(const CellConst& c, double wn, double Ksat, double P)
 {
     const double tdur = 6.0;
     const double r = P * (1.0 / 6.0); // P/tdur
@@ -1024,7 +1056,7 @@ __device__ __forceinline__ double inf_GA(const CellConst& c, double wn, double K
 //     the reference's own difference is rounding noise of fl(psi_m + depth*1000): DESIGN.md
 //     "Conditioning"; the parity tests set such cell-days aside.)
 template <bool UNI = false>
-__device__ __forceinline__ double transmittance_uns(const CellConst& c, double Ksat_visc,
+SPL_DEV double transmittance_uns(const CellConst& c, double Ksat_visc,
                                                     double sm, double& Acs_out)
 {
 #if defined(SPL_ABLATE) && SPL_ABLATE == 3
@@ -1043,12 +1075,11 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
     Acs_out = (c.depth - wtd) * c.so_cellout;
     const double w1000 = wtd * 1000.0;
     // A = Theta^((3*lambda+1)/lambda) = Theta^3 * Theta^(1/lambda) = Theta^3 / P: a reciprocal instead
-    // of a second exponential (P = +inf for Theta = 0 gives A = 0, like the reference's pow(-0, e))
-    // (the quotient is a finished value before the select: otherwise the compiler sinks the reciprocal into an
-    //  execution-mask branch; frcp(+inf) is NaN and is not selected)
-    double a_fin = (Theta * Theta * Theta) * frcp(P);
-    asm volatile("" : "+v"(a_fin));
-    const double A = (P < 1.0e300) ? a_fin : 0.0;
+    // of a second exponential (P = +inf for Theta = 0 gives A = 0, like the reference's pow(-0, e)).
+    // (Left as a conditional expression around the reciprocal, execution-mask branch and all: the compiler folds the
+    //  subtraction below into it and contracts -- the product's pinned bits are those of fma(Theta^3, 1/P, -1) --,
+    //  and a reciprocal pinned before a select costs k_run_all's day loop a spilled register: measured, round 6.)
+    const double A = (P < 1.0e300) ? (Theta * Theta * Theta) * frcp(P) : 0.0;
     double diff; // A - B
     if (wave_pred<UNI>(!clamped)) {
         diff = A - 1.0; // bub/(psi_m + wtd*1000) is 1 +- 1 ulp: B = 1 to 1e-16
@@ -1082,7 +1113,7 @@ __device__ __forceinline__ double transmittance_uns(const CellConst& c, double K
 // or read back from the spin-up's cache), what follows from the day's viscosity (visc_terms()) and
 // the day's rain and snowfall.
 template <bool UNI = false>
-__device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K, const ViscTerms& V,
+SPL_DEV void day_update(const CellConst& c, const DayTerms& K, const ViscTerms& V,
                                            double pn, double snowfall, State& st, DayOut& o)
 {
     const double wn = st.wn;
@@ -1159,7 +1190,7 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
         // (tr + 0.001 is formed here: hoisted out of the day loop the sum would be one more live register,
         // i.e. a spill to scratch memory, whose reload waits on the vector-memory counter)
         double tr = c.theta_r;
-        asm volatile("" : "+v"(tr));
+        SPL_FIN(tr);
         const double theta_i = (theta_i0 >= c.theta_s) ? c.theta_s - 0.001
                                                        : ((theta_i0 <= c.theta_r) ? tr + 0.001 : theta_i0);
         const double theta_m = SPL_MAX(c.wm_th, theta_i);
@@ -1251,7 +1282,7 @@ __device__ __forceinline__ void day_update(const CellConst& c, const DayTerms& K
 // as when they are read back from the cache.  FENCE = false (run_all): the compiler may fuse and
 // reorder across the seam (3 % faster: the 17 terms need not all be live at once).
 template <bool FENCE = false>
-__device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, const DayPre& pre,
+SPL_DEV void day_step(const CellConst& c, const DayConst& d, const DayPre& pre,
                                          double sw_in, double tc, double pn, double snowfall,
                                          State& st, DayOut& o)
 {
@@ -1261,12 +1292,125 @@ __device__ __forceinline__ void day_step(const CellConst& c, const DayConst& d, 
     day_update(c, T, visc_terms(c, T), pn, snowfall, st, o);
 }
 
+// ---- the two helper methods the module exports, with their general argument lists and written literally like the
+// reference (src/SPLASH.cpp:1921-1961, 1963-2023; library pow/log/cos): splash_mod_moist_surf / splash_mod_inf_GA
+SPL_DEV_NOINL double moist_surf_literal(double depth, double z, double bub_p, double wn, double SAT, double RES,
+                                        double lambda)
+{
+    double theta_r = RES / (depth * 1000.0);
+    double theta_s = SAT / (depth * 1000.0);
+    double bubbling_pr = bub_p / 10;
+    double theta_mean = (wn) / (depth * 1000.0);
+    double water_pot_BC =
+        bubbling_pr / pow((((theta_mean - theta_r) / (theta_s - theta_r))), (1 / lambda));
+    double total_head_BC = water_pot_BC + z;
+    double theta_BC =
+        (theta_s - theta_r) * pow((total_head_BC / bubbling_pr), (-1 * lambda)) + theta_r;
+    if (theta_mean < theta_r) {
+        theta_BC = theta_r;
+    } else if (isnan(theta_BC)) {
+        theta_BC = theta_s;
+    }
+    return theta_BC;
+}
+
+SPL_DEV_NOINL double inf_GA_literal(double bub_press, double theta_i, double Ksat, double theta_s, double lambda,
+                                    double P, double tdur, double slop)
+{
+    double r = P / tdur;
+    double h_f = ((2 + 3 * lambda) / (1 + 3 * lambda)) * (bub_press / 2);
+    double delta_head = h_f;
+    double delta_theta = (theta_s - theta_i);
+    double I = 0.0;
+    if (r <= Ksat) {
+        I = P;
+    } else {
+        if (delta_theta <= 0.0) {
+            I = Ksat * tdur;
+        } else {
+            double tp = (Ksat * delta_theta * -1.0 * delta_head) / (r * (r - Ksat));
+            if (tp <= 0.0 || isnan(tp)) tp = 0.01;
+            double cs = cos(slop * kPir);
+            double tp_s = tp / (cs * cs);
+            I = r * tp_s + (Ksat * (tdur - tp_s) -
+                            (delta_head * delta_theta *
+                             log(1 - (r * tp_s / (delta_head * delta_theta)))));
+        }
+    }
+    if (I > P) I = P;
+    return I;
+}
+
+// ---- soil_hydro + soil_info for one cell: R/splash.point.R:232-416, 96-115, :131 (asp-180) -----------------------
+// col[P_NPAR]: the cell's column of the cell-parameter array (k_soil_hydro on the device, the host backend on a CPU)
+SPL_DEV_NOINL void soil_hydro_cell(double lat, double elev, double slop, double asp, double res, double sand,
+                                   double clay, double OM, double fgravel, double bd, double depth_m,
+                                   double au_area, double au_in, double au_out, double* col)
+{
+    double fsand = sand / 100, fclay = clay / 100, fOM = OM / 100; // :261-264
+    fgravel = fgravel / 100;
+    const double depth30 = 30; // :268
+    double dp = 1 / ((fOM / 1.3) + ((1 - fOM) / 2.65));
+    if (isnan(bd)) { // :276
+        bd = (1.5 + (dp - 1.5 - 1.10 * (1 - fclay)) * (1 - exp(-0.022 * depth30))) /
+             (1 + 6.27 * fOM);
+    }
+    if (bd < 0.81) bd = 0.81; // :280
+    double sat = 1 - (bd / dp); // :285
+    double sq_clay = sqrt(fclay); // fclay^0.5
+    double fc = (sat / bd) * (0.4760944 + (0.9402962 - 0.4760944) * sq_clay) *
+                exp(-1 * (0.05472678 * fsand - 0.01 * fOM) / (sat / bd)); // :287
+    double wp_Ball = fc * (0.2018522 + (0.7809203 - 0.2018522) * sq_clay);    // :289
+    double wp = -2.464e-05 * sand + 3.650e-03 * clay + 8.680e-03 * OM + 9.393e-03 * bd; // :294
+    if (!isnan(wp) && wp >= fc) wp = wp_Ball;                                           // :295
+    double coef_B = (log(1500.0) - log(33.0)) / (log(fc) - log(wp)); // :319
+    double coef_A = exp(log(33.0) + coef_B * log(fc));               // :320
+    double coeff_c = 1000.0 / (997 * 9.80665);                       // :326
+    double theta_c = pow((coeff_c * coef_A / 2.0), (1 / (1 + coef_B))); // :327
+    double theta_r = (0.0285 + 0.00336 * (clay)) * bd;                  // :340
+    if (!isnan(theta_r) && theta_r > wp) theta_r = wp;                  // :341
+    sat = sat * (1 - fgravel); // :351-353
+    fc = fc * (1 - fgravel);
+    wp = wp * (1 - fgravel);
+    double coef_lambda = 1 / coef_B;
+    double ksat = 857.48454 / (1 + exp(-2.70927 * fsand + 3.62264 * bd + 7.33398 * fclay +
+                                       -8.11795 * (sat - fc) + 18.75552 * fOM +
+                                       1.03319 * coef_lambda)); // :355-363
+    double m33i = 0.278 * fsand + 0.034 * fclay + 0.022 * fOM - 0.018 * (fsand * fOM) -
+                  0.027 * (fclay * fOM) - 0.584 * (fsand * fclay) + 0.078; // :369
+    double m33 = m33i + (0.636 * m33i - 0.107);                            // :370
+    double bub_init = -21.6 * fsand - 27.93 * fclay - 81.97 * m33 + 71.12 * (fsand * m33) +
+                      8.29 * (fclay * m33) + 14.05 * (fsand * fclay) + 27.16; // :371
+    double bubbling_p = bub_init + (0.02 * (bub_init * bub_init) - 0.113 * bub_init - 0.7); // :372
+    bubbling_p = bubbling_p * -101.97162129779;                                             // :374
+    if (!isnan(bubbling_p) && bubbling_p > 0) bubbling_p = coef_A * -101.97162129779;        // :379
+    double RESv = theta_r * (1 - fgravel); // :410
+
+    col[P_LAT] = lat;
+    col[P_ELV] = elev;
+    col[P_SLOP] = slop;
+    col[P_ASP] = asp - 180; // R/splash.point.R:131
+    col[P_SAT] = sat * depth_m * 1000; // :98-101
+    col[P_WP] = wp * depth_m * 1000;
+    col[P_FC] = fc * depth_m * 1000;
+    col[P_KSAT] = ksat;
+    col[P_LAMBDA] = 1 / coef_B; // :104
+    col[P_DEPTH] = depth_m;
+    col[P_BUB] = bubbling_p;
+    col[P_RES] = RESv * depth_m * 1000;
+    col[P_AU] = au_area;
+    col[P_AI] = res * res; // resolution^2
+    col[P_CELLIN] = au_in;
+    col[P_CELLOUT] = au_out;
+    col[P_WMAXR] = theta_c * depth_m * 1000; // :102
+}
+
 // ---- rain / snow split: R/splash.point.R:120-128, 521-578 -------------------------------------
 // Exponent of the snowfall logistic (:576) in R's own evaluation order,
 //   ((-0.4710405934 + 1.0473543991*tc) - elev*0.0004596581) - |lat|*0.0110592101,
 // with every product and sum rounded separately (no FMA: R's build has none on x86-64).
 // e1 = elev*0.0004596581 and e2 = |lat|*0.0110592101 are the cell-static products.
-__device__ __forceinline__ double snow_logit(double tc, double e1, double e2)
+SPL_DEV double snow_logit(double tc, double e1, double e2)
 {
 #pragma clang fp contract(off)
     return ((-0.4710405934 + 1.0473543991 * tc) - e1) - e2;
@@ -1278,14 +1422,14 @@ __device__ __forceinline__ double snow_logit(double tc, double e1, double e2)
 // A NaN exponent (missing tc) is neither: R's ifelse() then yields NA (see rain_snow_split).
 constexpr double kSnowLogitMax = 0x1.8p-52;
 
-__device__ __forceinline__ double snowfall_prob(double tc, double e1, double e2)
+SPL_DEV double snowfall_prob(double tc, double e1, double e2)
 {
     return 1 / (1 + fexp(snow_logit(tc, e1, e2)));
 }
 
 // Tt is handed over as a callable and fetched only on possible-snow days (k_run_all keeps it in LDS).
 template <class TtSource>
-__device__ __forceinline__ void rain_snow_split(const DayConst& d, double tc, double pn,
+SPL_DEV void rain_snow_split(const DayConst& d, double tc, double pn,
                                                 const TtSource& Tt_of_cell, double e1, double e2,
                                                 double& rain, double& snowfall)
 {

@@ -965,6 +965,104 @@ int grid_worker(const GridPlan& P, int device, int share, const size_t* cells, s
 
 } // namespace
 
+// SPLASH_BACKEND_HOST: every valid cell through host_cell_run (splash_host_backend.hip: the product's own device
+// functions compiled for the host), a few cells per host thread.  For one site or a handful of cells, where a CPU
+// core steps through the chain of day steps faster than a lone wavefront; no device is touched.
+static int grid_on_host(const GridPlan& P, char* err, size_t errlen)
+{
+    const splash_grid_in* in = P.in;
+    const splash_grid_out* out = P.out;
+    const size_t N = P.N;
+    splash_calendar cal;
+    if (int rc = calendar_host(P.nt, in->doy, in->year, in->month, &cal, err, errlen)) return rc;
+    const size_t n_rec = (size_t)P.n_basin * P.nmonth;
+    std::vector<int64_t> acc(P.want_diag ? n_rec * SPLASH_DIAG_REC : 0, 0);
+    static_assert(sizeof(long long) == sizeof(int64_t), "limbs");
+    std::atomic<size_t> next{0};
+    std::atomic<int> rc_all{SPLASH_OK};
+    auto work = [&]() {
+        KnobScope knobs_of_the_call(P.kn);
+        for (;;) {
+            const size_t j = next.fetch_add(1);
+            if (j >= P.nv || rc_all.load() != SPLASH_OK) return;
+            const size_t c = P.idx[j];
+            HostCellIn ci{};
+            ci.nt = P.nt;
+            ci.days = cal.host.data();
+            ci.spin_days = cal.spin_host.empty() ? nullptr : cal.spin_host.data();
+            ci.stride = N;
+            if (in->sw_in) {
+                ci.sw = in->sw_in + c;
+                ci.tc = in->tc + c;
+                ci.pn = in->pn + c;
+            } else {
+                ci.sw32 = in->sw_in_f32 + c;
+                ci.tc32 = in->tc_f32 + c;
+                ci.pn32 = in->pn_f32 + c;
+            }
+            ci.lat = in->lat[c];
+            ci.elev = in->elev[c];
+            ci.slop = in->slop[c];
+            ci.asp = in->asp[c];
+            ci.resolution = in->resolution[c];
+            for (int k = 0; k < 6; k++) ci.soil[k] = in->soil[(size_t)k * N + c];
+            ci.have_au = in->au != nullptr;
+            for (int k = 0; k < 3; k++) ci.au[k] = in->au ? in->au[(size_t)k * N + c] : 0.0;
+            double tt1 = 0.0, st5[5], ai1 = 0.0;
+            if (in->tt) {
+                tt1 = in->tt[c];
+                ci.tt = &tt1;
+            }
+            if (in->state0) {
+                for (int k = 0; k < 5; k++) st5[k] = in->state0[(size_t)k * N + c];
+                ai1 = in->ai0[c];
+                ci.state0 = st5;
+                ci.ai0 = &ai1;
+            }
+            ci.monthly = P.monthly;
+            ci.want_passes = out->aux != nullptr;
+            HostCellOut co{};
+            for (int k = 0; k < SPLASH_NOUT; k++) {
+                if (out->out[k]) co.out[k] = out->out[k] + c;
+                else if (out->out_f32[k]) co.out32[k] = out->out_f32[k] + c;
+            }
+            co.ldo = N;
+            if (P.want_diag) {
+                const int b = in->basin ? in->basin[c] : 0;
+                if ((unsigned)b < (unsigned)P.n_basin) co.diag_rec = (long long*)acc.data() + (size_t)b * P.nmonth * SPLASH_DIAG_REC;
+            }
+            if (int rc = host_cell_run(ci, co)) {
+                rc_all.store(rc);
+                return;
+            }
+            if (out->state_end)
+                for (int k = 0; k < 5; k++) out->state_end[(size_t)k * N + c] = co.state_end[k];
+            if (out->aux) {
+                out->aux[c] = co.tt;
+                out->aux[N + c] = co.ai;
+                out->aux[2 * N + c] = co.passes1;
+                out->aux[3 * N + c] = co.passes2;
+            }
+        }
+    };
+    unsigned nthr = std::thread::hardware_concurrency();
+    nthr = nthr == 0 ? 4 : (nthr > 16 ? 16 : nthr);
+    nthr = (unsigned)std::min<size_t>(nthr, P.nv);
+    if (nthr <= 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < nthr; w++) pool.emplace_back(work);
+        for (auto& t : pool) t.join();
+    }
+    if (rc_all.load() != SPLASH_OK) return fail(rc_all.load(), err, errlen, "grid_run (host backend): a cell failed");
+    if (P.want_diag) {
+        if (out->diag_acc) std::copy(acc.begin(), acc.end(), out->diag_acc);
+        if (out->diag) splash_diag_finalize_host(acc.data(), P.n_basin, P.nmonth, out->diag, nullptr);
+    }
+    return SPLASH_OK;
+}
+
 // the call itself, on whatever thread runs it (the caller's, or the job thread of splash_grid_submit:
 // the environment knobs were sampled by the entry point, on the caller's thread)
 static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const splash_grid_out* out, char* err,
@@ -993,7 +1091,12 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
         if (out->out[k] && out->out_f32[k])
             return fail(SPLASH_EINVAL, err, errlen, "grid_run: series %d asked for in double AND single precision "
                         "(out[k] and out_f32[k]): one array per series", k);
-    if (int rc = need_device(err, errlen)) return rc;
+    const int backend = opt ? opt->backend : SPLASH_BACKEND_HIP;
+    if (backend != SPLASH_BACKEND_HIP && backend != SPLASH_BACKEND_HOST)
+        return fail(SPLASH_EINVAL, err, errlen, "grid_run: unknown backend %d", backend);
+    const bool on_host = backend == SPLASH_BACKEND_HOST; // an explicit choice (ABI 6), never a fallback:
+    if (!on_host)                                        // the default backend needs a HIP device
+        if (int rc = need_device(err, errlen)) return rc;
 
     // devices: one worker per entry of the list (the same ordinal may repeat)
     std::vector<int> devs;
@@ -1002,9 +1105,9 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
     } else {
         devs.push_back(opt ? ((opt->n_devices == 1 && opt->devices) ? opt->devices[0] : opt->device) : 0);
     }
-    const int ndev_present = splash_hip_device_count();
+    const int ndev_present = on_host ? 0 : splash_hip_device_count();
     for (int d : devs)
-        if (d < 0 || d >= ndev_present)
+        if (!on_host && (d < 0 || d >= ndev_present))
             return fail(SPLASH_EINVAL, err, errlen, "grid_run: device %d not present (%d visible)", d,
                         ndev_present);
 
@@ -1101,6 +1204,7 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
     if (out->diag) std::fill(out->diag, out->diag + n_rec * SPLASH_NDIAG, 0.0);
     if (out->diag_acc) std::fill(out->diag_acc, out->diag_acc + n_rec * SPLASH_DIAG_REC, (int64_t)0);
     if (P.nv == 0) return SPLASH_OK;
+    if (on_host) return grid_on_host(P, err, errlen);
 
     const double t_scan = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     // One worker per listed device.  Round 6: the valid cells are cut into CHUNKS that are dealt round-robin

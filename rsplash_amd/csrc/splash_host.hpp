@@ -127,9 +127,45 @@ constexpr size_t kMaxCellsPerLaunch = (1ull << 29) - 1;
 constexpr int kSpinPhases = 8;
 size_t spin_work_layout(size_t ncell, size_t* o_wl_b, size_t* o_meta, size_t* o_ai, size_t* o_cnt,
                         size_t* o_cache = nullptr, size_t* o_pend = nullptr);
+// the host part of splash_calendar_create (orbit per day, month bookkeeping, the spin-up's own 365 entries): no device
+int calendar_host(int nt, const int* doy, const int* year, const int* month, splash_calendar* cal, char* err, size_t errlen);
+void orbit_of_day(int doy, int year, double& dr, double& sd, double& cd);
 int spin_phases(const splash_calendar* cal, size_t ncell, const double* sw_in, const double* tc,
                 const double* pn, size_t ldf, const double* Tt, double* cellpar, size_t ldp,
                 double* state, size_t lds, int* passes, void* work, void* stream, int ph0, int ph1);
+
+// ---- SPLASH_BACKEND_HOST (splash_host_backend.hip): splash.point for ONE cell on the calling CPU thread ----
+struct HostCellIn {
+    int nt;
+    const DayRec* days;       // [nt] calendar table (splash_calendar::host)
+    const DayRec* spin_days;  // [365] spin-up table (splash_calendar::spin_host); unused when state0 is given
+    const double *sw, *tc, *pn;       // the cell's series, element t at [t * stride]; or (sw == NULL) ...
+    const float *sw32, *tc32, *pn32;  // ... the single-precision transport
+    size_t stride;
+    double lat, elev, slop, asp, resolution, soil[6], au[3];
+    bool have_au;
+    const double* tt;      // optional: the whole series' snowfall threshold (time chunks), else computed
+    const double* state0;  // optional [5] + ai0: continuing a run (no spin-up)
+    const double* ai0;
+    int monthly, want_passes;
+};
+struct HostCellOut {
+    double* out[SPLASH_NOUT];     // series k at [t_out * ldo], NULL to skip ...
+    float* out32[SPLASH_NOUT];    // ... or single precision
+    size_t ldo;
+    long long* diag_rec;          // the exact limbs of the cell's basin, [nmonth][SPLASH_NDIAG+1][2], or NULL
+    double state_end[5], tt, ai;
+    int passes1, passes2;
+};
+int host_cell_run(const HostCellIn& in, HostCellOut& out);
+bool host_backend_fma();
+void host_mod_spin_up(const double* par, int n, const DayRec* days, const double* sw, const double* tc, const double* pn,
+                      const double* snowfall, double* const series[7], int* passes);
+double host_mod_moist_surf(double depth, double z, double bub_p, double wn, double SAT, double RES, double lambda);
+double host_mod_inf_GA(double bub_press, double theta_i, double Ksat, double theta_s, double lambda, double P, double tdur,
+                       double slop);
+void host_mod_run_all(const double* par, int nt, const DayRec* days, const double* sw, const double* tc, const double* pn,
+                      const double* snowfall, const double* st0, double* const dst[11]);
 
 } // namespace host
 } // namespace splash

@@ -33,67 +33,12 @@ __global__ __launch_bounds__(kBlock) void k_soil_hydro(
 {
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= ncell) return;
-    const double sand = soil[i], clay = soil[ncell + i], OM = soil[2 * ncell + i];
-    double fgravel = soil[3 * ncell + i], bd = soil[4 * ncell + i];
-    const double depth_m = soil[5 * ncell + i];
-
-    double fsand = sand / 100, fclay = clay / 100, fOM = OM / 100; // :261-264
-    fgravel = fgravel / 100;
-    const double depth30 = 30; // :268
-    double dp = 1 / ((fOM / 1.3) + ((1 - fOM) / 2.65));
-    if (isnan(bd)) { // :276
-        bd = (1.5 + (dp - 1.5 - 1.10 * (1 - fclay)) * (1 - exp(-0.022 * depth30))) /
-             (1 + 6.27 * fOM);
-    }
-    if (bd < 0.81) bd = 0.81; // :280
-    double sat = 1 - (bd / dp); // :285
-    double sq_clay = sqrt(fclay); // fclay^0.5
-    double fc = (sat / bd) * (0.4760944 + (0.9402962 - 0.4760944) * sq_clay) *
-                exp(-1 * (0.05472678 * fsand - 0.01 * fOM) / (sat / bd)); // :287
-    double wp_Ball = fc * (0.2018522 + (0.7809203 - 0.2018522) * sq_clay);    // :289
-    double wp = -2.464e-05 * sand + 3.650e-03 * clay + 8.680e-03 * OM + 9.393e-03 * bd; // :294
-    if (!isnan(wp) && wp >= fc) wp = wp_Ball;                                           // :295
-    double coef_B = (log(1500.0) - log(33.0)) / (log(fc) - log(wp)); // :319
-    double coef_A = exp(log(33.0) + coef_B * log(fc));               // :320
-    double coeff_c = 1000.0 / (997 * 9.80665);                       // :326
-    double theta_c = pow((coeff_c * coef_A / 2.0), (1 / (1 + coef_B))); // :327
-    double theta_r = (0.0285 + 0.00336 * (clay)) * bd;                  // :340
-    if (!isnan(theta_r) && theta_r > wp) theta_r = wp;                  // :341
-    sat = sat * (1 - fgravel); // :351-353
-    fc = fc * (1 - fgravel);
-    wp = wp * (1 - fgravel);
-    double coef_lambda = 1 / coef_B;
-    double ksat = 857.48454 / (1 + exp(-2.70927 * fsand + 3.62264 * bd + 7.33398 * fclay +
-                                       -8.11795 * (sat - fc) + 18.75552 * fOM +
-                                       1.03319 * coef_lambda)); // :355-363
-    double m33i = 0.278 * fsand + 0.034 * fclay + 0.022 * fOM - 0.018 * (fsand * fOM) -
-                  0.027 * (fclay * fOM) - 0.584 * (fsand * fclay) + 0.078; // :369
-    double m33 = m33i + (0.636 * m33i - 0.107);                            // :370
-    double bub_init = -21.6 * fsand - 27.93 * fclay - 81.97 * m33 + 71.12 * (fsand * m33) +
-                      8.29 * (fclay * m33) + 14.05 * (fsand * fclay) + 27.16; // :371
-    double bubbling_p = bub_init + (0.02 * (bub_init * bub_init) - 0.113 * bub_init - 0.7); // :372
-    bubbling_p = bubbling_p * -101.97162129779;                                             // :374
-    if (!isnan(bubbling_p) && bubbling_p > 0) bubbling_p = coef_A * -101.97162129779;        // :379
-    double RESv = theta_r * (1 - fgravel); // :410
-
-    double res = resolution[i];
-    par[P_LAT * ncell + i] = lat[i];
-    par[P_ELV * ncell + i] = elev[i];
-    par[P_SLOP * ncell + i] = slop[i];
-    par[P_ASP * ncell + i] = asp[i] - 180; // R/splash.point.R:131
-    par[P_SAT * ncell + i] = sat * depth_m * 1000; // :98-101
-    par[P_WP * ncell + i] = wp * depth_m * 1000;
-    par[P_FC * ncell + i] = fc * depth_m * 1000;
-    par[P_KSAT * ncell + i] = ksat;
-    par[P_LAMBDA * ncell + i] = 1 / coef_B; // :104
-    par[P_DEPTH * ncell + i] = depth_m;
-    par[P_BUB * ncell + i] = bubbling_p;
-    par[P_RES * ncell + i] = RESv * depth_m * 1000;
-    par[P_AU * ncell + i] = au ? au[i] : 0.0;
-    par[P_AI * ncell + i] = res * res; // resolution^2
-    par[P_CELLIN * ncell + i] = au ? au[ncell + i] : 3.0;
-    par[P_CELLOUT * ncell + i] = au ? au[2 * ncell + i] : 3.0;
-    par[P_WMAXR * ncell + i] = theta_c * depth_m * 1000; // :102
+    double col[P_NPAR];
+    soil_hydro_cell(lat[i], elev[i], slop[i], asp[i], resolution[i], soil[i], soil[ncell + i], soil[2 * ncell + i],
+                    soil[3 * ncell + i], soil[4 * ncell + i], soil[5 * ncell + i],
+                    au ? au[i] : 0.0, au ? au[ncell + i] : 3.0, au ? au[2 * ncell + i] : 3.0, col);
+#pragma unroll
+    for (int k = 0; k < P_NPAR; k++) par[(size_t)k * ncell + i] = col[k];
 }
 
 // ================================================================ K2 snow threshold ===========
@@ -1280,54 +1225,20 @@ __global__ __launch_bounds__(kBlock) void k_infiltration_probe(size_t n, const d
     infi[i] = inf_GA(c, wn[i], ksat[i], P[i]);
 }
 
-// general-argument forms of the two exported helper methods (src/SPLASH.cpp:1921-1961, 1963-2023)
+// general-argument forms of the two exported helper methods (src/SPLASH.cpp:1921-1961, 1963-2023): the literal
+// statements live in splash_device.hpp (moist_surf_literal, inf_GA_literal), shared with the host backend
 __global__ void k_moist_surf(double depth, double z, double bub_p, double wn, double SAT,
                              double RES, double lambda, double* out)
 {
     lds_tables_init();
-    double theta_r = RES / (depth * 1000.0);
-    double theta_s = SAT / (depth * 1000.0);
-    double bubbling_pr = bub_p / 10;
-    double theta_mean = (wn) / (depth * 1000.0);
-    double water_pot_BC =
-        bubbling_pr / pow((((theta_mean - theta_r) / (theta_s - theta_r))), (1 / lambda));
-    double total_head_BC = water_pot_BC + z;
-    double theta_BC =
-        (theta_s - theta_r) * pow((total_head_BC / bubbling_pr), (-1 * lambda)) + theta_r;
-    if (theta_mean < theta_r) {
-        theta_BC = theta_r;
-    } else if (isnan(theta_BC)) {
-        theta_BC = theta_s;
-    }
-    *out = theta_BC;
+    *out = moist_surf_literal(depth, z, bub_p, wn, SAT, RES, lambda);
 }
 
 __global__ void k_inf_GA(double bub_press, double theta_i, double Ksat, double theta_s,
                          double lambda, double P, double tdur, double slop, double* out)
 {
     lds_tables_init();
-    double r = P / tdur;
-    double h_f = ((2 + 3 * lambda) / (1 + 3 * lambda)) * (bub_press / 2);
-    double delta_head = h_f;
-    double delta_theta = (theta_s - theta_i);
-    double I = 0.0;
-    if (r <= Ksat) {
-        I = P;
-    } else {
-        if (delta_theta <= 0.0) {
-            I = Ksat * tdur;
-        } else {
-            double tp = (Ksat * delta_theta * -1.0 * delta_head) / (r * (r - Ksat));
-            if (tp <= 0.0 || isnan(tp)) tp = 0.01;
-            double cs = cos(slop * kPir);
-            double tp_s = tp / (cs * cs);
-            I = r * tp_s + (Ksat * (tdur - tp_s) -
-                            (delta_head * delta_theta *
-                             log(1 - (r * tp_s / (delta_head * delta_theta)))));
-        }
-    }
-    if (I > P) I = P;
-    *out = I;
+    *out = inf_GA_literal(bub_press, theta_i, Ksat, theta_s, lambda, P, tdur, slop);
 }
 
 // single-precision transport of forcing rasters (FLT4S in the reference): widen on the device

@@ -202,12 +202,10 @@ SPL_HD double flog(double x)
         const unsigned rh = (x != x) ? 0x7FF80000u : (unsigned)(rb >> 32);
         return __builtin_bit_cast(double, ((unsigned long long)rh << 32) | (rb & 0xFFFFFFFFull));
     }
-#if defined(__HIP_DEVICE_COMPILE__)
-    // `res` is a finished value BEFORE the patches below select it: without the pin the compiler sinks the last
-    // additions into the x > 0 arm and turns the select into an execution-mask branch (s_and_saveexec, s_xor,
-    // s_andn2_saveexec, s_cbranch_execz around six instructions) at every call site
-    asm volatile("" : "+v"(res));
-#endif
+    // (The compiler sinks the last additions into the x > 0 arm of the patch below and emits an execution-mask
+    //  branch around them at every call site.  Pinning `res` before the select removes those branches -- measured,
+    //  round 6: within the run-to-run noise of the spin-up's tail -- but changes which multiply the compiler fuses
+    //  downstream: the product's pinned bits moved.  Left alone.)
     if (DOMAIN == kLogFull) res = (x < HUGE_VAL) ? res : x; // +inf (NaN falls through to the next line)
     res = (x > 0.0) ? res : ((x == 0.0) ? -HUGE_VAL : __builtin_nan("")); // 0 -> -inf, <0/NaN -> NaN
     return res;

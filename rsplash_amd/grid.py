@@ -164,6 +164,10 @@ def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control
     nl = z_out.size
     if not monthly and nl != nt:
         raise ValueError("daily output needs whole calendar years of input (R/splash.grid.R:161-181)")
+    nm_in = int(api.month_ids(*api.time_fields(ztime)[1:])[-1]) + 1
+    if monthly and nm_in != nl:   # (write_bricks raises on the same mismatch; a streamed brick would keep layers nobody writes)
+        raise ValueError(f"monthly output: the input covers {nm_in} calendar months, the output time axis of whole "
+                         f"years {y0}-{y1} has {nl} layers (R/splash.grid.R:161-181)")
     keys = api.OUT_NAMES
     writer = None
     mats = None
@@ -243,6 +247,14 @@ def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control
                 store(res_p, r0, nr, prev[1], prev[2])
                 if progress:
                     progress(i + 1, len(bs))
+        except BaseException:
+            for j in jobs:
+                j.close()
+            jobs = []
+            if writer:
+                writer.discard()   # no partial bricks whose missing blocks would read as data
+                writer = None
+            raise
         finally:
             for j in jobs:
                 j.close()
@@ -264,9 +276,18 @@ def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control
             store(res, r0, nr, 0, 0)
             if progress:
                 progress(i + 1, len(bs))
-    finally:
+    except BaseException:
         for j in jobs:          # an error mid-way: wait for what is still in the library before the
             if j is not None:   # arrays it reads and writes go away
+                j.close()
+        jobs = []
+        if writer:
+            writer.discard()    # ... and leave no partial bricks behind
+            writer = None
+        raise
+    finally:
+        for j in jobs:
+            if j is not None:
                 j.close()
         if writer:
             writer.close()

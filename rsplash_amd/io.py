@@ -174,7 +174,7 @@ class BrickWriter:
         z, zval, zunit, y0, y1 = output_time_axis(time_index, monthly_out)
         lon, lat = np.asarray(lon, dtype=np.float64), np.asarray(lat, dtype=np.float64)
         self.nl, self.shape = z.size, (lat.size, lon.size)
-        self.paths, self._maps = {}, {}
+        self.paths, self._maps, self._seen = {}, {}, {}
         os.makedirs(outdir, exist_ok=True)
         for key in keys:
             if key not in BRICKS:
@@ -198,6 +198,10 @@ class BrickWriter:
             o, shp, dt = lay[varname]
             self._maps[key] = np.memmap(path, dtype=dt, mode="r+", offset=o, shape=shp)
             self.paths[key] = path
+            # which (layer, row) stripes have been stored: whatever is still unwritten at close() becomes the
+            # fill value -- the file is created with all-zero data, and a layer or row that never arrives (a time
+            # axis longer than the months computed, a run that ends early) must read back as NA, not as 0.0
+            self._seen[key] = np.zeros((z.size, lat.size), bool)
 
     def write(self, key, row0, block, t0=0):
         """block [nl_b, nrows, ncol] -> layers t0..t0+nl_b, rows row0..row0+nrows (t0 > 0: a later time
@@ -209,15 +213,35 @@ class BrickWriter:
         if (b.ndim != 3 or t0 < 0 or t0 + b.shape[0] > self.nl or b.shape[2] != self.shape[1] or row0 + b.shape[1] > self.shape[0]):
             raise ValueError(f"{key}: block {b.shape} at layer {t0}, row {row0} does not fit a brick of {(self.nl,) + self.shape}")
         m[t0:t0 + b.shape[0], row0:row0 + b.shape[1], :] = np.where(np.isnan(b), NA_FLT4S, b)
+        self._seen[key][t0:t0 + b.shape[0], row0:row0 + b.shape[1]] = True
 
     def close(self):
-        for m in self._maps.values():
+        """flush and unmap; every (layer, row) stripe that was never written is set to the fill value first"""
+        for key, m in self._maps.items():
+            seen = self._seen[key]
+            if not seen.all():
+                for t in np.nonzero(~seen.all(1))[0]:
+                    m[t, ~seen[t], :] = NA_FLT4S
             m.flush()
-        self._maps = {}
+        self._maps, self._seen = {}, {}
+
+    def discard(self):
+        """a run that failed midway: unmap and REMOVE the partial bricks (a reader must not find files whose
+        missing blocks look like data)"""
+        self._maps, self._seen = {}, {}
+        for p in self.paths.values():
+            try:
+                os.remove(p)
+            except OSError:
+                pass
+        self.paths = {}
 
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
-        self.close()
+        if exc and exc[0] is not None:
+            self.discard()
+        else:
+            self.close()
         return False

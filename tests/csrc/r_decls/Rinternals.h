@@ -20,6 +20,7 @@ Rboolean Rf_isNull(SEXP s);
 Rboolean Rf_isInteger(SEXP s);
 Rboolean Rf_isReal(SEXP s);
 int Rf_asLogical(SEXP x);
+int Rf_asInteger(SEXP x);
 double Rf_asReal(SEXP x);
 int LENGTH(SEXP x);
 R_xlen_t XLENGTH(SEXP x);
@@ -48,6 +49,7 @@ void R_RegisterCFinalizerEx(SEXP s, R_CFinalizer_t fun, Rboolean onexit);
 #define isInteger Rf_isInteger
 #define isReal Rf_isReal
 #define asLogical Rf_asLogical
+#define asInteger Rf_asInteger
 #define asReal Rf_asReal
 #define mkNamed Rf_mkNamed
 #define allocMatrix Rf_allocMatrix

@@ -1,6 +1,7 @@
 // Drives the C++ host mirror (include/splash.hpp) the way an Rcpp-free C++ caller would.
 //   test_cpp_mirror                  link/throw check: without a GPU the call must throw
-//   test_cpp_mirror in.bin out.bin   one site: spin_up on year y, then run_all over the same year
+//   test_cpp_mirror in.bin out.bin [host]   one site: spin_up on year y, then run_all over the same year
+//                                           (third argument "host": SPLASH_BACKEND_HOST, no GPU needed)
 // in.bin : doubles  n, y, lat, elv, slop, asp, soil_info[12], sw[n], ta[n], pn[n], snowfall[n]
 // out.bin: doubles  spin_up {sm,snow,qin,tdrain,ro,snwage,pet}[n], run_all 11 series [n]
 #include <cstdio>
@@ -38,7 +39,8 @@ int main(int argc, char** argv)
     size_t at = 6;
     std::vector<double> soil = take(in, at, 12), sw = take(in, at, n), ta = take(in, at, n),
                         pn = take(in, at, n), sf = take(in, at, n);
-    splash::SPLASH sp(in[2], in[3]);
+    const bool on_host = argc > 3 && std::string(argv[3]) == "host";
+    splash::SPLASH sp(in[2], in[3], on_host ? SPLASH_BACKEND_HOST : SPLASH_BACKEND_HIP);
     splash::List s = sp.spin_up(n, y, sw, ta, pn, in[4], in[5], sf, soil);
     std::vector<int> doys(n), yrs(n, y);
     for (int i = 0; i < n; i++) doys[i] = i + 1;

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in include/splash_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.lib.splash_hip_abi_version() == 5
+    assert _lib.lib.splash_hip_abi_version() == 6
 
 
 def test_product_never_touches_the_oracle():

@@ -307,6 +307,53 @@ def test_splash_point_bourne(api, oracle, bourne, flat, monthly):
     print("max |dwn| =", np.max(np.abs(g["wn"] - o["wn"])))
 
 
+def test_host_and_device_backends_agree(api, oracle, bourne):
+    """ABI 6: SPLASH_BACKEND_HOST is the library's own device functions compiled for the host -- a
+    second executable of the product's arithmetic.  The two backends must agree to rounding: on the bundled Bourne site
+    (all nine series, daily and monthly; BASELINE.json configs[0]) and, cell for cell, on a synthetic terrain grid of
+    1 024 cells (each backend from its OWN spin-up: pass counts, aridity index, snowfall threshold, every daily value
+    of every cell in which neither run meets a critical event of the reference).  The host side is compared with the
+    oracle on the CPU in tests/test_host_backend.py; R/splash.point.R:92-172."""
+    import time
+    b, s = bourne, bourne["site"]
+    for monthly in (False, True):
+        kw = dict(time_index=b["dates"], monthly_out=monthly)
+        args = (b["sw_in"], b["Ta"], b["P"], s["latitude"], s["elev_m"], s["slop_250m"], s["asp_250m"], b["soil"],
+                s["Aups_250m"], s["resolution"])
+        d = api.splash_point(*args, **kw)
+        t0 = time.perf_counter()
+        d = api.splash_point(*args, **kw)
+        t1 = time.perf_counter()
+        h = api.splash_point(*args, backend="host", **kw)
+        t2 = time.perf_counter()
+        worst = {}
+        for k in d:
+            with np.errstate(invalid="ignore", divide="ignore"):
+                e = np.where(np.abs(d[k]) > 1e-6, np.abs(h[k] - d[k]) / np.abs(d[k]), np.abs(h[k] - d[k]))
+            worst[k] = float(np.nanmax(e))
+        print(f"Bourne, monthly={monthly}: device {1e3 * (t1 - t0):.1f} ms, host {1e3 * (t2 - t1):.1f} ms; host vs device max rel "
+              f"{ {k: f'{v:.1e}' for k, v in worst.items()} }")
+        assert max(worst.values()) < 1e-10, worst
+    H, W, nt = 16, 64, 400
+    dd = _synth(oracle, H, W, nt, 1, seed=4711)
+    st = dd["st"]
+    args = (dd["sw"], dd["tc"], dd["pn"], st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"], st["resolution"])
+    kw = dict(time_index=dd["dates"], sim_control=dict(monthly_out=False), want_aux=True)
+    g = api.splash_grid(*args, **kw)
+    h = api.splash_grid(*args, backend="host", **kw)
+    _, aux = oracle.grid(dd["doy"], dd["year"], dd["month"], dd["mid"], dd["nm"], dd["sw"], dd["tc"], dd["pn"], st["lat"],
+                         st["elev"], st["slop"], st["asp"], st["soil"], st["au"], st["resolution"])
+    calm = aux["critical"] == 0
+    assert calm.mean() > 0.9
+    assert np.array_equal(g["aux"]["Tt"], h["aux"]["Tt"])
+    assert np.array_equal(g["aux"]["passes2"][calm], h["aux"]["passes2"][calm])
+    assert np.allclose(g["aux"]["AI"][calm], h["aux"]["AI"][calm], rtol=1e-10, atol=0)
+    from oracle.parity import _bad, _floor
+    for k in ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "sm_lim"):
+        bad = _bad(h[k], g[k], floor=_floor(k, g))[:, calm]
+        assert bad.mean() <= 1e-5, (k, int(bad.sum()))
+
+
 @pytest.mark.parametrize("slop,asp", [(0.0, 0.0), (12.0, 215.0)])
 def test_splash_point_atneu(api, oracle, atneu, slop, asp):
     """the reference's second bundled site (FLUXNET AT-Neu, 11 years, measured bulk density)"""
@@ -1212,7 +1259,7 @@ def test_config4_full_size_0p5_degree_land_mask_30_years_properties(api):
     water-balance totals for 72 basins.  No oracle at this size (30 years x 67 k cells is hours of CPU): the
     size-independent properties -- idempotence (two runs: the same bits in every raster, every exact limb of the
     totals and the end state), bounds (RES <= monthly mean wn <= SAT, snow/ro/aet/pet >= 0, all finite), a sane
-    pass-count histogram of the spin-up (2 <= passes <= 1000, median <= 6, under 1 % capped), and totals == the sums
+    pass-count histogram of the spin-up (1 <= passes <= 1000, median <= 6, under 1 % capped), and totals == the sums
     of the rasters (per basin and month, to 1e-12).  R/splash.grid.R:260-314 with data/SA_cru.RData's layout."""
     import torch
     dev = torch.device("cuda:0")
@@ -1289,7 +1336,7 @@ def test_config4_full_size_0p5_degree_land_mask_30_years_properties(api):
     hist = np.bincount(np.minimum(p2, 12), minlength=13)
     print(f"config 4 at full size: {n} land cells x {nt} days; passes of spin-up #2: histogram 0..11, >=12 = {hist.tolist()}, "
           f"capped {int((p2 >= 1000).sum())}")
-    assert p2.min() >= 2 and p2.max() <= 1000 and np.median(p2) <= 6 and (p2 >= 1000).mean() < 0.01
+    assert p2.min() >= 1 and p2.max() <= 1000 and np.median(p2) <= 6 and (p2 >= 1000).mean() < 0.01
     diag = torch.zeros(n_basin, nm, api.NDIAG, **f64)
     api.dev_diag_finalize(a["acc"], n_basin, nm, diag)
     d = diag.cpu().numpy()

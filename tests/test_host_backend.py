@@ -1,0 +1,190 @@
+"""SPLASH_BACKEND_HOST (ABI 6): the product's own day step -- the library's device functions compiled for the host
+(rsplash_amd/csrc/splash_host_backend.hip) -- against the oracle, on the CPU: these tests need no GPU and run in the
+build container every round.  BASELINE.json configs[0] ("splash.point on the bundled Bourne SNOTEL station, CPU
+reference path (plumbing, no GPU)") is exercised here as written; the GPU suite compares the two backends with each
+other (tests/test_gpu_parity.py::test_host_and_device_backends_agree).
+
+The host backend is an explicit option, never a fallback: the default backend without a device still fails loudly
+(tests/test_abi.py::test_no_gpu_means_loud_failure)."""
+import time
+
+import numpy as np
+import pytest
+
+RTOL, ATOL = 1e-5, 1e-9
+
+
+@pytest.fixture(scope="module")
+def api():
+    import rsplash_amd
+    rsplash_amd.build_library()
+    from rsplash_amd import api as a
+    return a
+
+
+def close(x, ref, name="", rtol=RTOL, atol=ATOL):
+    x, ref = np.asarray(x, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert x.shape == ref.shape, (name, x.shape, ref.shape)
+    assert (np.isnan(x) == np.isnan(ref)).all(), f"{name}: NaN pattern differs"
+    with np.errstate(invalid="ignore"):
+        d = np.abs(x - ref)
+        bad = ~((d <= rtol * np.abs(ref) + atol) | (x == ref) | np.isnan(ref))
+    assert not bad.any(), f"{name}: {int(bad.sum())} of {bad.size} out of tolerance, worst {np.nanmax(d / np.maximum(np.abs(ref), 1e-300)):.3e}"
+    with np.errstate(invalid="ignore", divide="ignore"):   # reported: the raw relative error of values that are not tiny
+        e = np.where(np.isfinite(ref) & (np.abs(ref) > 1e-6), d / np.abs(ref), 0.0)
+    return float(np.nanmax(e)) if e.size else 0.0
+
+
+@pytest.mark.parametrize("flat", [False, True])
+@pytest.mark.parametrize("monthly", [False, True])
+def test_splash_point_bourne_on_the_host(api, oracle, bourne, flat, monthly):
+    """BASELINE.json configs[0] as written: splash.point on the bundled Bourne SNOTEL site (README.md:28-61;
+    R/splash.point.R:29-225), no GPU.  All nine outputs against the oracle."""
+    b, s = bourne, bourne["site"]
+    slop, asp = (0.0, 0.0) if flat else (s["slop_250m"], s["asp_250m"])
+    t0 = time.perf_counter()
+    g = api.splash_point(b["sw_in"], b["Ta"], b["P"], s["latitude"], s["elev_m"], slop, asp, b["soil"], s["Aups_250m"],
+                         s["resolution"], time_index=b["dates"], monthly_out=monthly, backend="host")
+    dt = time.perf_counter() - t0
+    o, aux = oracle.point(b["doy"], b["year"], b["month"], b["month_id"], b["nmonth"], b["sw_in"], b["Ta"], b["P"],
+                          s["latitude"], s["elev_m"], slop, asp, b["soil"], [s["Aups_250m"], 3, 3], s["resolution"],
+                          monthly_out=monthly)
+    worst = {k: close(g[k], o[k], f"host point[{'flat' if flat else 'slope'}].{k}") for k in o}
+    print(f"host backend, Bourne ({len(b['doy'])} days): {1e3 * dt:.1f} ms; max rel err", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) < 1e-7      # (the tolerance is 1e-5: the host build sits near rounding level)
+
+
+@pytest.mark.parametrize("slop,asp", [(0.0, 0.0), (12.0, 215.0)])
+def test_splash_point_atneu_on_the_host(api, oracle, atneu, slop, asp):
+    b, s = atneu, atneu["site"]
+    au = 0.0 if slop == 0.0 else 40000.0
+    g = api.splash_point(b["sw_in"], b["Ta"], b["P"], s["latitude"], s["elev_m"], slop, asp, b["soil"], au, 250.0,
+                         time_index=b["dates"], monthly_out=False, backend="host")
+    o, aux = oracle.point(b["doy"], b["year"], b["month"], b["month_id"], b["nmonth"], b["sw_in"], b["Ta"], b["P"],
+                          s["latitude"], s["elev_m"], slop, asp, b["soil"], [au, 3, 3], 250.0)
+    worst = {k: close(g[k], o[k], f"host atneu[{slop}].{k}") for k in o}
+    print("max rel err", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+def test_module_mirrors_on_the_host(api, oracle, bourne):
+    """the Rcpp module's methods (src/SPLASH.h:85-103) with the host backend: spin_up, run_all, run_one_year,
+    moist_surf, inf_GA against the oracle's"""
+    b, s = bourne, bourne["site"]
+    si, wmax_r = oracle.soil_info(b["soil"], [s["Aups_250m"], 3, 3], s["resolution"])
+    Tt, rain, snowf = oracle.snow_partition(b["Ta"], b["P"], b["month"], s["latitude"], s["elev_m"])
+    asp = s["asp_250m"] - 180
+    sp = api.SPLASH(s["latitude"], s["elev_m"], backend="host")
+    y0 = int(b["year"][0])
+    g = sp.spin_up(365, y0, b["sw_in"][:365], b["Ta"][:365], rain[:365], s["slop_250m"], asp, snowf[:365], si)
+    o = oracle.spin_up(s["latitude"], s["elev_m"], 365, y0, b["sw_in"][:365], b["Ta"][:365], rain[:365],
+                       s["slop_250m"], asp, snowf[:365], si)
+    assert g["passes"] == o["passes"]
+    for k in ("sm", "snow", "qin", "tdrain", "ro", "pet"):
+        close(g[k], o[k], "host spin_up." + k)
+    assert np.array_equal(g["snwage"], o["snwage"])
+    r = sp.run_all(b["doy"], b["year"], b["sw_in"], b["Ta"], rain, o["sm"][-1], s["slop_250m"], asp, o["snow"][-1],
+                   snowf, si, o["qin"][-1], o["tdrain"][-1], o["snwage"][-1])
+    q = oracle.run_all(s["latitude"], s["elev_m"], b["doy"], b["year"], b["sw_in"], b["Ta"], rain, o["sm"][-1],
+                       s["slop_250m"], asp, o["snow"][-1], snowf, si, o["qin"][-1], o["tdrain"][-1], o["snwage"][-1])
+    for k in ("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "qin_prev", "tdrain"):
+        close(r[k], q[k], "host run_all." + k)
+    assert np.array_equal(r["snwage"], q["snwage"])
+    yr = sp.run_one_year(365, y0, b["sw_in"][:365], b["Ta"][:365], rain[:365], o["sm"], s["slop_250m"], asp, o["snow"],
+                         snowf[:365], si, o["qin"], o["tdrain"], o["snwage"])
+    close(yr["wn"], r["wn"][:365], "host run_one_year.wn", rtol=1e-12)
+    # the two helper methods, literal forms (src/SPLASH.cpp:1921-1961, 1963-2023)
+    rng = np.random.default_rng(3)
+    L = oracle.lib
+    for _ in range(200):
+        depth = rng.uniform(0.6, 2.0)
+        SAT, RES = rng.uniform(200, 600), rng.uniform(10, 60)
+        wn = rng.choice([RES, SAT, rng.uniform(RES, SAT), RES - 1.0])
+        lam, bub = rng.uniform(0.1, 0.6), -rng.uniform(100, 3000)
+        a = api.SPLASH.moist_surf(depth, 10.0, bub, wn, SAT, RES, lam, backend="host")
+        f = L.orc_moist_surf(depth, 10.0, bub, wn, SAT, RES, lam)
+        assert a == pytest.approx(f, rel=1e-12)
+        th_s = SAT / (depth * 1000)
+        th_i = rng.choice([th_s, th_s * rng.uniform(0.1, 0.99), th_s + 0.01])
+        Ks = rng.uniform(0.05, 40)
+        P = rng.choice([0.0, rng.uniform(0, 5), rng.uniform(5, 300)])
+        slop = rng.choice([0.0, rng.uniform(0, 60)])
+        a = api.SPLASH.inf_GA(bub, th_i, Ks, th_s, lam, P, 6.0, slop, backend="host")
+        f = L.orc_inf_GA(bub, th_i, Ks, th_s, lam, P, 6.0, slop)
+        assert a == pytest.approx(f, rel=1e-11, abs=1e-300)
+
+
+def test_splash_grid_on_the_host_with_na_cells_monthly_and_totals(api, oracle):
+    """splash_grid_run with splash_opts.backend = SPLASH_BACKEND_HOST: a small synthetic terrain grid with NA cells,
+    monthly outputs of all nine series, state, aridity index, pass counts and the exact monthly totals per basin --
+    against the oracle's splash.grid restatement (R/splash.grid.R:277-308), each side from its own spin-up."""
+    from oracle.parity import assert_whole_pipeline
+    H, W, nt = 4, 24, 500
+    n = H * W
+    doy, year, month, mid, nm = oracle.calendar(2003, nt)
+    st = oracle.synth_statics(91, H, W, 0, n, 1)
+    sw, tc, pn = oracle.synth_forcing(91, H, W, 0, n, 0, doy, st["lat"], st["elev"])
+    rng = np.random.default_rng(3)
+    na = rng.random(n) < 0.2
+    elev = np.where(na, np.nan, st["elev"])
+    basin = (np.arange(n) % 3).astype(np.int32)
+    dates = np.datetime64("2003-01-01") + np.arange(nt)
+    for monthly in (False, True):
+        g = api.splash_grid(sw, tc, pn, elev, st["soil"], st["lat"], st["slop"], st["asp"], st["au"], st["resolution"],
+                            time_index=dates, sim_control=dict(monthly_out=monthly), want_aux=True, want_diag=True,
+                            basin=basin, n_basin=3, backend="host")
+        o, aux = oracle.grid(doy, year, month, mid, nm, sw, tc, pn, st["lat"], elev, st["slop"], st["asp"], st["soil"],
+                             st["au"], st["resolution"], monthly_out=monthly)
+        for k in o:
+            assert np.isnan(g[k][:, na]).all() and np.isnan(o[k][:, na]).all(), k
+        r = assert_whole_pipeline(oracle, g, o, aux, st, doy, year, f"host grid monthly={monthly}",
+                                  monthly_mid=mid if monthly else None)
+        ok = r.pop("ok")
+        assert np.array_equal(g["aux"]["passes2"][ok & ~na], aux["passes2"][ok & ~na])
+        close(g["aux"]["AI"][ok & ~na], aux["AI"][ok & ~na], "host AI", rtol=1e-9)
+        assert np.array_equal(g["aux"]["Tt"][~na], aux["Tt"][~na])
+        # exact totals == sums of the returned rasters (daily run: monthly sums of the daily values)
+        if monthly:
+            for b_ in range(3):
+                cells = (basin == b_) & ~na
+                for k in ("aet", "ro", "bflow"):
+                    ref = g[k][:, cells].astype(np.longdouble).sum(1).astype(float)
+                    assert np.allclose(g["diag"][k][b_], ref, rtol=1e-12, atol=1e-9), (b_, k)
+                assert (g["diag_cells"][b_] == cells.sum()).all()
+
+
+def test_host_backend_is_explicit_and_unknown_backends_are_refused(api, bourne):
+    import ctypes as C
+    from rsplash_amd import _lib
+    b, s = bourne, bourne["site"]
+    with pytest.raises(ValueError, match="backend"):
+        api.splash_point(b["sw_in"], b["Ta"], b["P"], s["latitude"], s["elev_m"], 0, 0, b["soil"], 0.0, 250.0,
+                         time_index=b["dates"], backend="cpu")
+    assert _lib.lib.splash_mod_backend(7) == -1          # SPLASH_EINVAL, setting unchanged
+    assert _lib.lib.splash_mod_backend(0) in (0, 1)
+    assert _lib.lib.splash_host_backend_fma() in (0, 1)
+    assert _lib.lib.splash_hip_abi_version() == 6
+
+
+def test_cpp_host_mirror_with_the_host_backend(oracle, bourne, tmp_path):
+    """include/splash.hpp: class SPLASH(lat, elv, SPLASH_BACKEND_HOST) from a plain C++ program (spin_up + run_all on
+    one year of the Bourne site), no GPU -- the argument lists of src/SPLASH.h:85-103"""
+    import subprocess
+    from test_abi import build_cpp_mirror
+    b, s = bourne, bourne["site"]
+    si, wmax_r = oracle.soil_info(b["soil"], [s["Aups_250m"], 3, 3], s["resolution"])
+    Tt, rain, snowf = oracle.snow_partition(b["Ta"], b["P"], b["month"], s["latitude"], s["elev_m"])
+    asp, n, y = s["asp_250m"] - 180, 365, int(b["year"][0])
+    head = [n, y, s["latitude"], s["elev_m"], s["slop_250m"], asp]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    np.concatenate([head, si[:12], b["sw_in"][:n], b["Ta"][:n], rain[:n], snowf[:n]]).astype("f8").tofile(fin)
+    subprocess.check_call([build_cpp_mirror(str(tmp_path)), fin, fout, "host"])
+    got = np.fromfile(fout).reshape(18, n)
+    o = oracle.spin_up(s["latitude"], s["elev_m"], n, y, b["sw_in"][:n], b["Ta"][:n], rain[:n], s["slop_250m"], asp,
+                       snowf[:n], si)
+    for i, k in enumerate(("sm", "snow", "qin", "tdrain", "ro", "snwage", "pet")):
+        close(got[i], o[k], "cpp host spin_up." + k)
+    q = oracle.run_all(s["latitude"], s["elev_m"], np.arange(1, n + 1), np.full(n, y), b["sw_in"][:n], b["Ta"][:n],
+                       rain[:n], o["sm"][-1], s["slop_250m"], asp, o["snow"][-1], snowf[:n], si, o["qin"][-1],
+                       o["tdrain"][-1], o["snwage"][-1])
+    for i, k in enumerate(("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "qin_prev", "tdrain", "snwage")):
+        close(got[7 + i], q[k], "cpp host run_all." + k)

@@ -84,6 +84,33 @@ def test_streamed_bricks_equal_the_one_shot_writer(tmp_path):
                         assert np.array_equal(vf._attributes[an], av), (k, name, an)
 
 
+def test_unwritten_stripes_read_back_as_na_and_a_failed_run_leaves_no_bricks(tmp_path):
+    """the streamed brick is created with all-zero data; a row block or layer that never arrives must
+    read back as the fill value (raster's FLT4S NA), not as 0.0 -- and a run that fails midway removes its partial
+    files instead of leaving bricks whose missing blocks look like data (R/splash.grid.R:370-400 writes blocks as they
+    arrive; raster's writeStart initialises with NA)."""
+    t = np.arange("2014-01-01", "2015-01-01", dtype="datetime64[D]")
+    H, W = 4, 3
+    lat, lon = 10.25 - 0.5 * np.arange(H), -70.25 + 0.5 * np.arange(W)
+    a = tmp_path / "partial"
+    a.mkdir()
+    with io.BrickWriter(str(a), ["wn"], lon, lat, t, True) as w:
+        w.write("wn", 1, np.full((12, 2, W), 5.0))            # rows 1-2 of 0..3, all layers
+        w.write("wn", 3, np.full((6, 1, W), 7.0), t0=6)       # row 3, layers 6..11 only
+    with netcdf_file(w.paths["wn"], "r", mmap=False) as f:
+        v = f.variables[io.BRICKS["wn"][1]][:]
+    na = np.float32(io.NA_FLT4S)
+    assert (v[:, 1:3] == 5.0).all() and (v[6:, 3] == 7.0).all()
+    assert (v[:, 0] == na).all() and (v[:6, 3] == na).all()
+    b = tmp_path / "failed"
+    b.mkdir()
+    with pytest.raises(RuntimeError, match="midway"):
+        with io.BrickWriter(str(b), ["wn", "ro"], lon, lat, t, True) as w2:
+            w2.write("wn", 0, np.zeros((12, 2, W)))
+            raise RuntimeError("the block loop failed midway")
+    assert os.listdir(str(b)) == [] and w2.paths == {}
+
+
 def test_classic_header_of_a_brick_beyond_4_gib(tmp_path):
     """the data variable is the last one, so it may exceed 4 GiB: its vsize field is then 2^32 - 1
     (NetCDF classic format specification) and its offset is a 64-bit one; scipy opens the file"""

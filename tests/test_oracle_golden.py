@@ -66,8 +66,8 @@ def test_expf_algorithm_matches_glibc():
     # the table literal in the device header must be this table
     src = open(os.path.join(os.path.dirname(GOLD), "..", "rsplash_amd", "csrc",
                             "splash_device.hpp")).read()
-    body = src[src.index("kExp2fTab[32] = {"):]
-    body = body[:body.index("};")]
+    body = src[src.index("#define SPL_EXP2F_TABLE"):]     # (one literal list: the device table and its host copy)
+    body = body[:body.index("#if")].replace("\\", " ")
     lits = [int(x.strip(",").rstrip("ULL"), 16) for x in body.replace("{", " ").split()
             if x.strip(",").startswith("0x")]
     assert lits == T

@@ -116,7 +116,10 @@ def main():
                 "salu_insts_per_wave_day": sq["SQ_INSTS_SALU"] / waves / nt}
     tj = {f"{rows_blk}x{W}x{nt}": {**valu, "hbm_bytes_per_launch": traffic, "fetch_bytes_corrected": ra_fetch,
                                     "write_bytes": ra_write, "fetch_size_calibration": factor,
-                                    "algorithmic_bytes": alg_read + alg_write, "source": f"profiles/{tag}_summary.md"}}
+                                    "algorithmic_bytes": alg_read + alg_write, "source": f"profiles/{tag}_summary.md",
+                                    # the kernel sources these counters were measured on (bench.py prints the hash of
+                                    # the sources it runs; a mismatch shows in every later bench line)
+                                    "kernel_sources_sha16": (bench or {}).get("roofline", {}).get("kernel_sources_sha16")}}
     json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     if bench:
         json.dump(bench, open(os.path.join(out, f"{tag}_bench.json"), "w"), indent=1)

@@ -18,10 +18,18 @@ def best(f, n=5):
     for _ in range(n):
         t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
     return min(ts), ts[0]
-b, first = best(lambda: api.splash_point(sw, Ta, P, site["latitude"], site["elev_m"], site["slop_250m"], site["asp_250m"],
-                                         soil, site["Aups_250m"], site["resolution"], time_index=dates))
-print(f"splash_point, Bourne ({len(dates)} days): first call {first*1e3:.1f} ms, best of 5 {b*1e3:.1f} ms")
+from rsplash_amd._lib import lib
+print(f"host backend build: {'AVX2+FMA' if lib.splash_host_backend_fma() else 'generic x86-64'}")
+for backend in ("hip", "host"):
+    b, first = best(lambda: api.splash_point(sw, Ta, P, site["latitude"], site["elev_m"], site["slop_250m"], site["asp_250m"],
+                                             soil, site["Aups_250m"], site["resolution"], time_index=dates, backend=backend))
+    print(f"splash_point, Bourne ({len(dates)} days), backend {backend}: first call {first*1e3:.1f} ms, best of 5 {b*1e3:.1f} ms")
 o = Oracle()
+op = lambda: o.point(*[np.asarray(x) for x in api.time_fields(dates)], api.month_ids(*api.time_fields(dates)[1:]),
+                     int(api.month_ids(*api.time_fields(dates)[1:])[-1]) + 1, sw, Ta, P, site["latitude"], site["elev_m"],
+                     site["slop_250m"], site["asp_250m"], soil, [site["Aups_250m"], 3, 3], site["resolution"])
+b, first = best(op)
+print(f"(the parity oracle's plain-C restatement of the same call, one core: best of 5 {b*1e3:.1f} ms)")
 for H, W, nt in ((1, 1, 365), (1, 64, 365), (8, 128, 365), (64, 128, 365), (8, 128, 3653)):
     doy, year, month, mid, nm = o.calendar(2001, nt)
     st = o.synth_statics(20221130, H, W, 0, H * W, 1)
@@ -31,4 +39,8 @@ for H, W, nt in ((1, 1, 365), (1, 64, 365), (8, 128, 365), (64, 128, 365), (8, 1
                                   time_index=d, sim_control=dict(monthly_out=True), want_aux=True)
     b, first = best(run, 4)
     r = run()
-    print(f"splash_grid {H}x{W} cells x {nt} days, monthly: best of 4 {b*1e3:.1f} ms; max passes of spin-up #2: {int(r['aux']['passes2'].max())}")
+    runh = lambda: api.splash_grid(*f, st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"], st["resolution"],
+                                   time_index=d, sim_control=dict(monthly_out=True), want_aux=True, backend="host")
+    bh, _ = best(runh, 2 if H * W * nt > 2e6 else 4)
+    print(f"splash_grid {H}x{W} cells x {nt} days, monthly: hip best of 4 {b*1e3:.1f} ms, host {bh*1e3:.1f} ms; max passes of "
+          f"spin-up #2: {int(r['aux']['passes2'].max())}")
