@@ -84,7 +84,6 @@ void knobs_read_locked()
     k.no_nd_skip = getenv("SPLASH_HIP_NO_ND_SKIP") != nullptr;
     k.no_block_phase1 = getenv("SPLASH_HIP_NO_BLOCK_PHASE1") != nullptr;
     k.no_solo_tail = getenv("SPLASH_HIP_NO_SOLO_TAIL") != nullptr;
-    k.no_uniform_tail = getenv("SPLASH_HIP_NO_UNIFORM_TAIL") != nullptr;
     if (const char* e = getenv("SPLASH_HIP_TAIL_STAGES")) {
         int b0 = 0, b1 = 0;
         if (sscanf(e, "%d,%d", &b0, &b1) == 2) {
@@ -722,19 +721,7 @@ int splash::host::spin_phases(const splash_calendar* cal, size_t ncell, const do
                     a.no_queue = last ? 1 : 0; // (the budgets cover the 1000-pass cap: nothing is left after the last stage)
                     a.wl_out = last ? wl[ph & 1] : lists[st + 1];
                     a.n_out = last ? cnt + ph : counts[st + 1];
-                    // Round 6: every stage is a PAIR of launches over the same list, of which exactly one works --
-                    // the list's length is known on the device only.  More than 1 024 jobs: the general spread
-                    // kernel (several jobs to a wavefront).  At most 1 024 -- the last stage of a big grid, every
-                    // stage of a small one --: ONE job per wavefront, the other lanes repeating it, so every branch
-                    // of the day step is wave-uniform and the SOLO variant says so (k_spin_phase, wave_pred).
-                    a.solo_split = kn.no_uniform_tail ? 0 : 1;
                     HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
-                    a.solo_split = 0;
-                    if (!kn.no_uniform_tail) {
-                        a.solo = 1;
-                        HIP_TRY(launch_spin_phase(a, s), nullptr, 0);
-                        a.solo = 0;
-                    }
                     prev = st + 1;
                 }
                 a.spread = 0;

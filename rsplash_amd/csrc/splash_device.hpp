@@ -94,22 +94,6 @@ constexpr double kFluidity = 35187037.0;
 #define SPL_MAX(a, b) (((a) < (b)) ? (b) : (a))
 #define SPL_MIN(a, b) (((b) < (a)) ? (b) : (a))
 
-// Predicate of one of the day step's LARGE branches.  UNI = false: the lane's own predicate (a wavefront executes the
-// union of its lanes' branches under execution masks).  UNI = true: the caller guarantees that all 64 lanes of the
-// wavefront hold the SAME cell (the last spread stage of the spin-up's tail, one job per wavefront, k_spin_phase
-// SOLO), so the predicate is wave-uniform; saying so -- a ballot compared with zero is a scalar value -- lets the
-// compiler emit s_cmp + s_cbranch_scc instead of v_cmp -> s_and_saveexec -> s_cbranch_execz ... s_or exec: no
-// execution-mask bookkeeping around ~10 blocks of a day step on which a lone wavefront pays for every instruction.
-// The arithmetic inside the blocks is untouched (same statements in the same basic blocks: same bits).
-template <bool UNI>
-SPL_DEV bool wave_pred(bool p)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (UNI) return __builtin_amdgcn_ballot_w64(p) != 0ull;
-#endif
-    return p;
-}
-
 struct State {
     double wn, snow, qin, td, nd;
 };
@@ -874,7 +858,6 @@ SPL_DEV void day_terms(const CellConst& c, const DayConst& d, const DayPre& pre,
     T.warm = (tc >= 3.0);
 }
 
-template <bool UNI = false>
 SPL_DEV void evap_update(const CellConst& c, const DayTerms& T, const ViscTerms& V,
                                             double sw, double snow, double nd, Etr& o)
 {
@@ -882,7 +865,7 @@ SPL_DEV void evap_update(const CellConst& c, const DayTerms& T, const ViscTerms&
     const double sw_s = sw > 1.0 ? 1.0 : sw; // :92
     const double alb_v = kAlbSw - 0.17 * sw_s; // :215
     double alb = alb_v;                        // snow-free: sfc = 0 => alb = alb_v exactly
-    if (wave_pred<UNI>(snow > 0.0 || isnan(snow))) { // :208-219
+    if (snow > 0.0 || isnan(snow)) { // :208-219
         const double max_alb_snw = (1.0 - 0.443700) + (0.443700 * fexp(-0.895189 * nd));
         const double sfc = snow * frcp(140.0 + snow);
         alb = alb_v * (1.0 - sfc) + sfc * max_alb_snw;
@@ -1010,7 +993,6 @@ SPL_DEV double moist_surf(const CellConst& c, double wn)
 // src/SPLASH.cpp:1963-2023 with tdur = 6 h (call at :1268).  The surface moisture (moist_surf,
 // :1265) only enters when the rain rate exceeds the conductivity, so it is evaluated inside that
 // branch (two logs and two exps saved on every other cell-day).
-template <bool UNI = false>
 SPL_DEV double inf_GA(const CellConst& c, double wn, double Ksat, double P)
 {
     const double tdur = 6.0;
@@ -1019,12 +1001,12 @@ SPL_DEV double inf_GA(const CellConst& c, double wn, double Ksat, double P)
 #if defined(SPL_ABLATE) && SPL_ABLATE == 11
     if (false) {
 #else
-    if (wave_pred<UNI>(!(r <= Ksat))) {
+    if (!(r <= Ksat)) {
 #endif
         SPL_SITE();
         const double theta_i = moist_surf(c, wn);
         const double delta_theta = (c.theta_s - theta_i);
-        if (wave_pred<UNI>(delta_theta <= 0.0)) {
+        if (delta_theta <= 0.0) {
             I = Ksat * tdur;
         } else {
             const double hd = c.h_f * delta_theta;
@@ -1055,7 +1037,6 @@ SPL_DEV double inf_GA(const CellConst& c, double wn, double Ksat, double P)
 //     relative accuracy -- not its size -- sets the drainage time.  (Past |psi_m| ~ 1e11*depth
 //     the reference's own difference is rounding noise of fl(psi_m + depth*1000): DESIGN.md
 //     "Conditioning"; the parity tests set such cell-days aside.)
-template <bool UNI = false>
 SPL_DEV double transmittance_uns(const CellConst& c, double Ksat_visc,
                                                     double sm, double& Acs_out)
 {
@@ -1081,7 +1062,7 @@ SPL_DEV double transmittance_uns(const CellConst& c, double Ksat_visc,
     //  and a reciprocal pinned before a select costs k_run_all's day loop a spilled register: measured, round 6.)
     const double A = (P < 1.0e300) ? (Theta * Theta * Theta) * frcp(P) : 0.0;
     double diff; // A - B
-    if (wave_pred<UNI>(!clamped)) {
+    if (!clamped) {
         diff = A - 1.0; // bub/(psi_m + wtd*1000) is 1 +- 1 ulp: B = 1 to 1e-16
     } else {
         // u = wtd*1000/psi_m, with the increment taken as the reference forms it: fl(psi_m +
@@ -1094,10 +1075,10 @@ SPL_DEV double transmittance_uns(const CellConst& c, double Ksat_visc,
         const double u = (xs - psi_m) * frcp(psi_m); // in (-1, 0] for a dry column (NaN if psi_m = -inf:
                                                       // T_uns then falls to the guard below, = 0)
         double l1p, em1;
-        if (wave_pred<UNI>(fabs(u) < 1.0e-5)) l1p = u * (1.0 - u * (0.5 - u * (1.0 / 3.0)));
+        if (fabs(u) < 1.0e-5) l1p = u * (1.0 - u * (0.5 - u * (1.0 / 3.0)));
         else l1p = flog<kLogPositive>(1.0 + u); // 1 + u in (0, 2] or NaN
         const double z = -c.e3l1 * l1p;
-        if (wave_pred<UNI>(fabs(z) < 1.0e-5)) em1 = z * (1.0 + z * (0.5 + z * (1.0 / 6.0)));
+        if (fabs(z) < 1.0e-5) em1 = z * (1.0 + z * (0.5 + z * (1.0 / 6.0)));
         else em1 = fexp(z) - 1.0;
         diff = -A * em1;
     }
@@ -1112,7 +1093,6 @@ SPL_DEV double transmittance_uns(const CellConst& c, double Ksat_visc,
 // day_update(): the water balance given the day's state-independent terms (computed by day_terms()
 // or read back from the spin-up's cache), what follows from the day's viscosity (visc_terms()) and
 // the day's rain and snowfall.
-template <bool UNI = false>
 SPL_DEV void day_update(const CellConst& c, const DayTerms& K, const ViscTerms& V,
                                            double pn, double snowfall, State& st, DayOut& o)
 {
@@ -1131,14 +1111,14 @@ SPL_DEV void day_update(const CellConst& c, const DayTerms& K, const ViscTerms& 
     snow += snowfall;
 
     Etr ev;
-    evap_update<UNI>(c, K, V, sw, snow, nd, ev);  // :1235
+    evap_update(c, K, V, sw, snow, nd, ev);  // :1235
     snow -= ev.snowmelt;                          // :1240
     const double snowmelt = ev.snowmelt - ev.sublimation; // :1243
 
     // :1260-1272
     const double Ksat_visc = V.kv;
     const double inflow = pn + ev.cond + snowmelt;
-    const double infi = inf_GA<UNI>(c, wn, Ksat_visc, inflow);
+    const double infi = inf_GA(c, wn, Ksat_visc, inflow);
     const double ro_h_arg = inflow - infi;
     const double ro_h = SPL_MAX(ro_h_arg, 0.0);
     double R = infi - ev.aet;
@@ -1155,7 +1135,7 @@ SPL_DEV void day_update(const CellConst& c, const DayTerms& K, const ViscTerms& 
     double q_in_o = 0.0;
     double Kb = 0.0;
     bool have_kb = false;
-    if (wave_pred<UNI>(!((td <= 0.0) || (qin <= 0.0)))) {
+    if (!((td <= 0.0) || (qin <= 0.0))) {
         Kb = fexp(lkb_arg);
         have_kb = true;
         q_in_o = qin * Kb;
@@ -1174,13 +1154,13 @@ SPL_DEV void day_update(const CellConst& c, const DayTerms& K, const ViscTerms& 
     // :1406-1457 transmittance after recharge
     double Acs_out;
     SPL_SITE();
-    const double T_uns1 = transmittance_uns<UNI>(c, Ksat_visc, sm, Acs_out);
+    const double T_uns1 = transmittance_uns(c, Ksat_visc, sm, Acs_out);
     const double sm1 = sm;
     double T_uns = T_uns1, T_sat;
 #if defined(SPL_ABLATE) && SPL_ABLATE == 12
     if (false) {
 #else
-    if (wave_pred<UNI>(c.deep)) { // depth >= 2.0: vertical drainage corrections :1433-1450
+    if (c.deep) { // depth >= 2.0: vertical drainage corrections :1433-1450
 #endif
         SPL_SITE();
         // :984-990 clamp of the start-of-day volumetric content, :1267 theta_m
@@ -1206,7 +1186,7 @@ SPL_DEV void day_update(const CellConst& c, const DayTerms& K, const ViscTerms& 
     double t_drain = 0.0;
     double q_in_f = 0.0;
     td -= 1.0;
-    if (wave_pred<UNI>((R > 0.0) && (sm > c.Wmax))) {
+    if ((R > 0.0) && (sm > c.Wmax)) {
         SPL_SITE();
         // log(Kb) with Kb = exp(lkb_arg) (:1326, :1470): the round trip returns lkb_arg up to the
         // rounding of Kb, an ABSOLUTE 1e-16, i.e. relative 1e-16/|lkb_arg|.  Above 1e-7 that is
@@ -1216,7 +1196,7 @@ SPL_DEV void day_update(const CellConst& c, const DayTerms& K, const ViscTerms& 
         // and an underflowing Kb, go the reference's way.
         const double ax = fabs(lkb_arg);
         double lkb = lkb_arg;
-        if (wave_pred<UNI>(!(ax == 0.0 || (ax >= 1.0e-7 && ax <= 700.0)))) {
+        if (!(ax == 0.0 || (ax >= 1.0e-7 && ax <= 700.0))) {
             if (!have_kb) Kb = fexp(lkb_arg);
             lkb = flog(Kb);
         }
@@ -1249,10 +1229,10 @@ SPL_DEV void day_update(const CellConst& c, const DayTerms& K, const ViscTerms& 
 #if defined(SPL_ABLATE) && SPL_ABLATE == 13
     if (false) {
 #else
-    if (wave_pred<UNI>(sm != sm1)) {
+    if (sm != sm1) {
 #endif
         SPL_SITE();
-        T_uns2 = transmittance_uns<UNI>(c, Ksat_visc, sm, Acs2);
+        T_uns2 = transmittance_uns(c, Ksat_visc, sm, Acs2);
     }
     const double T2 = (Ksat_visc * 24.0 * (Acs2 * c.inv_Ai) + T_uns2) * hyd_grad_out;
 

@@ -43,7 +43,6 @@ struct Knobs {
     bool no_nd_skip = false;           // SPLASH_HIP_NO_ND_SKIP
     bool no_block_phase1 = false;      // SPLASH_HIP_NO_BLOCK_PHASE1
     bool no_solo_tail = false;         // SPLASH_HIP_NO_SOLO_TAIL
-    bool no_uniform_tail = false;      // SPLASH_HIP_NO_UNIFORM_TAIL (A/B, tests: no wave-uniform variant for one-job wavefronts)
     int tail_stage[2] = {-1, -1};      // SPLASH_HIP_TAIL_STAGES="a,b"
     int tail_lds_pad = 57344;          // SPLASH_HIP_TAIL_LDS_PAD
     int prefault_mode = 0;             // SPLASH_HIP_PREFAULT (populate | touch | off)

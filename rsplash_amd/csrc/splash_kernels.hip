@@ -333,16 +333,9 @@ __device__ __forceinline__ DayRecord rec_decode(const CellConst& c, const RawRec
 // tail is ~1000 passes x 365 sequential day steps of lone wavefronts, every instruction of which is
 // latency; compiled together with the general loop its day step carried ~100 v_readlane (scalar
 // registers spilled to vector lanes) and ~300 s_mov per day that the smaller kernel does not need.
-// SOLO (round 6; READBACK + RICH + spread only): the variant for lists of at most 1 024 jobs, i.e. ONE job per
-// wavefront with the other 63 lanes repeating it -- every predicate of day_update() is then wave-uniform and is
-// handed to the compiler as such (wave_pred<true>, splash_device.hpp): scalar branches without execution-mask
-// bookkeeping, and no lane % k arithmetic.  The launch returns at once when the list is longer (the general
-// spread launch issued beside it over the same list then does the work: a.solo_split makes THAT one return when
-// the list is short), so the host needs no read-back of the list length to choose.
-template <bool CACHED, bool READBACK = false, bool RICH = false, bool SOLO = false>
+template <bool CACHED, bool READBACK = false, bool RICH = false>
 __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPhaseArgs a)
 {
-    static_assert(!SOLO || (READBACK && RICH), "SOLO is a variant of the tail's read-back kernel");
 #if defined(SPL_TAIL_STATS) && defined(SPL_DIFF_STATS)
     const unsigned long long t_wave_start = wall_clock64();
 #endif
@@ -351,8 +344,6 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     // positions the host sized the launch for, a.ncell = min(list bound, cache capacity): positions beyond
     // the cache have no records here and belong to the general-kernel launch that follows (spin_phases).
     if (READBACK && a.spread && !a.wl_slots && nin > a.ncell) nin = a.ncell;
-    if (SOLO && nin > 1024) return;                                          // (uniform over the grid)
-    if (!SOLO && READBACK && a.spread && a.solo_split && nin <= 1024) return; // the SOLO launch beside this one has them
     // Launch position -> job.  Packed (default): 64 jobs to a wavefront.  Spread (the tail's stages, READBACK
     // only): the jobs are dealt over 1024 wavefronts -- one per SIMD of the chip --, k = ceil(n / 1024) to each.
     // A wavefront executes the union of the branches of its lanes: a job that has the wavefront to itself skips
@@ -361,16 +352,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
     // against 1 035 ms for the 971 passes of the longest chains, tools/solo_tail.py, profiles/r04_spinup.md).
     size_t slot;
     bool valid, writer = true;
-    if constexpr (SOLO) {
-        // the wavefront's index as a SCALAR: slot, cell, cache slot and with them every address this wavefront
-        // loads from are wave-uniform, and so -- to the compiler's uniformity analysis -- is everything computed
-        // from what those loads return: the cell's constants, the records, the state, every predicate
-        const size_t wave = (size_t)blockIdx.x * (kBlock / 64) + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        if ((size_t)blockIdx.x * (kBlock / 64) >= nin) return; // whole workgroup past the list
-        slot = wave < nin ? wave : (size_t)blockIdx.x * (kBlock / 64); // (a wavefront past the list leaves after the tables' barrier)
-        valid = wave < nin;
-        writer = (threadIdx.x & 63) == 0 && valid;
-    } else if (READBACK && a.spread) {
+    if (READBACK && a.spread) {
         size_t k = (nin + 1023) / 1024;
         k = k < 1 ? 1 : (k > 64 ? 64 : k);
         const size_t wave = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -472,7 +454,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             if (CACHED && cached) rec_store<RICH>(a.cache, a.cache_cap, 0, cs, r);
         }
         if (p_day) *p_day = r.rain + r.snf;
-        day_update<SOLO>(c, r.T, r.V, r.rain, r.snf, st_, o_);
+        day_update(c, r.T, r.V, r.rain, r.snf, st_, o_);
     };
     State cur;
     double e_wn;
@@ -524,7 +506,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_spin_phase(SpinPh
             for (int i = 1; i < a.n; i++) {
                 const DayRecord r = rec_decode<RICH>(c, w, RICH ? 0.0 : days[i].cd);
                 if (i + 1 < a.n) w = rec_load<RICH>(a.cache, a.cache_cap, i + 1, cs_ld); // tomorrow's, untouched until tomorrow
-                day_update<SOLO>(c, r.T, r.V, r.rain, r.snf, cur, o);
+                day_update(c, r.T, r.V, r.rain, r.snf, cur, o);
             }
         } else if constexpr (!READBACK) {
             // order of the day's vector-memory traffic as in k_run_all: gathers at the top; once
@@ -1305,29 +1287,23 @@ hipError_t launch_spin_phase(const SpinPhaseArgs& a, hipStream_t s)
         // more than 256 busy workgroups -- run one per CU instead of two, and the tails of two calls in flight on
         // one device take their CUs in turn instead of sharing them at 1.6x the time each.)
         unsigned pad = 0;
-        const void* const fn = a.solo ? (const void*)k_spin_phase<true, true, true, true>
-                                      : (const void*)k_spin_phase<true, true, true>;
         if (a.spread) {
-            // (the attribute belongs to the function ON A DEVICE: asked for once per device and variant of the process)
-            static std::atomic<int> granted[2][64]; // 0: not asked yet, > 0: bytes, -1: refused or switched off
+            // (the attribute belongs to the function ON A DEVICE: asked for once per device of the process)
+            static std::atomic<int> granted[64]; // 0: not asked yet, > 0: bytes, -1: refused or switched off
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
-            int g = dev < 0 ? -1 : granted[a.solo ? 1 : 0][dev].load(std::memory_order_acquire);
+            int g = dev < 0 ? -1 : granted[dev].load(std::memory_order_acquire);
             if (g == 0) {
                 const int want = a.lds_pad;                        // static 25.9 KB + 56 KB > 80 KB (A/B: 0 switches it off)
-                g = want > 0 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess
+                g = want > 0 && hipFuncSetAttribute((const void*)k_spin_phase<true, true, true>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess
                         ? want : -1;
                 (void)hipGetLastError();
-                granted[a.solo ? 1 : 0][dev].store(g, std::memory_order_release);
+                granted[dev].store(g, std::memory_order_release);
             }
             pad = g > 0 ? (unsigned)g : 0u;
         }
-        if (a.solo) {
-            if (!a.spread) return hipErrorInvalidValue;
-            // at most 1 024 jobs, one per wavefront: 256 workgroups
-            hipLaunchKernelGGL((k_spin_phase<true, true, true, true>), dim3(256), dim3(kBlock), pad, s, a);
-        } else
-            hipLaunchKernelGGL((k_spin_phase<true, true, true>), dim3(g_rb), dim3(kBlock), pad, s, a);
+        hipLaunchKernelGGL((k_spin_phase<true, true, true>), dim3(g_rb), dim3(kBlock), pad, s, a);
     } else if (a.readback)
         hipLaunchKernelGGL((k_spin_phase<true, true, false>), dim3(g_rb), dim3(kBlock), 0, s, a);
     else if (a.cache && a.rich)

@@ -87,10 +87,6 @@ struct SpinPhaseArgs {
     int dbg_active_lanes;   // measurement builds only (tools/solo_tail.py): lanes of a spread wavefront that stay active
     int no_nd_skip;         // test aid (SPLASH_HIP_NO_ND_SKIP): the cycle detector compares the snow age too, always
     int lds_pad;            // spread launches: bytes of dynamic LDS asked for and never touched (one workgroup per CU), 0: none
-    int solo;               // 1 (spread + readback + rich): the one-job-per-wavefront variant with wave-uniform branches; it returns at
-                            //    once unless the list holds <= 1024 jobs
-    int solo_split;         // 1 (spread launches of the general read-back kernel): return at once when the list holds <= 1024 jobs --
-                            //    a solo launch over the same list, issued beside this one, takes them
     int rich;               // 1: the cache holds rich records, 20 words each, record by record (cache_cap = spin_cache_rich_cap of the
                             //    workspace's capacity), see splash_kernels.hip "Two layouts"
 };
