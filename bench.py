@@ -254,16 +254,23 @@ def base_line(ctx, value, steps, warmup, dt, workload, extra_cfg):
             "config": cfg}
 
 
-def kernel_sources_sha16():
-    """sha256 (first 16 hex digits) of the kernels' sources: the PMC figures of profiles/traffic.json carry the hash of
-    the sources they were measured on, so a stale constant shows in the line"""
+def kernel_sources_sha16(root=None):
+    """sha256 (first 16 hex digits) of the kernels' sources WITHOUT comments and white space: the PMC figures of
+    profiles/traffic.json carry the hash of the sources they were measured on, so a constant that went stale with a
+    kernel change shows in the line (and an edited comment does not raise a false alarm)"""
     import glob
     import hashlib
+    import re
+    root = root or ROOT
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "rsplash_amd", "csrc", "*.hip")) +
-                    glob.glob(os.path.join(ROOT, "rsplash_amd", "csrc", "*.hpp"))):
+    for f in sorted(glob.glob(os.path.join(root, "rsplash_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(root, "rsplash_amd", "csrc", "*.hpp"))):
+        txt = open(f, encoding="utf-8", errors="replace").read()
+        txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)      # block comments
+        txt = re.sub(r"//[^\n]*", " ", txt)                    # line comments (no string of these files holds "//")
+        txt = re.sub(r"\s+", "", txt)
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(txt.encode())
     return h.hexdigest()[:16]
 
 

@@ -40,7 +40,7 @@ using namespace splash::host;
 //                       it).  It MODIFIES the range, so the range must be the calling block's own
 //                       columns only: the first version touched the whole worker range from the first
 //                       lane to arrive and could zero values the other lane's helper thread had just
-//                       delivered (tests/test_gpu_parity.py::test_prefault_touches_only_its_own_columns);
+//                       delivered (tests/test_gpu_host_path.py::test_prefault_touches_only_its_own_columns);
 //   off                 nothing.
 // SPLASH_HIP_PREFAULT selects the mode, SPLASH_HIP_PREFAULT_MIN_BYTES the block size (bytes of one
 // block's share of the arrays) from which it pays: 64 MiB.

@@ -175,7 +175,7 @@ extern "C" int splash_dbg_set_diff(float* p)
 #endif
 
 #ifdef SPL_CHECK_SLOTS
-// checking build (librsplash_hip_check.so; tests/test_gpu_parity.py::test_read_back_never_addresses_a_slot_beyond_the_cache):
+// checking build (librsplash_hip_check.so; tests/test_gpu_host_path.py::test_read_back_never_addresses_a_slot_beyond_the_cache):
 // every access to the spin-up's record cache reports its slot.  [0] wavefront-level accesses, [1] lane accesses
 // whose slot lies beyond the capacity the launch was given -- must stay 0.
 __device__ unsigned long long g_slot_check[2];

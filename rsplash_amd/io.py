@@ -198,10 +198,12 @@ class BrickWriter:
             o, shp, dt = lay[varname]
             self._maps[key] = np.memmap(path, dtype=dt, mode="r+", offset=o, shape=shp)
             self.paths[key] = path
-            # which (layer, row) stripes have been stored: whatever is still unwritten at close() becomes the
+            # which (layer range, row) stripes have been stored: whatever is still unwritten at close() becomes the
             # fill value -- the file is created with all-zero data, and a layer or row that never arrives (a time
-            # axis longer than the months computed, a run that ends early) must read back as NA, not as 0.0
-            self._seen[key] = np.zeros((z.size, lat.size), bool)
+            # axis longer than the months computed, a run that ends early) must read back as NA, not as 0.0.
+            # Kept per distinct layer range (a run writes row blocks of ALL layers, or of a few time chunks): one
+            # row mask each, not a [layers x rows] table (30 years of daily layers x 4096 rows x 9 bricks)
+            self._seen[key] = {}
 
     def write(self, key, row0, block, t0=0):
         """block [nl_b, nrows, ncol] -> layers t0..t0+nl_b, rows row0..row0+nrows (t0 > 0: a later time
@@ -213,15 +215,21 @@ class BrickWriter:
         if (b.ndim != 3 or t0 < 0 or t0 + b.shape[0] > self.nl or b.shape[2] != self.shape[1] or row0 + b.shape[1] > self.shape[0]):
             raise ValueError(f"{key}: block {b.shape} at layer {t0}, row {row0} does not fit a brick of {(self.nl,) + self.shape}")
         m[t0:t0 + b.shape[0], row0:row0 + b.shape[1], :] = np.where(np.isnan(b), NA_FLT4S, b)
-        self._seen[key][t0:t0 + b.shape[0], row0:row0 + b.shape[1]] = True
+        rows = self._seen[key].setdefault((int(t0), int(t0 + b.shape[0])), np.zeros(self.shape[0], bool))
+        rows[row0:row0 + b.shape[1]] = True
 
     def close(self):
         """flush and unmap; every (layer, row) stripe that was never written is set to the fill value first"""
         for key, m in self._maps.items():
             seen = self._seen[key]
-            if not seen.all():
-                for t in np.nonzero(~seen.all(1))[0]:
-                    m[t, ~seen[t], :] = NA_FLT4S
+            cuts = sorted({0, self.nl} | {t for rng in seen for t in rng})
+            for a, b in zip(cuts[:-1], cuts[1:]):     # elementary layer intervals: rows some range covering it has stored
+                rows = np.zeros(self.shape[0], bool)
+                for (t0, t1), r in seen.items():
+                    if t0 <= a and b <= t1:
+                        rows |= r
+                if not rows.all():
+                    m[a:b, ~rows, :] = NA_FLT4S
             m.flush()
         self._maps, self._seen = {}, {}
 

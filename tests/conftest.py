@@ -24,6 +24,19 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def api():
+    """the Python mirror over the built library ON A GPU (the GPU test modules; tests/test_host_backend.py has its own,
+    device-free one)"""
+    import torch
+    assert torch.cuda.is_available(), "GPU suite needs a GPU"
+    import rsplash_amd
+    rsplash_amd.build_library()
+    from rsplash_amd import api as a
+    assert a.device_count() >= 1
+    return a
+
+
+@pytest.fixture(scope="session")
 def bourne():
     """the reference's bundled example site (data/Bourne.RData -> tests/golden, README.md:28-61)"""
     rows = list(csv.DictReader(open(os.path.join(GOLD, "bourne_forcing.csv"))))
