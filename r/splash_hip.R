@@ -36,7 +36,8 @@ splash.point <- function(sw_in, tc, pn, lat, elev, slop = 0, asp = 0, soil_data,
 # Replaces clFun + the send/receive loop of R/splash.grid.R:277-400: one .Call per row block.
 # `bs` is raster::blockSize(sw_in, ...) as in the reference; the static rasters (lat, terraines,
 # resolution, Au) are prepared exactly as R/splash.grid.R:76-110 does.  `devices`: HIP ordinals the
-# block is split over inside the call (this is what stands where the SOCK cluster stood).
+# block is split over inside the call (this is what stands where the SOCK cluster stood); `devices = -1L`:
+# no device -- the host backend (ABI 6), for blocks of a few cells.
 # .splash_grid_submit starts the block's call and returns a handle at once; .splash_grid_collect
 # waits for it and returns
 #   list(wn, ro, pet, aet, snow, cond, bflow, netr, sm_lim) of [ncell_blk x nl] matrices, which

@@ -6,9 +6,11 @@
  * (src/SPLASH.cpp:12-21, src/RcppExports.cpp:9-25): instead of one R->C++ crossing per cell and
  * method (R/splash.point.R:92,148,152,158), one crossing per row block.
  *
- * NOT compiled in this repository's image (no R headers there); it is deliberately thin: unpack
- * SEXPs, allocate results, call the C ABI, raise an R error on a non-zero code.  Everything with
- * logic in it lives behind the C ABI, which the test-suite exercises.
+ * There is no R in this repository's image: the file is syntax-checked against declarations-only headers of R's
+ * public C API and, since round 6, COMPILED AND EXECUTED against a mock of that API (tests/csrc/r_mock/r_mock.c,
+ * tests/test_abi.py::test_r_shim_runs_against_a_mock_r_api) -- never against R itself.  It is deliberately thin:
+ * unpack SEXPs, allocate results, call the C ABI, raise an R error on a non-zero code.  Everything with logic in
+ * it lives behind the C ABI, which the test-suite exercises.
  *
  * Build inside the package:   PKG_LIBS = -L<dir> -lrsplash_hip   (src/Makevars)
  */
@@ -63,9 +65,15 @@ static SEXP grid_call_setup(SEXP sw_in, SEXP tc, SEXP pn, SEXP stat, SEXP soil, 
 
     memset(opt, 0, sizeof *opt);
     opt->monthly_out = asLogical(monthly);
-    opt->device = INTEGER(devices)[0];
-    opt->n_devices = LENGTH(devices);   /* > 1: the block is split over these GPUs inside the call */
-    opt->devices = INTEGER(devices);
+    if (INTEGER(devices)[0] < 0) {
+        /* devices = -1L: no device -- SPLASH_BACKEND_HOST, the library's own day step compiled for the host, for a
+         * block of a few cells (ABI 6; the default backend without a HIP device is an error, never a fallback) */
+        opt->backend = SPLASH_BACKEND_HOST;
+    } else {
+        opt->device = INTEGER(devices)[0];
+        opt->n_devices = LENGTH(devices);   /* > 1: the block is split over these GPUs inside the call */
+        opt->devices = INTEGER(devices);
+    }
 
     /* number of output steps: months present in the calendar, or days */
     int nmonth = 1;

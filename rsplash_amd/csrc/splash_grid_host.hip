@@ -1332,7 +1332,11 @@ extern "C" int splash_grid_submit(const splash_grid_in* in, const splash_opts* o
                                   splash_grid_job** job, char* err, size_t errlen)
 {
     if (!in || !out || !job) return fail(SPLASH_EINVAL, err, errlen, "grid_submit: NULL in/out/job");
-    if (int rc = enter_device(err, errlen)) return rc;
+    if (opt && opt->backend == SPLASH_BACKEND_HOST) {
+        knobs_refresh(); // (the host backend touches no device: nothing to refuse at submit time)
+    } else if (int rc = enter_device(err, errlen)) {
+        return rc;
+    }
     auto* j = new splash_grid_job;
     j->in = *in;
     j->out = *out;

@@ -220,3 +220,67 @@ def test_r_shim_syntax_and_registration():
     r = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", "-I" + os.path.join(ROOT, "tests", "csrc", "r_decls"),
                         "-I" + os.path.join(ROOT, "include"), "-"], input=bad, capture_output=True, text=True)
     assert r.returncode != 0
+
+
+def test_r_shim_runs_against_a_mock_r_api(oracle, bourne, tmp_path):
+    """r/splash_shim.c COMPILED AND EXECUTED (no R in this image: against tests/csrc/r_mock/r_mock.c, a mock of the ~30
+    functions of R's C API the shim uses, and the declarations-only headers of tests/csrc/r_decls/).  The mock's driver
+    calls the shim's .Call entry points through the shim's own registration table, with the host backend (devices = -1L /
+    backend = 1L: no GPU needed), and checks on its side: registration arities, PROTECT balance of every call, result list
+    names and matrix dimensions, submit/wait == run bit for bit, the finalizer of a dropped handle, and that bad arguments,
+    a second collect, and the default backend without a device are R errors.  Here: what came back through the SEXPs equals
+    what the Python mirror gets from the same C ABI -- splash.point on Bourne (R/splash.point.R:29), a row block
+    (R/splash.grid.R:277-308), and the series in two time chunks (ABI 5) == the undivided block, bit for bit.
+    What this cannot show is that real R behaves like the mock."""
+    import subprocess
+    import rsplash_amd
+    from rsplash_amd import api
+    so = rsplash_amd.build_library()
+    d = os.path.dirname(so)
+    exe = str(tmp_path / "r_mock")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wno-cast-function-type", "-Werror",
+                           "-I" + os.path.join(ROOT, "tests/csrc/r_decls"), "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "r/splash_shim.c"), os.path.join(ROOT, "tests/csrc/r_mock/r_mock.c"),
+                           "-L" + d, "-lrsplash_hip", "-Wl,-rpath," + d, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
+                           "-o", exe])
+    b, s = bourne, bourne["site"]
+    nt = 800
+    cut = 397                                     # 2009-02-01 (2008 is a leap year): the second chunk starts on the first day of a month
+    assert b["dates"][cut].astype("datetime64[D]").astype(object).day == 1
+    H, W = 2, 8
+    n = H * W
+    doy, year, month = b["doy"][:nt], b["year"][:nt], b["month"][:nt]
+    st = oracle.synth_statics(1234, H, W, 0, n, 1)
+    sw, tc, pn = oracle.synth_forcing(1234, H, W, 0, n, 0, doy, st["lat"], st["elev"])
+    # the whole series' snowfall threshold per cell (R/splash.point.R:120-122), from the host backend's own aux
+    dates = b["dates"][:nt]
+    full = api.splash_grid(sw, tc, pn, st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"], st["resolution"],
+                           time_index=dates, sim_control=dict(monthly_out=False), want_aux=True, backend="host")
+    tt = full["aux"]["Tt"]
+    site = [s["latitude"], s["elev_m"], s["slop_250m"], s["asp_250m"], s["resolution"], s["Aups_250m"]]
+    soil1 = np.asarray(b["soil"], dtype=np.float64)
+    stat = np.stack([st["lat"], st["elev"], st["slop"], st["asp"], st["resolution"]])
+    blob = np.concatenate([[nt, n, cut], site, soil1, doy, year, month, b["sw_in"][:nt], b["Ta"][:nt], b["P"][:nt],
+                           stat.ravel(), st["soil"].ravel(), st["au"].ravel(), tt, sw.ravel(), tc.ravel(), pn.ravel()])
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    blob.astype("f8").tofile(fin)
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "0 problems" in r.stdout
+    got = np.fromfile(fout)
+    names = api.OUT_NAMES
+    pt = got[:9 * nt].reshape(9, nt)
+    ref = api.splash_point(b["sw_in"][:nt], b["Ta"][:nt], b["P"][:nt], s["latitude"], s["elev_m"], s["slop_250m"],
+                           s["asp_250m"], soil1, s["Aups_250m"], s["resolution"], time_index=dates, backend="host")
+    for i, k in enumerate(names):
+        assert np.array_equal(pt[i], ref[k], equal_nan=True), k
+    at = 9 * nt
+    gr = got[at:at + 9 * nt * n].reshape(9, nt, n)
+    at += 9 * nt * n
+    ch = got[at:at + 9 * nt * n].reshape(9, nt, n)       # (each series: chunk 1 then chunk 2)
+    at += 9 * nt * n
+    se = got[at:at + 5 * n].reshape(5, n)
+    for i, k in enumerate(names):
+        assert np.array_equal(gr[i], full[k], equal_nan=True), k
+        assert np.array_equal(ch[i], full[k], equal_nan=True), "time chunks: " + k
+    assert np.array_equal(se, full["state_end"], equal_nan=True)
