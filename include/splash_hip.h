@@ -20,8 +20,10 @@
  * matrix from raster::getValues, R/splash.grid.R:278-280), cell index = row-major raster cell.
  * Every function returns 0 on success or a negative SPLASH_E* code; when `err` is non-NULL a
  * message is written there.  Nothing is freed or retained except what the *_create calls return.
- * The library has no CPU fallback: without a HIP device every compute entry point fails with
- * SPLASH_ENODEV.
+ * The library has no CPU FALLBACK: without a HIP device every compute entry point fails with
+ * SPLASH_ENODEV.  (ABI 6: a caller may CHOOSE the host backend for one-site / few-cell calls --
+ * splash_opts.backend, splash_point_run_backend, splash_mod_backend: the same day step, the
+ * library's own device functions compiled for the host; it is never chosen for the caller.)
  */
 #ifndef SPLASH_HIP_H
 #define SPLASH_HIP_H
