@@ -10,6 +10,8 @@ ranks already exist and nothing is spawned.
 
 Workloads (BASELINE.json configs; --config selects, default 2 = the configuration the metric is
 quoted on):
+  0  splash.point on the bundled Bourne SNOTEL site (2 922 days + both spin-ups): the call's latency on the GPU and
+     with the host backend (ABI 6: "CPU reference path (plumbing, no GPU)"), checked against the oracle
   1  256 x 256 flat-terrain grid, 365 days, 1 GPU
   2  4096 x 4096 grid with slope/aspect/upslope area, 365 days.  With N ranks (`--scaling`):
        strong (default)  THE 4096 x 4096 grid of the metric, row blocks of `--chunk-rows` rows dealt
@@ -88,7 +90,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4))
+    ap.add_argument("--config", type=int, default=2, choices=(0, 1, 2, 3, 4))
     ap.add_argument("--rows", type=int, default=None, help="grid rows per GPU")
     ap.add_argument("--cols", type=int, default=None)
     ap.add_argument("--days", type=int, default=None)
@@ -183,7 +185,10 @@ def main():
     from rsplash_amd import api
 
     ctx = dict(args=args, world=world, rank=rank, dev=dev, backend=backend, api=api, torch=torch, dist=dist)
-    line = run_resident(ctx) if args.config in (1, 2) else run_streamed(ctx)
+    if args.config == 0:
+        line = run_point(ctx)
+    else:
+        line = run_resident(ctx) if args.config in (1, 2) else run_streamed(ctx)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
@@ -301,6 +306,56 @@ def roofline(avg_launch_s, units_per_launch, key, kernel):
             "alg_bytes_per_unit": ALG_BYTES_PER_CELL_DAY, "valu_busy_frac": valu_busy,
             "note": "the launch is FP64-VALU-issue bound, not HBM bound (vector instructions per "
                     "wavefront-day and valu_busy_frac from the PMC pass in profiles/; DESIGN.md)"}
+
+
+# ------------------------------------------------------------------------------------ config 0
+def run_point(ctx):
+    """BASELINE configs[0]: splash.point on the bundled Bourne site (tests/golden: decoded from data/Bourne.RData),
+    the reference's README example (README.md:28-61).  One cell: a latency, not a throughput -- reported as cell-days/s of
+    the call on the GPU (`value`) and with the host backend, both checked against the oracle."""
+    import csv
+    import datetime
+    api = ctx["api"]
+    from oracle.binding import Oracle
+    gold = os.path.join(ROOT, "tests", "golden")
+    rows = list(csv.DictReader(open(os.path.join(gold, "bourne_forcing.csv"))))
+    site = json.load(open(os.path.join(gold, "bourne_site.json")))
+    dates = np.array([datetime.date.fromisoformat(r["date"]) for r in rows], dtype="datetime64[D]")
+    P, Ta, sw = (np.array([float(r[k]) for r in rows]) for k in ("P", "Ta", "sw_in"))
+    soil = np.array([np.nan if v is None else v for v in site["soil"]])
+    nt = len(dates)
+    steps = ctx["args"].steps if ctx["args"].steps is not None else 10
+    warmup = ctx["args"].warmup if ctx["args"].warmup is not None else 2
+    call = lambda backend: api.splash_point(sw, Ta, P, site["latitude"], site["elev_m"], site["slop_250m"], site["asp_250m"],
+                                            soil, site["Aups_250m"], site["resolution"], time_index=dates, backend=backend)
+    res, secs = {}, {}
+    for backend in ("hip", "host"):
+        for _ in range(warmup):
+            call(backend)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res[backend] = call(backend)
+        secs[backend] = (time.perf_counter() - t0) / steps
+    o = Oracle()
+    doy, year, month = api.time_fields(dates)
+    mid = api.month_ids(year, month)
+    t0 = time.perf_counter()
+    ref, aux = o.point(doy, year, month, mid, int(mid[-1]) + 1, sw, Ta, P, site["latitude"], site["elev_m"], site["slop_250m"],
+                       site["asp_250m"], soil, [site["Aups_250m"], 3, 3], site["resolution"])
+    t_orc = time.perf_counter() - t0
+    rel = {b: max(float(np.max(np.abs(res[b][k] - ref[k]) / np.maximum(np.abs(ref[k]), 1e-6))) for k in OUT5) for b in res}
+    line = base_line(ctx, nt / secs["hip"], steps, warmup, secs["hip"] * steps,
+                     f"splash.point on the bundled Bourne SNOTEL site, {nt} days (+ both spin-ups), one cell: the call's latency",
+                     {"scaling": "weak", "days": nt, "timed": "the whole splash_point_run call (host buffers in and out)"})
+    line["config"].pop("scaling", None)
+    line["latency_ms"] = {"gpu": secs["hip"] * 1e3, "host_backend": secs["host"] * 1e3, "oracle_plain_c_one_core": t_orc * 1e3}
+    line["value_host_backend"] = nt / secs["host"]
+    line["max_rel_err_vs_oracle"] = rel
+    line["roofline"] = None
+    line["cpu_baseline"] = {"value": nt / t_orc, "unit": "cell-days/s", "cores": 1, "kind": "port",
+                            "sample": "the same call through the oracle's plain-C restatement, one core, one run"}
+    assert max(rel.values()) < 1e-5, rel
+    return line
 
 
 # ------------------------------------------------------------------------------------ configs 1, 2

@@ -1,6 +1,7 @@
 """Randomised gaps in the forcing (NaN in tc, sw_in or pn on random cell-days, before and after the
 spin-up year): the NaN pattern of every output must equal the oracle's (R's NA propagation,
-R/splash.point.R:120-128) and the numbers must be within tolerance.  GPU box.
+R/splash.point.R:120-128) and the numbers must be within tolerance.  GPU box -- or, with SPLASH_SWEEP_BACKEND=host, the
+host backend (ABI 6) in the build container, no GPU.
     python tools/fuzz_gaps.py [n_cases=8]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +10,7 @@ import rsplash_amd.api as api
 from oracle.binding import Oracle
 from oracle.parity import _bad
 o = Oracle()
+backend = os.environ.get("SPLASH_SWEEP_BACKEND", "hip")
 rng = np.random.default_rng(4242)
 bad = 0
 for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
@@ -25,7 +27,8 @@ for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
         for t in rng.choice(nt, int(rng.integers(1, 4)), replace=False):
             arr[t, c] = np.nan
     g = api.splash_grid(sw, tc, pn, st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"],
-                        st["resolution"], time_index=dates, sim_control=dict(monthly_out=False), want_aux=True)
+                        st["resolution"], time_index=dates, sim_control=dict(monthly_out=False), want_aux=True,
+                        backend=backend)
     ref, aux = o.grid(doy, year, month, mid, nm, sw, tc, pn, st["lat"], st["elev"], st["slop"], st["asp"],
                       st["soil"], st["au"], st["resolution"])
     msgs = []
