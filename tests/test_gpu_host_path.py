@@ -275,6 +275,15 @@ def test_host_path_pipeline_lanes_pool_and_jobs_give_the_same_bits(api, oracle):
         os.environ["SPLASH_HIP_BLOCKS_PER_LANE"] = "6"
         os.environ["SPLASH_HIP_LANES"] = "3"
         same(ref, call(), "prefault + registered arrays, 3 lanes x 6 blocks")
+        # round 6: three workers on the one GPU -- 6 144 cells are dealt as 24 chunks of 256, eight to a worker, so a
+        # worker's blocks are SEVERAL runs of consecutive cells: the dense fast paths (strided copies from and to the
+        # caller's arrays, page mapping per run, page-locked arrays) loop over them (for_runs), on two lanes with the pool
+        os.environ["SPLASH_HIP_LANES"] = "2"
+        os.environ["SPLASH_HIP_BLOCKS_PER_LANE"] = "2"
+        bufs = {k: np.full((nt_out, n), -12345.678) for k in ("wn", "ro", "pet", "aet", "snow", "cond", "bflow",
+                                                               "netr", "sm_lim")}
+        same(ref, call(out=bufs, devices=[0, 0, 0]), "three workers, chunks dealt round-robin, blocks of several runs")
+        os.environ["SPLASH_HIP_LANES"] = "3"
         for k in ("SPLASH_HIP_PREFAULT", "SPLASH_HIP_PREFAULT_MIN_BYTES", "SPLASH_HIP_REGISTER_MIN_BYTES",
                   "SPLASH_HIP_BLOCKS_PER_LANE", "SPLASH_HIP_MIN_BLOCK_CELLS"):
             os.environ.pop(k)
