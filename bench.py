@@ -263,13 +263,13 @@ def kernel_sources_sha16(root=None):
     """sha256 (first 16 hex digits) of the kernels' sources WITHOUT comments and white space: the PMC figures of
     profiles/traffic.json carry the hash of the sources they were measured on, so a constant that went stale with a
     kernel change shows in the line (and an edited comment does not raise a false alarm)"""
-    import glob
     import hashlib
     import re
     root = root or ROOT
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(root, "rsplash_amd", "csrc", "*.hip")) +
-                    glob.glob(os.path.join(root, "rsplash_amd", "csrc", "*.hpp"))):
+    # the translation unit of the day-loop kernels and what it includes -- not the host side of the library
+    names = ("splash_kernels.hip", "splash_kernels.hpp", "splash_device.hpp", "splash_math.hpp", "splash_log_table.hpp")
+    for f in [os.path.join(root, "rsplash_amd", "csrc", n) for n in names]:
         txt = open(f, encoding="utf-8", errors="replace").read()
         txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)      # block comments
         txt = re.sub(r"//[^\n]*", " ", txt)                    # line comments (no string of these files holds "//")
