@@ -41,6 +41,25 @@ int fail(int code, char* err, size_t errlen, const char* fmt, ...)
     }
     return code;
 }
+
+int exception_code(char* err, size_t errlen, const char* where) noexcept
+{
+    // (fail() assigns a std::string: under memory pressure that can throw again -- then only the code is reported)
+    try {
+        try {
+            throw;
+        } catch (const std::bad_alloc&) {
+            return fail(SPLASH_ENOMEM, err, errlen, "%s: out of host memory", where);
+        } catch (const std::exception& e) {
+            return fail(SPLASH_EHIP, err, errlen, "%s: %s", where, e.what());
+        } catch (...) {
+            return fail(SPLASH_EHIP, err, errlen, "%s: unknown C++ exception", where);
+        }
+    } catch (...) {
+        if (err && errlen) snprintf(err, errlen, "%s: out of host memory", where);
+        return SPLASH_ENOMEM;
+    }
+}
 } // namespace host
 } // namespace splash
 
@@ -99,6 +118,7 @@ void knobs_read_locked()
     k.prefault_min_bytes = env_size("SPLASH_HIP_PREFAULT_MIN_BYTES", k.prefault_min_bytes);
     k.prefault_delay_ms = env_size("SPLASH_HIP_PREFAULT_DELAY_MS", 0);
     k.test_prefault_whole_range = getenv("SPLASH_HIP_TEST_PREFAULT_WHOLE_RANGE") != nullptr;
+    if (const char* e = getenv("SPLASH_HIP_TEST_THROW")) k.test_throw = atoi(e);
     k.trace = getenv("SPLASH_TRACE") != nullptr;
     if (const char* e = getenv("SPLASH_HIP_LANES")) k.lanes = std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("SPLASH_HIP_FAKE_DEVICE_BYTES")) {
@@ -281,11 +301,13 @@ int visc_tables(ViscTables& vt)
 } // namespace splash
 
 extern "C" int splash_hip_cache_stats(int device, size_t* held_bytes, size_t* idle_bytes)
-{
+try {
     if (device < 0 || device >= 64) return fail(SPLASH_EINVAL, nullptr, 0, "cache_stats: device %d out of range", device);
     if (held_bytes) *held_bytes = pool_held_bytes(device);
     if (idle_bytes) *idle_bytes = pool_idle_bytes(device);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_hip_cache_stats");
 }
 
 extern "C" void splash_hip_release_cache(void)
@@ -366,11 +388,13 @@ void orbit_day(int n, int y, double& dr, double& sd, double& cd)
 
 // host-only: the day-static orbit terms of one calendar day (no device needed)
 extern "C" int splash_orbit_day(int doy, int year, double* dr, double* sd, double* cd)
-{
+try {
     if (doy < 1 || doy > 366 || !dr || !sd || !cd)
         return fail(SPLASH_EINVAL, nullptr, 0, "orbit_day: bad argument");
     orbit_day(doy, year, *dr, *sd, *cd);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_orbit_day");
 }
 
 void splash::host::orbit_of_day(int doy, int year, double& dr, double& sd, double& cd) { orbit_day(doy, year, dr, sd, cd); }
@@ -418,7 +442,7 @@ int splash::host::calendar_host(int nt, const int* doy, const int* year, const i
 
 extern "C" int splash_calendar_create(int nt, const int* doy, const int* year, const int* month,
                                       splash_calendar** out, char* err, size_t errlen)
-{
+try {
     if (!out || nt <= 0 || !doy || !year || !month)
         return fail(SPLASH_EINVAL, err, errlen, "calendar: nt must be > 0 and doy/year/month given");
     if (int rc = enter_device(err, errlen)) return rc;
@@ -444,6 +468,8 @@ extern "C" int splash_calendar_create(int nt, const int* doy, const int* year, c
     }
     *out = cal;
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(err, errlen, "splash_calendar_create");
 }
 
 extern "C" void splash_calendar_destroy(splash_calendar* cal)
@@ -457,7 +483,7 @@ extern "C" int splash_calendar_nt(const splash_calendar* cal) { return cal ? cal
 extern "C" int splash_calendar_nmonth(const splash_calendar* cal) { return cal ? cal->nmonth : 0; }
 
 extern "C" int splash_calendar_orbit(const splash_calendar* cal, double* dr, double* sd, double* cd)
-{
+try {
     if (!cal) return fail(SPLASH_EINVAL, nullptr, 0, "calendar is NULL");
     for (int t = 0; t < cal->nt; t++) {
         if (dr) dr[t] = cal->host[t].dr;
@@ -465,6 +491,8 @@ extern "C" int splash_calendar_orbit(const splash_calendar* cal, double* dr, dou
         if (cd) cd[t] = cal->host[t].cd;
     }
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_calendar_orbit");
 }
 
 // ------------------------------------------------------------------ device-resident stages
@@ -472,23 +500,27 @@ extern "C" int splash_dev_soil_hydro(size_t ncell, const double* lat, const doub
                                      const double* slop, const double* asp,
                                      const double* resolution, const double* soil, const double* au,
                                      double* cellpar, void* stream)
-{
+try {
     REQ(lat && elev && slop && asp && resolution && soil && cellpar, "soil_hydro: NULL argument");
     if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_soil_hydro(ncell, lat, elev, slop, asp, resolution, soil, au, cellpar,
                               (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_soil_hydro");
 }
 
 extern "C" int splash_dev_snow_threshold(size_t ncell, int nt, const double* tc, size_t ldf,
                                          const double* cellpar, size_t ldp, double* Tt, void* stream)
-{
+try {
     REQ(tc && cellpar && Tt && nt > 0, "snow_threshold: NULL argument or nt <= 0");
     REQ(ldf >= ncell && ldp >= ncell, "snow_threshold: leading dimension smaller than ncell");
     if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_snow_threshold(ncell, nt, tc, ldf, cellpar, ldp, Tt, (hipStream_t)stream),
             nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_snow_threshold");
 }
 
 // workspace of splash_dev_spin_up: three worklists, job records, aridity index, phase counters, and
@@ -756,10 +788,12 @@ extern "C" int splash_dev_spin_up(const splash_calendar* cal, size_t ncell, cons
                                   const double* tc, const double* pn, size_t ldf, const double* Tt,
                                   double* cellpar, size_t ldp, double* state, size_t lds,
                                   int* passes, void* work, void* stream)
-{
+try {
     knobs_refresh(); // the caller's thread (a no-op on a lane or pool thread: KnobScope); spin_phases() itself never refreshes
     return spin_phases(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, passes, work,
                        stream, 0, kSpinPhases);
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_spin_up");
 }
 
 extern "C" int splash_dev_spin_up_begin(const splash_calendar* cal, size_t ncell,
@@ -767,10 +801,12 @@ extern "C" int splash_dev_spin_up_begin(const splash_calendar* cal, size_t ncell
                                         size_t ldf, const double* Tt, double* cellpar, size_t ldp,
                                         double* state, size_t lds, int* passes, void* work,
                                         void* stream)
-{
+try {
     knobs_refresh(); // the caller's thread (a no-op on a lane or pool thread: KnobScope); spin_phases() itself never refreshes
     return spin_phases(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, passes, work,
                        stream, 0, kSpinPhases - 1);
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_spin_up_begin");
 }
 
 extern "C" int splash_dev_spin_up_finish(const splash_calendar* cal, size_t ncell,
@@ -778,15 +814,17 @@ extern "C" int splash_dev_spin_up_finish(const splash_calendar* cal, size_t ncel
                                          size_t ldf, const double* Tt, double* cellpar, size_t ldp,
                                          double* state, size_t lds, int* passes, void* work,
                                          void* stream)
-{
+try {
     knobs_refresh(); // the caller's thread (a no-op on a lane or pool thread: KnobScope); spin_phases() itself never refreshes
     return spin_phases(cal, ncell, sw_in, tc, pn, ldf, Tt, cellpar, ldp, state, lds, passes, work,
                        stream, kSpinPhases - 1, kSpinPhases);
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_spin_up_finish");
 }
 
 extern "C" int splash_dev_spin_up_pending(void* work, size_t ncell, const unsigned char** mask,
                                           const uint32_t** cells, const uint32_t** n_cells)
-{
+try {
     REQ(work, "spin_up_pending: NULL workspace");
     size_t o_wl_b, o_meta, o_ai, o_cnt, o_cache, o_pend;
     spin_work_layout(ncell, &o_wl_b, &o_meta, &o_ai, &o_cnt, &o_cache, &o_pend);
@@ -796,17 +834,21 @@ extern "C" int splash_dev_spin_up_pending(void* work, size_t ncell, const unsign
     if (cells) *cells = (const uint32_t*)w;
     if (n_cells) *n_cells = (const uint32_t*)(w + o_cnt) + (kSpinPhases - 2);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_spin_up_pending");
 }
 
 extern "C" int splash_dev_spin_up_pending_count(void* work, size_t ncell, void* stream,
                                                 uint32_t* n_pending)
-{
+try {
     REQ(work && n_pending, "spin_up_pending_count: NULL argument");
     const uint32_t* d_n = nullptr;
     (void)splash_dev_spin_up_pending(work, ncell, nullptr, nullptr, &d_n);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream), nullptr, 0);
     HIP_TRY(hipMemcpy(n_pending, d_n, sizeof(uint32_t), hipMemcpyDeviceToHost), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_spin_up_pending_count");
 }
 
 extern "C" size_t splash_dev_diag_acc_size(int n_basin, int nmonth)
@@ -816,12 +858,14 @@ extern "C" size_t splash_dev_diag_acc_size(int n_basin, int nmonth)
 
 extern "C" int splash_dev_diag_finalize(const int64_t* diag_acc, int n_basin, int nmonth,
                                         double* diag, double* counts, void* stream)
-{
+try {
     REQ(diag_acc && diag && nmonth >= 0, "diag_finalize: NULL argument");
     if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_diag_finalize((const long long*)diag_acc, std::max(n_basin, 1) * nmonth, diag,
                                  counts, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_diag_finalize");
 }
 
 // the same conversion on the host: value = limb0/2^16 + limb1/2^48 (exact up to the final rounding)
@@ -848,7 +892,7 @@ extern "C" int splash_dev_run_all(const splash_calendar* cal, int t0, int nt, si
                                   const double* sw_in, const double* tc, const double* pn,
                                   size_t ldf, const double* Tt, const double* cellpar, size_t ldp,
                                   double* state, size_t lds, const splash_dev_out* out, void* stream)
-{
+try {
     REQ(cal && sw_in && tc && pn && Tt && cellpar && state && out, "run_all: NULL argument");
     REQ(t0 >= 0 && nt >= 0 && t0 + nt <= cal->nt, "run_all: day range outside the calendar");
     REQ(ldf >= ncell && ldp >= ncell && lds >= ncell && out->ldo >= ncell,
@@ -890,26 +934,30 @@ extern "C" int splash_dev_run_all(const splash_calendar* cal, int t0, int nt, si
     if (int rc = visc_tables(a.vt)) return rc;
     HIP_TRY(launch_run_all(a, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_run_all");
 }
 
 extern "C" int splash_dev_synth_statics(uint64_t seed, int H, int W, int64_t cell0, size_t ncell,
                                         int terrain, double* lat, double* elev, double* slop,
                                         double* asp, double* resolution, double* soil, double* au,
                                         void* stream)
-{
+try {
     REQ(lat && elev && slop && asp && resolution && soil && au && H > 0 && W > 0,
         "synth_statics: NULL argument");
     if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_synth_statics(seed, H, W, cell0, ncell, terrain, lat, elev, slop, asp,
                                  resolution, soil, au, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_synth_statics");
 }
 
 extern "C" int splash_dev_synth_forcing(uint64_t seed, const splash_calendar* cal, int t0, int nt,
                                         int64_t cell0, size_t ncell, const double* lat,
                                         const double* elev, double* sw_in, double* tc, double* pn,
                                         size_t ldf, void* stream)
-{
+try {
     REQ(cal && lat && elev && sw_in && tc && pn, "synth_forcing: NULL argument");
     REQ(t0 >= 0 && nt >= 0 && t0 + nt <= cal->nt, "synth_forcing: day range outside the calendar");
     REQ(ldf >= ncell, "synth_forcing: leading dimension < ncell");
@@ -917,13 +965,15 @@ extern "C" int splash_dev_synth_forcing(uint64_t seed, const splash_calendar* ca
     HIP_TRY(launch_synth_forcing(seed, cal->dev + t0, t0, nt, cell0, ncell, lat, elev, sw_in, tc,
                                  pn, ldf, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_synth_forcing");
 }
 
 // static rasters before the loop: R/splash.grid.R:96-110, R/upslope_area.R:31-33
 extern "C" int splash_dev_terrain(int H, int W, const double* elev, double ymax, double yres,
                                   double xres, int na_to_zero, double* slope_deg, double* aspect_deg,
                                   double* lat, double* resolution_m, double* flowdir, void* stream)
-{
+try {
     REQ(elev && H > 0 && W > 0, "terrain: NULL elevation or empty grid");
     REQ(yres > 0 && xres > 0, "terrain: cell size must be positive (degrees)");
     REQ(slope_deg || aspect_deg || lat || resolution_m || flowdir, "terrain: no output requested");
@@ -931,34 +981,40 @@ extern "C" int splash_dev_terrain(int H, int W, const double* elev, double ymax,
     HIP_TRY(launch_terrain(H, W, elev, ymax, yres, xres, na_to_zero, slope_deg, aspect_deg, lat,
                            resolution_m, flowdir, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_terrain");
 }
 
 extern "C" int splash_dev_ncellflow(int H, int W, const double* flowdir, const double* codes9,
                                     int pad, double* ncell, void* stream)
-{
+try {
     REQ(flowdir && codes9 && ncell && H > 0 && W > 0, "ncellflow: NULL argument or empty grid");
     if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_ncellflow(H, W, flowdir, codes9, pad, ncell, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_ncellflow");
 }
 
 // sink fill and contributing area (the rest of R/upslope_area.R: SURVEY 8f-1)
 extern "C" int splash_dev_sinkfill(int H, int W, const double* elev, double resolution_m,
                                    double degree, double* filled, int* sweeps, void* stream)
-{
+try {
     REQ(elev && filled && H > 0 && W > 0, "sinkfill: NULL argument or empty grid");
     REQ(elev != filled, "sinkfill: the filled surface needs its own raster");
     REQ(resolution_m > 0 && degree >= 0 && degree < 90, "sinkfill: resolution must be positive, 0 <= degree < 90");
     if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_sinkfill(H, W, elev, resolution_m, degree, filled, sweeps, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_sinkfill");
 }
 
 extern "C" int splash_dev_flow_accumulation(int H, int W, const double* flowdir, const double* elev,
                                             int tau_codes, const double* resolution_m,
                                             double* ups_ncell, double* ups_area, int* levels,
                                             void* stream)
-{
+try {
     REQ(flowdir && H > 0 && W > 0, "flow_accumulation: NULL flow direction or empty grid");
     REQ(ups_ncell || ups_area, "flow_accumulation: no output requested");
     REQ(!ups_area || resolution_m, "flow_accumulation: the area needs the resolution raster");
@@ -967,24 +1023,28 @@ extern "C" int splash_dev_flow_accumulation(int H, int W, const double* flowdir,
     HIP_TRY(launch_flow_accumulation(H, W, flowdir, elev, tau_codes, resolution_m, ups_ncell, ups_area, levels,
                                      (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_flow_accumulation");
 }
 
 extern "C" int splash_dev_mfd_area(int H, int W, const double* elev, double resolution_m,
                                    double* area, int* levels, void* stream)
-{
+try {
     REQ(elev && area && H > 0 && W > 0, "mfd_area: NULL argument or empty grid");
     REQ(resolution_m > 0, "mfd_area: resolution must be positive");
     REQ((size_t)H * W < ((size_t)1 << 32), "mfd_area: more than 2^32-1 cells");
     if (int rc = enter_device(nullptr, 0)) return rc;
     HIP_TRY(launch_mfd_area(H, W, elev, resolution_m, area, levels, (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_mfd_area");
 }
 
 // unSWC epilogue on device-resident rasters (R/unsSWC.R:14-88, R/unsSWC.grid.R)
 extern "C" int splash_dev_unswc(size_t ncell, int nt, const double* wn, size_t ldw,
                                 const double* soil, double uns_depth, double* wn_z, double* wtd,
                                 double* theta, size_t ldo, void* stream)
-{
+try {
     REQ(wn && soil && (wn_z || wtd || theta), "unswc: NULL argument");
     REQ(ldw >= ncell && ldo >= ncell && nt >= 0, "unswc: leading dimension < ncell");
     REQ(uns_depth > 0, "unswc: uns_depth must be positive");
@@ -992,6 +1052,8 @@ extern "C" int splash_dev_unswc(size_t ncell, int nt, const double* wn, size_t l
     HIP_TRY(launch_unswc(ncell, nt, wn, ldw, soil, uns_depth, wn_z, wtd, theta, ldo,
                          (hipStream_t)stream), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_unswc");
 }
 
 // test hook: SOLAR+EVAP rows (host pointers)
@@ -1000,7 +1062,7 @@ extern "C" int splash_dev_evap_batch(size_t m, const double* lat, const double* 
                                      const double* sw_in, const double* tc, const double* slop,
                                      const double* asp, const double* snow, const double* nd,
                                      double* out, void* stream)
-{
+try {
     (void)stream;
     REQ(lat && elv && sw && n && y && sw_in && tc && slop && asp && snow && nd && out,
         "evap_batch: NULL argument");
@@ -1026,11 +1088,13 @@ extern "C" int splash_dev_evap_batch(size_t m, const double* lat, const double* 
                               buf[8].as<double>(), dout.as<double>(), vt, nullptr), nullptr, 0);
     HIP_TRY(hipMemcpy(out, dout.p, 11 * m * 8, hipMemcpyDeviceToHost), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_evap_batch");
 }
 
 // test hook: device flog/fexp/fpow/facos/fsqrt for n arguments (host pointers); out [5][n]
 extern "C" int splash_dev_math_probe(size_t n, const double* x, const double* y, double* out)
-{
+try {
     REQ(x && y && out, "math_probe: NULL argument");
     if (int rc = enter_device(nullptr, 0)) return rc;
     if (n == 0) return SPLASH_OK;
@@ -1044,13 +1108,15 @@ extern "C" int splash_dev_math_probe(size_t n, const double* x, const double* y,
             nullptr, 0);
     HIP_TRY(hipMemcpy(out, dout.p, 7 * n * 8, hipMemcpyDeviceToHost), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_math_probe");
 }
 
 // test hook: the day loop's own moist_surf()/inf_GA() device functions (host pointers)
 extern "C" int splash_dev_infiltration_probe(size_t n, const double* cellpar, const double* wn,
                                              const double* ksat_visc, const double* P,
                                              double* theta_surf, double* infiltration)
-{
+try {
     REQ(cellpar && wn && ksat_visc && P && theta_surf && infiltration,
         "infiltration_probe: NULL argument");
     if (int rc = enter_device(nullptr, 0)) return rc;
@@ -1072,6 +1138,8 @@ extern "C" int splash_dev_infiltration_probe(size_t n, const double* cellpar, co
     HIP_TRY(hipMemcpy(theta_surf, dt.p, n * 8, hipMemcpyDeviceToHost), nullptr, 0);
     HIP_TRY(hipMemcpy(infiltration, di.p, n * 8, hipMemcpyDeviceToHost), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_infiltration_probe");
 }
 
 extern "C" int splash_point_run_backend(int backend, int nt, const int* doy, const int* year, const int* month,
@@ -1079,7 +1147,7 @@ extern "C" int splash_point_run_backend(int backend, int nt, const int* doy, con
                                         double elev, double slop, double asp, const double* soil_data,
                                         const double* au, int n_au, double resolution, int monthly_out,
                                         double* const outp[SPLASH_NOUT], char* err, size_t errlen)
-{
+try {
     if (!soil_data || !outp) return fail(SPLASH_EINVAL, err, errlen, "point_run: NULL argument");
     if (backend != SPLASH_BACKEND_HIP && backend != SPLASH_BACKEND_HOST)
         return fail(SPLASH_EINVAL, err, errlen, "point_run: unknown backend %d", backend);
@@ -1114,6 +1182,8 @@ extern "C" int splash_point_run_backend(int backend, int nt, const int* doy, con
     splash_grid_out o{};
     for (int k = 0; k < SPLASH_NOUT; k++) o.out[k] = outp[k];
     return splash_grid_run(&in, &opt, &o, err, errlen);
+} catch (...) {
+    return exception_code(err, errlen, "splash_point_run_backend");
 }
 
 extern "C" int splash_point_run(int nt, const int* doy, const int* year, const int* month,
@@ -1121,9 +1191,11 @@ extern "C" int splash_point_run(int nt, const int* doy, const int* year, const i
                                 double elev, double slop, double asp, const double* soil_data,
                                 const double* au, int n_au, double resolution, int monthly_out,
                                 double* const outp[SPLASH_NOUT], char* err, size_t errlen)
-{
+try {
     return splash_point_run_backend(SPLASH_BACKEND_HIP, nt, doy, year, month, sw_in, tc, pn, lat, elev, slop, asp,
                                     soil_data, au, n_au, resolution, monthly_out, outp, err, errlen);
+} catch (...) {
+    return exception_code(err, errlen, "splash_point_run");
 }
 
 extern "C" int splash_host_backend_fma(void) { return host_backend_fma() ? 1 : 0; }
@@ -1132,7 +1204,7 @@ extern "C" int splash_host_backend_fma(void) { return host_backend_fma() ? 1 : 0
 extern "C" int splash_unswc_run(size_t ncell, int nt, const double* wn, const double* soil,
                                 double uns_depth, double* wn_z, double* wtd, double* theta,
                                 char* err, size_t errlen)
-{
+try {
     if (!wn || !soil) return fail(SPLASH_EINVAL, err, errlen, "unswc_run: NULL input");
     if (int rc = enter_device(err, errlen)) return rc;
     if (ncell == 0 || nt <= 0) return SPLASH_OK;
@@ -1154,13 +1226,15 @@ extern "C" int splash_unswc_run(size_t ncell, int nt, const double* wn, const do
     if (wtd) HIP_TRY(hipMemcpy(wtd, dt_.p, n * 8, hipMemcpyDeviceToHost), err, errlen);
     if (theta) HIP_TRY(hipMemcpy(theta, dh.p, n * 8, hipMemcpyDeviceToHost), err, errlen);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(err, errlen, "splash_unswc_run");
 }
 
 // K2 on host buffers (ABI 5): the snowfall threshold of a tc series, for callers that process a long
 // series in time chunks -- the threshold of the whole series is the maximum of the chunks' (R/splash.point.R:120-122).
 extern "C" int splash_snow_threshold_run(size_t ncell, int nt, const double* tc, const float* tc_f32,
                                          const double* lat, const double* elev, double* tt, char* err, size_t errlen)
-{
+try {
     if (!lat || !elev || !tt || ((tc != nullptr) == (tc_f32 != nullptr)) || nt < 1)
         return fail(SPLASH_EINVAL, err, errlen,
                     "snow_threshold_run: NULL argument, nt < 1, or not exactly one of tc / tc_f32");
@@ -1195,13 +1269,15 @@ extern "C" int splash_snow_threshold_run(size_t ncell, int nt, const double* tc,
         HIP_TRY(hipMemcpy(tt + c0, d_tt.p, n * 8, hipMemcpyDeviceToHost), err, errlen);
     }
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(err, errlen, "splash_snow_threshold_run");
 }
 
 // static rasters on host buffers: R/splash.grid.R:96-110 + upslope_area() (R/upslope_area.R:12-58)
 extern "C" int splash_static_rasters_run(int H, int W, const double* elev, double ymax, double yres,
                                          double xres, int na_to_zero, double degree,
                                          const splash_static_out* out, char* err, size_t errlen)
-{
+try {
     if (!elev || !out || H <= 0 || W <= 0)
         return fail(SPLASH_EINVAL, err, errlen, "static_rasters_run: NULL argument or empty grid");
     if (int rc = enter_device(err, errlen)) return rc;
@@ -1281,6 +1357,8 @@ extern "C" int splash_static_rasters_run(int H, int W, const double* elev, doubl
     for (auto& b : back)
         if (b.h) HIP_TRY(hipMemcpy(b.h, b.d->p, nb, hipMemcpyDeviceToHost), err, errlen);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(err, errlen, "splash_static_rasters_run");
 }
 
 // ------------------------------------------------------------------ Rcpp-module mirrors
@@ -1328,7 +1406,7 @@ extern "C" int splash_mod_spin_up(double lat, double elv, int n, int y, const do
                                   const double* snowfall, const double* soil_info, double* sm,
                                   double* snow, double* qin, double* tdrain, double* ro,
                                   double* snwage, double* pet, int* passes)
-{
+try {
     REQ(n > 0 && sw_in && tair && pn && snowfall && soil_info, "mod_spin_up: bad argument");
     const bool on_host = t_mod_backend == SPLASH_BACKEND_HOST;
     if (!on_host)
@@ -1389,6 +1467,8 @@ extern "C" int splash_mod_spin_up(double lat, double elv, int n, int y, const do
             HIP_TRY(hipMemcpy(dst[k], hptr[k], 8 * (size_t)n, hipMemcpyDeviceToHost), nullptr, 0);
     if (passes) HIP_TRY(hipMemcpy(passes, dpass.p, sizeof(int), hipMemcpyDeviceToHost), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_mod_spin_up");
 }
 
 // SPLASH::run_all (src/SPLASH.cpp:1833-1916; R call at R/splash.point.R:158-172)
@@ -1400,7 +1480,7 @@ extern "C" int splash_mod_run_all(double lat, double elv, int nt, const int* doy
                                   double* pet, double* aet, double* snow, double* cond,
                                   double* bflow, double* netr, double* qin_prev, double* tdrain,
                                   double* snwage)
-{
+try {
     REQ(nt > 0 && doys && yrs && sw_in && tair && pn && snowfall && soil_info,
         "mod_run_all: bad argument");
     const bool on_host = t_mod_backend == SPLASH_BACKEND_HOST;
@@ -1460,6 +1540,8 @@ extern "C" int splash_mod_run_all(double lat, double elv, int nt, const int* doy
             HIP_TRY(hipMemcpy(dst[k], dser.as<double>() + (size_t)k * nt, 8 * (size_t)nt,
                               hipMemcpyDeviceToHost), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_mod_run_all");
 }
 
 // SPLASH::run_one_year (src/SPLASH.cpp:1751-1830): day i+1 of year y for i < n, starting from the
@@ -1474,7 +1556,7 @@ extern "C" int splash_mod_run_one_year(double lat, double elv, int n, int y, int
                                        double* ro, double* pet, double* aet, double* snow_o,
                                        double* cond, double* bflow, double* netr, double* qin_prev,
                                        double* tdrain, double* snwage)
-{
+try {
     REQ(n > 0 && n_end >= n && wn_vec && snow && qin_vec && td_vec && nds,
         "mod_run_one_year: bad argument");
     std::vector<int> doys(n), yrs(n, y);
@@ -1483,11 +1565,13 @@ extern "C" int splash_mod_run_one_year(double lat, double elv, int n, int y, int
                               wn_vec[n_end - 1], slop, asp, snow[n_end - 1], snowfall, soil_info,
                               qin_vec[n_end - 1], td_vec[n_end - 1], nds[n_end - 1], wn_o, ro, pet,
                               aet, snow_o, cond, bflow, netr, qin_prev, tdrain, snwage);
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_mod_run_one_year");
 }
 
 extern "C" int splash_mod_moist_surf(double depth, double z, double bub_p, double wn, double SAT,
                                      double RES, double lambda, double* theta)
-{
+try {
     REQ(theta, "mod_moist_surf: NULL result");
     if (t_mod_backend == SPLASH_BACKEND_HOST) {
         *theta = host_mod_moist_surf(depth, z, bub_p, wn, SAT, RES, lambda);
@@ -1500,12 +1584,14 @@ extern "C" int splash_mod_moist_surf(double depth, double z, double bub_p, doubl
             nullptr, 0);
     HIP_TRY(hipMemcpy(theta, d.p, 8, hipMemcpyDeviceToHost), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_mod_moist_surf");
 }
 
 extern "C" int splash_mod_inf_GA(double bub_press, double theta_i, double Ksat, double theta_s,
                                  double lambda, double P, double tdur, double slop,
                                  double* infiltration)
-{
+try {
     REQ(infiltration, "mod_inf_GA: NULL result");
     if (t_mod_backend == SPLASH_BACKEND_HOST) {
         *infiltration = host_mod_inf_GA(bub_press, theta_i, Ksat, theta_s, lambda, P, tdur, slop);
@@ -1518,4 +1604,6 @@ extern "C" int splash_mod_inf_GA(double bub_press, double theta_i, double Ksat, 
                           nullptr), nullptr, 0);
     HIP_TRY(hipMemcpy(infiltration, d.p, 8, hipMemcpyDeviceToHost), nullptr, 0);
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_mod_inf_GA");
 }

@@ -19,6 +19,8 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <new>
+#include <stdexcept>
 #include <thread>
 
 using namespace splash;
@@ -89,9 +91,9 @@ static void prefault_outputs(const Knobs& kn, void* const* bufs, const int* esz,
         work(0);
         return;
     }
-    std::vector<std::thread> pool;
-    for (unsigned w = 0; w < nthr; w++) pool.emplace_back(work, w);
-    for (auto& t : pool) t.join();
+    Threads pool;
+    for (unsigned w = 0; w < nthr; w++) pool.add(work, w);
+    pool.join();
 }
 
 // ------------------------------------------------------------------ splash.grid / splash.point
@@ -161,12 +163,12 @@ void parallel_rows(size_t n, size_t bytes_per_row, F fn)
         for (size_t i = 0; i < n; i++) fn(i);
         return;
     }
-    std::vector<std::thread> pool;
+    Threads pool;
     for (unsigned w = 0; w < nthr; w++)
-        pool.emplace_back([=]() {
+        pool.add([=]() {
             for (size_t i = w; i < n; i += nthr) fn(i);
         });
-    for (auto& t : pool) t.join();
+    pool.join();
 }
 
 struct Stream {
@@ -324,19 +326,24 @@ int Worker::run_lane(int li)
     if (hipSetDevice(device) != hipSuccess) {
         lane_fail(L, SPLASH_ENODEV, "hipSetDevice", hipErrorInvalidDevice);
     } else {
-        const size_t nblk = nblocks();
-        for (;;) {
-            size_t k;
-            {   // the next block, once nobody else is loading: host->device copies of two lanes at once
-                // only share the link (measured: 52 GB/s for one or for two), and lanes that load in
-                // lockstep compute in lockstep -- one at a time, copies and kernels interleave
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !loading || abort; });
-                if (abort || next_block >= nblk) break;
-                k = next_block++;
-                loading = true;
+        try { // (a throw on a lane's thread would be terminate(): it becomes the lane's error instead)
+            const size_t nblk = nblocks();
+            if (P.kn.test_throw == 2) throw std::runtime_error("injected on a lane's thread");
+            for (;;) {
+                size_t k;
+                {   // the next block, once nobody else is loading: host->device copies of two lanes at once
+                    // only share the link (measured: 52 GB/s for one or for two), and lanes that load in
+                    // lockstep compute in lockstep -- one at a time, copies and kernels interleave
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !loading || abort; });
+                    if (abort || next_block >= nblk) break;
+                    k = next_block++;
+                    loading = true;
+                }
+                if (run_block(L, k)) break;
             }
-            if (run_block(L, k)) break;
+        } catch (...) {
+            lane_fail(L, exception_code(nullptr, 0, "a lane's host side"), "lane", hipSuccess);
         }
         if (L.d2h.joinable()) L.d2h.join();
         if (L.d2h_rc && !L.rc) {
@@ -575,7 +582,11 @@ int Worker::run_block(Lane& L, size_t k)
         L.d2h = std::thread([this, &L, b0, nb, dout] {
             KnobScope knobs_of_the_call(P.kn);
             (void)hipSetDevice(device);
-            L.d2h_rc = deliver(L, b0, nb, dout);
+            try {
+                L.d2h_rc = deliver(L, b0, nb, dout);
+            } catch (...) {
+                L.d2h_rc = exception_code(nullptr, 0, "delivery of a block's results");
+            }
         });
     }
     const double t_e = now_s();
@@ -947,10 +958,10 @@ int grid_worker(const GridPlan& P, int device, int share, const size_t* cells, s
         fprintf(stderr, "[splash] device %d: %zu cells in %zu blocks of <= %zu on %zu lanes, pool of %zu slots; calendar + "
                         "allocations %.3f s\n", device, want, W.nblocks(), W.nb_max, W.lanes.size(), W.pool.cap, now_s() - t_w0);
 
-    std::vector<std::thread> threads;
-    for (size_t l = 0; l < W.lanes.size(); l++) threads.emplace_back([&W, l] { W.run_lane((int)l); });
+    Threads threads; // (lanes take blocks off a shared counter: should one fail to start, the others finish the list)
+    for (size_t l = 0; l < W.lanes.size(); l++) threads.add([&W, l] { W.run_lane((int)l); });
     const int rc_pool = W.finish_pool(err, errlen); // waits for the lanes' last gathers, then runs the tail
-    for (auto& t : threads) t.join();
+    threads.join();
     for (Lane& L : W.lanes)
         if (L.rc) return fail(L.rc, err, errlen, "%s", L.msg);
     if (rc_pool) return rc_pool;
@@ -984,7 +995,7 @@ static int grid_on_host(const GridPlan& P, char* err, size_t errlen)
         KnobScope knobs_of_the_call(P.kn);
         for (;;) {
             const size_t j = next.fetch_add(1);
-            if (j >= P.nv || rc_all.load() != SPLASH_OK) return;
+            if (j >= P.nv || rc_all.load() != SPLASH_OK) return; // (host_cell_run reports ENOMEM itself: no throw here)
             const size_t c = P.idx[j];
             HostCellIn ci{};
             ci.nt = P.nt;
@@ -1051,9 +1062,9 @@ static int grid_on_host(const GridPlan& P, char* err, size_t errlen)
     if (nthr <= 1) {
         work();
     } else {
-        std::vector<std::thread> pool;
-        for (unsigned w = 0; w < nthr; w++) pool.emplace_back(work);
-        for (auto& t : pool) t.join();
+        Threads pool;
+        for (unsigned w = 0; w < nthr; w++) pool.add(work);
+        pool.join();
     }
     if (rc_all.load() != SPLASH_OK) return fail(rc_all.load(), err, errlen, "grid_run (host backend): a cell failed");
     if (P.want_diag) {
@@ -1066,8 +1077,8 @@ static int grid_on_host(const GridPlan& P, char* err, size_t errlen)
 // the call itself, on whatever thread runs it (the caller's, or the job thread of splash_grid_submit:
 // the environment knobs were sampled by the entry point, on the caller's thread)
 static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const splash_grid_out* out, char* err,
-                         size_t errlen, const Knobs& kn_call)
-{
+                         size_t errlen, const Knobs& kn_call) noexcept
+try {
     KnobScope knobs_of_the_call(kn_call); // (the job thread of splash_grid_submit: no getenv, the submitter's knobs)
     if (!in || !out) return fail(SPLASH_EINVAL, err, errlen, "grid_run: NULL in/out");
     const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -1171,9 +1182,10 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
         nthr = nthr == 0 ? 4 : (nthr > 8 ? 8 : nthr);
         if (N < ((size_t)1 << 20)) nthr = 1;
         std::vector<std::vector<size_t>> part(nthr);
+        for (unsigned w = 0; w < nthr; w++) // (here, not on the helpers' threads: an allocation may throw)
+            part[w].reserve(N * (w + 1) / nthr - N * w / nthr);
         auto scan = [&](unsigned w) {
             const size_t a0 = N * w / nthr, a1 = N * (w + 1) / nthr;
-            part[w].reserve(a1 - a0);
             for (size_t c = a0; c < a1; c++)
                 if (!is_bad(c)) part[w].push_back(c);
         };
@@ -1181,9 +1193,9 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
             scan(0);
             idx.swap(part[0]);
         } else {
-            std::vector<std::thread> pool;
-            for (unsigned w = 0; w < nthr; w++) pool.emplace_back(scan, w);
-            for (auto& t : pool) t.join();
+            Threads pool;
+            for (unsigned w = 0; w < nthr; w++) pool.add(scan, w);
+            pool.join();
             size_t total = 0;
             for (auto& v : part) total += v.size();
             idx.reserve(total);
@@ -1204,6 +1216,7 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
     if (out->diag) std::fill(out->diag, out->diag + n_rec * SPLASH_NDIAG, 0.0);
     if (out->diag_acc) std::fill(out->diag_acc, out->diag_acc + n_rec * SPLASH_DIAG_REC, (int64_t)0);
     if (P.nv == 0) return SPLASH_OK;
+    if (P.kn.test_throw == 1) throw std::bad_alloc(); // fault injection for tests/: no exception leaves the C ABI
     if (on_host) return grid_on_host(P, err, errlen);
 
     const double t_scan = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -1230,15 +1243,21 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
     std::vector<std::vector<int64_t>> acc(nw);
     std::vector<int> rcs(nw, 0);
     std::vector<std::string> msgs(nw);
+    for (auto& m : msgs) m.reserve(512); // (so that a worker's thread need not allocate to report)
     auto run = [&](int w) {
         KnobScope knobs_of_the_call(P.kn);
-        int share = 0;
-        for (int d : devs) share += (d == devs[w]);
-        if (P.want_diag) acc[w].assign(n_rec * SPLASH_DIAG_REC, 0);
         char buf[512] = "";
-        rcs[w] = nw > 1 ? grid_worker(P, devs[w], share, wcells[w].data(), wcells[w].size(), acc[w].data(), buf, sizeof buf)
-                        : grid_worker(P, devs[w], share, P.idx, P.nv, acc[w].data(), buf, sizeof buf);
-        msgs[w] = buf;
+        try {
+            int share = 0;
+            for (int d : devs) share += (d == devs[w]);
+            if (P.kn.test_throw == 3) throw std::runtime_error("injected on a worker's thread");
+            if (P.want_diag) acc[w].assign(n_rec * SPLASH_DIAG_REC, 0);
+            rcs[w] = nw > 1 ? grid_worker(P, devs[w], share, wcells[w].data(), wcells[w].size(), acc[w].data(), buf, sizeof buf)
+                            : grid_worker(P, devs[w], share, P.idx, P.nv, acc[w].data(), buf, sizeof buf);
+        } catch (...) { // (on a worker's own thread a throw would be terminate())
+            rcs[w] = exception_code(buf, sizeof buf, "a device's worker");
+        }
+        msgs[w].assign(buf);
     };
     // Large result arrays (daily outputs: tens of GB) are page-locked while the first blocks load and
     // compute: device->host copies into registered memory run beside the host->device copies of the
@@ -1271,6 +1290,7 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
             void* fptr[3] = {f64 ? (void*)in->sw_in : (void*)in->sw_in_f32, f64 ? (void*)in->tc : (void*)in->tc_f32,
                              f64 ? (void*)in->pn : (void*)in->pn_f32};
             const GridPlan* plan = &P;
+            reg.done.reserve(3 + SPLASH_NOUT); // (the helper thread never allocates)
             reg.th = std::thread([&reg, plan, elems_each, dev0, fbytes, fptr] {
                 (void)hipSetDevice(dev0);
                 auto lock = [&](void* p, size_t n) {
@@ -1288,9 +1308,9 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
     if (nw == 1) {
         run(0);
     } else {
-        std::vector<std::thread> pool;
-        for (int w = 0; w < nw; w++) pool.emplace_back(run, w);
-        for (auto& t : pool) t.join();
+        Threads pool;
+        for (int w = 0; w < nw; w++) pool.add(run, w);
+        pool.join();
     }
     for (int w = 0; w < nw; w++)
         if (rcs[w]) return fail(rcs[w], err, errlen, "device %d: %s", devs[w], msgs[w].c_str());
@@ -1307,13 +1327,17 @@ static int grid_run_impl(const splash_grid_in* in, const splash_opts* opt, const
                 t_end - t_scan, t_end - t_enter);
     }
     return SPLASH_OK;
+} catch (...) { // (this is also the body of splash_grid_submit's job thread)
+    return exception_code(err, errlen, "grid_run");
 }
 
 extern "C" int splash_grid_run(const splash_grid_in* in, const splash_opts* opt,
                                const splash_grid_out* out, char* err, size_t errlen)
-{
+try {
     knobs_refresh();
     return grid_run_impl(in, opt, out, err, errlen, knobs());
+} catch (...) {
+    return exception_code(err, errlen, "splash_grid_run");
 }
 
 struct splash_grid_job {
@@ -1330,14 +1354,14 @@ struct splash_grid_job {
 
 extern "C" int splash_grid_submit(const splash_grid_in* in, const splash_opts* opt, const splash_grid_out* out,
                                   splash_grid_job** job, char* err, size_t errlen)
-{
+try {
     if (!in || !out || !job) return fail(SPLASH_EINVAL, err, errlen, "grid_submit: NULL in/out/job");
     if (opt && opt->backend == SPLASH_BACKEND_HOST) {
         knobs_refresh(); // (the host backend touches no device: nothing to refuse at submit time)
     } else if (int rc = enter_device(err, errlen)) {
         return rc;
     }
-    auto* j = new splash_grid_job;
+    std::unique_ptr<splash_grid_job> j(new splash_grid_job);
     j->in = *in;
     j->out = *out;
     if (opt) {
@@ -1348,24 +1372,25 @@ extern "C" int splash_grid_submit(const splash_grid_in* in, const splash_opts* o
             j->opt.devices = j->devices.data();
         }
     }
-    try {
-        j->kn = knobs();
-        j->th = std::thread([j] { j->rc = grid_run_impl(&j->in, j->has_opt ? &j->opt : nullptr, &j->out, j->msg, sizeof j->msg, j->kn); });
-    } catch (...) {
-        delete j;
-        return fail(SPLASH_ENOMEM, err, errlen, "grid_submit: could not start a host thread");
-    }
-    *job = j;
+    j->kn = knobs();
+    splash_grid_job* jp = j.get();
+    // (the job thread: grid_run_impl catches what its body throws, so nothing is thrown on this thread)
+    j->th = std::thread([jp] { jp->rc = grid_run_impl(&jp->in, jp->has_opt ? &jp->opt : nullptr, &jp->out, jp->msg, sizeof jp->msg, jp->kn); });
+    *job = j.release();
     return SPLASH_OK;
+} catch (...) {
+    return exception_code(err, errlen, "splash_grid_submit");
 }
 
 extern "C" int splash_grid_wait(splash_grid_job* job, char* err, size_t errlen)
-{
+try {
     if (!job) return fail(SPLASH_EINVAL, err, errlen, "grid_wait: NULL job");
     if (job->th.joinable()) job->th.join();
     const int rc = job->rc;
     if (rc) (void)fail(rc, err, errlen, "%s", job->msg);
     delete job;
     return rc;
+} catch (...) {
+    return exception_code(err, errlen, "splash_grid_wait");
 }
 

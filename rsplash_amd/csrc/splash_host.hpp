@@ -12,8 +12,12 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <exception>
 #include <mutex>
+#include <new>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "splash_kernels.hpp"
@@ -49,6 +53,8 @@ struct Knobs {
     size_t prefault_min_bytes = (size_t)64 << 20; // SPLASH_HIP_PREFAULT_MIN_BYTES
     size_t prefault_delay_ms = 0;      // SPLASH_HIP_PREFAULT_DELAY_MS (test aid)
     bool test_prefault_whole_range = false; // SPLASH_HIP_TEST_PREFAULT_WHOLE_RANGE (fault injection, tests only)
+    int test_throw = 0;                // SPLASH_HIP_TEST_THROW (fault injection, tests only): 1 = std::bad_alloc in the body of
+                                       // grid_run, 2 = std::runtime_error on a lane's thread, 3 = on a device worker's thread
     bool trace = false;                // SPLASH_TRACE
     int lanes = 0;                     // SPLASH_HIP_LANES (0: chosen by the call)
     bool fake_device = false;          // SPLASH_HIP_FAKE_DEVICE_BYTES given
@@ -165,6 +171,46 @@ double host_mod_inf_GA(double bub_press, double theta_i, double Ksat, double the
                        double slop);
 void host_mod_run_all(const double* par, int nt, const DayRec* days, const double* sw, const double* tc, const double* pn,
                       const double* snowfall, const double* st0, double* const dst[11]);
+
+// No C++ exception leaves the C ABI: the callers are C (R's .Call shim, cgo, ctypes), where an exception in flight
+// is a terminate() without a message.  Every public entry point that allocates host memory or starts threads runs
+// its body under c_guard(); thread bodies that do more than copy run under their own (a throw on a std::thread is
+// terminate() as well) and hand the code to their owner.
+int exception_code(char* err, size_t errlen, const char* where) noexcept; // call inside a catch (...) block
+template <class F>
+int c_guard(char* err, size_t errlen, const char* where, F&& body) noexcept
+{
+    try {
+        return body();
+    } catch (...) {
+        return exception_code(err, errlen, where);
+    }
+}
+
+// Host threads that are ALWAYS joined.  A std::thread that is destroyed while joinable terminates the process, and
+// that is what a plain vector of them does when starting the k-th thread throws (EAGAIN: the container's thread
+// limit): here the threads already running finish their share, the destructor joins them, and the exception travels
+// on to the entry point's c_guard().
+class Threads {
+    std::vector<std::thread> pool_;
+
+public:
+    Threads() = default;
+    Threads(const Threads&) = delete;
+    Threads& operator=(const Threads&) = delete;
+    ~Threads() { join(); }
+    template <class F, class... A>
+    void add(F&& fn, A&&... args)
+    {
+        pool_.emplace_back(std::forward<F>(fn), std::forward<A>(args)...);
+    }
+    void join() noexcept
+    {
+        for (auto& t : pool_)
+            if (t.joinable()) t.join();
+        pool_.clear();
+    }
+};
 
 } // namespace host
 } // namespace splash

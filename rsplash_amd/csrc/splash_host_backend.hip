@@ -20,7 +20,8 @@
 
 #include <cmath>
 #include <limits>
-#include <vector>
+#include <memory>
+#include <new>
 
 #include "splash_device.hpp"
 
@@ -136,7 +137,8 @@ __attribute__((always_inline)) inline int cell_impl(const HostCellIn& in, HostCe
     } else {
         // K4: the year's records once -- doy 1..365 of the first year with the months of the records' real dates
         // (splash_calendar: spin_days) --, then both spin-ups on them
-        YearRecords* Y = new YearRecords;
+        std::unique_ptr<YearRecords> Y(new (std::nothrow) YearRecords); // 60 KB: not on a helper thread's stack
+        if (!Y) return SPLASH_ENOMEM;
         cell_setup(c, par, 1, 0, par[P_CELLOUT]);
         for (int i = 0; i < 365; i++) {
             const DayRec& d = in.spin_days[i];
@@ -152,7 +154,6 @@ __attribute__((always_inline)) inline int cell_impl(const HostCellIn& in, HostCe
         out.ai = ai;
         cell_setup(c, par, 1, 0, ai); // soil_info[12] <- AI: ncellout (R/splash.point.R:150; the day terms do not depend on it)
         st = spin_once(c, *Y, false, true, nullptr, &out.passes2);
-        delete Y;
     }
     par[P_CELLOUT] = out.ai;
 
@@ -161,8 +162,6 @@ __attribute__((always_inline)) inline int cell_impl(const HostCellIn& in, HostCe
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double dg[4] = {0, 0, 0, 0};
     const bool in_basin = out.diag_rec != nullptr;
-    long long skipped_dummy = 0;
-    (void)skipped_dummy;
     for (int t = 0; t < nt; t++) {
         const DayRec& d = in.days[t];
         const DayConst dc{d.dr, d.sd, d.cd, d.ttm_s, d.inv_trm14};

@@ -401,6 +401,33 @@ def test_host_path_out_of_memory_is_an_error_not_a_hang(api, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("where,devices", [(2, None), (3, [0, 0]), (1, None)])
+def test_a_cpp_exception_on_any_thread_of_a_call_becomes_its_error(api, oracle, monkeypatch, where, devices):
+    """No C++ exception leaves the C ABI, and none ends the process from a helper thread: thrown
+    (SPLASH_HIP_TEST_THROW, fault injection) in the body of grid_run (1), on a lane's thread (2: the other lanes
+    drain the block list, the straggler pool's wait ends) or on a device worker's thread (3), the call returns an
+    error code and a message -- from the blocking call and from submit/wait -- and the next call works."""
+    from rsplash_amd._lib import SplashError
+    H, W, nt = 8, 64, 365
+    g_ = _synth(oracle, H, W, nt, 1, seed=4242)
+    st = g_["st"]
+    args = (g_["sw"], g_["tc"], g_["pn"], st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"], st["resolution"])
+    kw = dict(time_index=g_["dates"], devices=devices)
+    ref = api.splash_grid(*args, **kw)
+    monkeypatch.setenv("SPLASH_HIP_TEST_THROW", str(where))
+    pat = "out of host memory" if where == 1 else "injected on a"
+    with pytest.raises(SplashError, match=pat):
+        api.splash_grid(*args, **kw)
+    job = api.splash_grid(*args, submit=True, **kw)
+    with pytest.raises(SplashError, match=pat):
+        job.wait()
+    monkeypatch.delenv("SPLASH_HIP_TEST_THROW")
+    g = api.splash_grid(*args, **kw)
+    for k in ("wn", "ro", "snow"):
+        assert np.array_equal(g[k], ref[k], equal_nan=True), k
+
+
+@pytest.mark.gpu
 def test_prefault_touches_only_its_own_columns(api, oracle):
     """Regression test for the race fixed by inspection in ff89765 (round 3).  While a block's kernels
     run, its lane maps the caller's result pages.  The first version did that ONCE, from the first lane

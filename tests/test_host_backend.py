@@ -152,6 +152,34 @@ def test_splash_grid_on_the_host_with_na_cells_monthly_and_totals(api, oracle):
                 assert (g["diag_cells"][b_] == cells.sum()).all()
 
 
+@pytest.mark.parametrize("submit", [False, True])
+def test_no_cpp_exception_leaves_the_c_abi(api, oracle, monkeypatch, submit):
+    """The callers of include/splash_hip.h are C (R's .Call shim, ctypes, cgo): a C++ exception in flight there is
+    terminate() without a message.  Every entry point that allocates or starts threads runs under a function-try-
+    block (splash_host.hpp: exception_code); SPLASH_HIP_TEST_THROW=1 throws std::bad_alloc in the body of grid_run
+    -- on the caller's thread, and on the job thread of splash_grid_submit -- and the call must come back with
+    SPLASH_ENOMEM and a message, the process alive and the next call fine."""
+    from rsplash_amd._lib import SplashError
+    H, W, nt = 1, 4, 365
+    n = H * W
+    doy, year, month, mid, nm = oracle.calendar(2003, nt)
+    st = oracle.synth_statics(5, H, W, 0, n, 1)
+    sw, tc, pn = oracle.synth_forcing(5, H, W, 0, n, 0, doy, st["lat"], st["elev"])
+    dates = np.datetime64("2003-01-01") + np.arange(nt)
+
+    def call():
+        r = api.splash_grid(sw, tc, pn, st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"],
+                            st["resolution"], time_index=dates, backend="host", submit=submit)
+        return r.wait() if submit else r
+
+    monkeypatch.setenv("SPLASH_HIP_TEST_THROW", "1")
+    with pytest.raises(SplashError, match=r"\(-3\).*out of host memory"):
+        call()
+    monkeypatch.delenv("SPLASH_HIP_TEST_THROW")
+    g = call()
+    assert np.isfinite(g["wn"]).all()
+
+
 def test_host_backend_is_explicit_and_unknown_backends_are_refused(api, bourne):
     import ctypes as C
     from rsplash_amd import _lib
