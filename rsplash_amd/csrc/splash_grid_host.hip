@@ -670,7 +670,7 @@ int Worker::late_fallback(Lane& L, size_t b0, size_t nb, const splash_dev_out& d
     // the buffer the sizing reserved for this (late_slots(); allocated on first use, kept by the lane)
     const size_t late_cap = std::min<size_t>(n_late, late_slots(nb_max));
     LANE_TRY(L.d_late.reserve((size_t)nt_out * std::max(n_out, 1) * late_slots(nb_max) * 8));
-    std::vector<double> patch((size_t)nt_out * late_cap);
+    std::vector<double> late_vals((size_t)nt_out * late_cap); // (not the worker's `patch`: that one belongs to the pool)
     for (size_t k0 = 0; k0 < n_late; k0 += late_cap) {
         const size_t nl = std::min(late_cap, (size_t)n_late - k0);
         splash_dev_out dl = dout;
@@ -684,11 +684,11 @@ int Worker::late_fallback(Lane& L, size_t b0, size_t nb, const splash_dev_out& d
         LANE_TRY(hipStreamSynchronize(s));
         for (int k = 0; k < SPLASH_NOUT; k++) {
             if (!P.dst[k]) continue;
-            LANE_TRY(hipMemcpy2D(patch.data(), nl * 8, dl.out[k], late_cap * 8, nl * 8, (size_t)nt_out,
+            LANE_TRY(hipMemcpy2D(late_vals.data(), nl * 8, dl.out[k], late_cap * 8, nl * 8, (size_t)nt_out,
                                  hipMemcpyDeviceToHost));
             for (int t = 0; t < nt_out; t++)
                 for (size_t j = 0; j < nl; j++)
-                    put_value(P, k, (size_t)t * N + idx[late[k0 + j]], patch[(size_t)t * nl + j]);
+                    put_value(P, k, (size_t)t * N + idx[late[k0 + j]], late_vals[(size_t)t * nl + j]);
         }
     }
     // state, threshold, aridity index and pass counts of the late cells
