@@ -36,3 +36,32 @@ def test_readme_example_on_the_gpu_follows_the_observed_snowpack_and_soil_water(
     assert abs(swe["r"] - host["swe"]["r"]) < 1e-6 and abs(swe["nse"] - host["swe"]["nse"]) < 1e-6
     # soil water of the top 0.49 m against the sensors: the seasonal cycle is there (the README's second plot)
     assert swc["n"] > 2000 and swc["r"] > 0.8 and swc["nse"] > 0.4 and abs(swc["bias"]) < 20.0, swc   # measured: 0.866, 0.60, -5.1 mm
+
+
+def _check_atneu(res):
+    a, am, p_, n = res["aet daily"], res["aet monthly"], res["pet daily"], res["netr daily"]
+    assert a["n"] > 3000 and a["r"] > 0.9 and a["nse"] > 0.7 and abs(a["bias"]) < 0.6, a        # measured 0.939, 0.82, -0.30 mm/d
+    assert am["r"] > 0.95 and am["nse"] > 0.75, am                                              # 0.974, 0.86
+    assert p_["r"] > 0.9 and n["r"] > 0.9, (p_, n)                                              # 0.953, 0.945
+    assert res["sm_lim vs sensor"]["r"] > 0.4                                                   # 0.575 (relative saturation vs a shallow sensor)
+
+
+def test_fluxnet_site_on_the_host_backend_follows_the_measured_evapotranspiration():
+    """the reference's second bundled site (data/ATNeu_example.RData) ships the tower's measurements beside the
+    forcing: eleven years of eddy-covariance evapotranspiration and net radiation (examples/atneu_fluxnet.py)"""
+    import rsplash_amd
+    rsplash_amd.build_library()
+    import atneu_fluxnet
+    res, _ = atneu_fluxnet.run("host")
+    print(res)
+    _check_atneu(res)
+
+
+@pytest.mark.gpu
+def test_fluxnet_site_on_the_gpu_follows_the_measured_evapotranspiration(api):
+    import atneu_fluxnet
+    res, _ = atneu_fluxnet.run("hip")
+    host, _ = atneu_fluxnet.run("host")
+    _check_atneu(res)
+    for k in res:
+        assert abs(res[k]["r"] - host[k]["r"]) < 1e-6, k

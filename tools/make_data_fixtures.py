@@ -2,6 +2,7 @@
 
   data/ATNeu_example.RData -> tests/golden/atneu_forcing.csv (date,tc,sw_in,pn; 4018 daily rows,
                               2002-01-01..2012-12-31) + tests/golden/atneu_site.json (soil vector)
+                              + tests/golden/atneu_obs.csv (the measured aet, pet, netr, sm, snowmelt columns)
   data/SA_cru.RData        -> tests/golden/sa_cru_statics.npz: elev [139*159] and soil [6][139*159]
                               (sand, clay, SOM, fgravel, bdens, depth2br) of the 0.5 degree South
                               America grid, 72 % NA (ocean), stored as float32 (the rasters are FLT4S)
@@ -35,6 +36,14 @@ with open(os.path.join(G, "atneu_forcing.csv"), "w") as fh:
     fh.write("date,tc,sw_in,pn\n")
     for dt, row in zip(dates, mat):
         fh.write(dt.isoformat() + "," + ",".join(repr(float(row[i])) for i in ix) + "\n")
+# the measurements that come with the forcing (FLUXNET AT-Neu: evapotranspiration from the eddy-covariance latent heat
+# flux, net radiation, soil moisture of the sensor depth; NA kept as empty fields): examples/readme_bourne.py scores
+# the simulation against them
+ox = [cols.index(k) for k in ("aet", "pet", "netr", "sm", "snowmelt")]
+with open(os.path.join(G, "atneu_obs.csv"), "w") as fh:
+    fh.write("date,aet_obs,pet_obs,netr_obs,sm_obs,snowmelt_obs\n")
+    for dt, row in zip(dates, mat):
+        fh.write(dt.isoformat() + "," + ",".join("" if np.isnan(row[i]) else repr(float(row[i])) for i in ox) + "\n")
 site = {
     "soil": [float(v) for v in A["soil"].value],
     "soil_names": ["sand", "clay", "OM", "fgravel", "bd", "depth"],
