@@ -6,7 +6,7 @@ prints what the plots show (correlation, bias, Nash-Sutcliffe efficiency) -- the
 
     python examples/readme_bourne.py [hip|host]
 
-`host` runs splash.point on a CPU core (ABI 6); unSWC is a device kernel either way and is skipped without a GPU."""
+`host` runs both steps on a CPU core (ABI 6: no GPU touched)."""
 import csv
 import json
 import os
@@ -47,14 +47,13 @@ def run(backend="hip", with_unswc=True):
                             resolution=250.0, time_index=Bourne["dates"], backend=backend)
     out = {"swe": scores(run1["snow"], Bourne["swe"])}                      # README.md:49-50
     if with_unswc:  # README.md:52-59: water content of the measured part of the profile
-        swc = api.unSWC(soil_data=Bourne["soil"], uns_depth=Bourne["max_depth_sm"], wn=run1["wn"])
+        swc = api.unSWC(soil_data=Bourne["soil"], uns_depth=Bourne["max_depth_sm"], wn=run1["wn"], backend=backend)
         out["swc"] = scores(swc["wn_z"], Bourne["sm"])
     return out, run1
 
 
 if __name__ == "__main__":
     backend = sys.argv[1] if len(sys.argv) > 1 else "hip"
-    import torch
-    res, _ = run(backend, with_unswc=torch.cuda.is_available())
+    res, _ = run(backend)
     for k, v in res.items():
         print(f"{k.upper()} sim. against obs. ({v['n']} days): r = {v['r']:.3f}, bias = {v['bias']:+.1f} mm, NSE = {v['nse']:.3f}")

@@ -285,6 +285,10 @@ int splash_dev_unswc(size_t ncell, int nt, const double* wn, size_t ldw, const d
 int splash_unswc_run(size_t ncell, int nt, const double* wn /*[nt][ncell]*/,
                      const double* soil /*[6][ncell]*/, double uns_depth, double* wn_z, double* wtd,
                      double* theta, char* err, size_t errlen);
+/* ABI 6: the same with the backend chosen by the caller (SPLASH_BACKEND_HOST: the kernel's two functions on the
+ * calling thread -- the README example, README.md:52-59, then runs without a GPU; splash_unswc_run == backend HIP) */
+int splash_unswc_run_backend(int backend, size_t ncell, int nt, const double* wn, const double* soil,
+                             double uns_depth, double* wn_z, double* wtd, double* theta, char* err, size_t errlen);
 
 /* test hook: the device build of the FP64 log/exp/pow/acos used by the day step, for n arguments
  * (host pointers): out [7][n] = flog(x), fexp(x), fpow(x,y), facos(x), fsqrt(x), fatan(x), fatan2(x,y) */

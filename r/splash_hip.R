@@ -187,9 +187,10 @@ splash.grid.statics.hip <- function(elev, degree = 1) {
 
 # unSWC (R/unsSWC.R:14): same signature; the analytical integral runs in the HIP library.
 # One site = one "cell": wn is handed over as a [1 x nt] matrix, soil as [1 x 6].
-unSWC <- function(soil_data, uns_depth, wn) {
+unSWC <- function(soil_data, uns_depth, wn, backend = c("hip", "host")) {
+  backend <- match.arg(backend)          # "host" (ABI 6): on a CPU core, as splash.point(..., backend = "host")
   res <- .Call("C_splash_unswc_run", matrix(as.numeric(wn), nrow = 1),
-               matrix(as.numeric(soil_data), nrow = 1), as.numeric(uns_depth))
+               matrix(as.numeric(soil_data), nrow = 1), as.numeric(uns_depth), if (backend == "host") 1L else 0L)
   result <- list(wn_z = res$wn_z[1, ], wtd = res$wtd[1, ])
   if (xts::is.xts(wn)) result <- mapply(FUN = xts::xts, result, MoreArgs = list(order.by = time(wn)), SIMPLIFY = FALSE)
   result$theta_i <- if (xts::is.xts(wn)) xts::xts(res$theta_i[1, ], time(wn)) else res$theta_i[1, ]

@@ -259,8 +259,9 @@ SEXP C_splash_point_run(SEXP sw_in, SEXP tc, SEXP pn, SEXP lat, SEXP elev, SEXP 
 }
 
 /* unSWC / unSWC.grid (R/unsSWC.R:14, R/unsSWC.grid.R:14): wn [ncell x nt] matrix (one column per
- * time step as getValues() gives it; one site = [1 x nt]), soil [ncell x 6], uns_depth numeric(1) */
-SEXP C_splash_unswc_run(SEXP wn, SEXP soil, SEXP uns_depth)
+ * time step as getValues() gives it; one site = [1 x nt]), soil [ncell x 6], uns_depth numeric(1),
+ * backend integer(1): SPLASH_BACKEND_HIP (0) or SPLASH_BACKEND_HOST (1, ABI 6: no GPU touched) */
+SEXP C_splash_unswc_run(SEXP wn, SEXP soil, SEXP uns_depth, SEXP backend)
 {
     SEXP dim = getAttrib(wn, R_DimSymbol);
     if (isNull(dim) || LENGTH(dim) != 2) error("wn must be a [ncell x nt] matrix");
@@ -278,8 +279,8 @@ SEXP C_splash_unswc_run(SEXP wn, SEXP soil, SEXP uns_depth)
         UNPROTECT(1);
     }
     char err[512];
-    int rc = splash_unswc_run(ncell, nt, REAL(wn), REAL(soil), asReal(uns_depth), o[0], o[1], o[2],
-                              err, sizeof err);
+    int rc = splash_unswc_run_backend(asInteger(backend), ncell, nt, REAL(wn), REAL(soil), asReal(uns_depth), o[0], o[1],
+                                      o[2], err, sizeof err);
     UNPROTECT(1);
     if (rc != SPLASH_OK) error("splash_unswc_run failed (%d): %s", rc, err);
     return res;
@@ -323,7 +324,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"C_splash_grid_chunk", (DL_FUNC)&C_splash_grid_chunk, 14},
     {"C_splash_snow_threshold", (DL_FUNC)&C_splash_snow_threshold, 3},
     {"C_splash_point_run", (DL_FUNC)&C_splash_point_run, 15},
-    {"C_splash_unswc_run", (DL_FUNC)&C_splash_unswc_run, 3},
+    {"C_splash_unswc_run", (DL_FUNC)&C_splash_unswc_run, 4},
     {"C_splash_static_rasters", (DL_FUNC)&C_splash_static_rasters, 5},
     {NULL, NULL, 0}};
 

@@ -340,17 +340,17 @@ def _grid_results(res, shp, lat, lon, outdir, time_index, monthly, want_state, s
 
 
 # ---------------------------------------------------------------------------- unSWC
-def unSWC(soil_data, uns_depth, wn):
+def unSWC(soil_data, uns_depth, wn, backend="hip"):
     """R/unsSWC.R:14.  soil_data = c(sand, clay, OM, gravel, bulk density, depth); wn: series of
     column water content [mm].  Returns dict(wn_z, wtd, theta_i) like the reference's list
-    (its first element is the water to uns_depth, :85-86)."""
+    (its first element is the water to uns_depth, :85-86).  backend="host" (ABI 6): on the calling thread, no GPU."""
     soil = np.asarray(soil_data, dtype=np.float64).reshape(6, 1)
     w = np.ascontiguousarray(np.asarray(wn, dtype=np.float64).reshape(-1, 1))
-    r = unSWC_grid(soil, uns_depth, w)
+    r = unSWC_grid(soil, uns_depth, w, backend=backend)
     return {k: v[:, 0] for k, v in r.items()}
 
 
-def unSWC_grid(soil, uns_depth, wn):
+def unSWC_grid(soil, uns_depth, wn, backend="hip"):
     """R/unsSWC.grid.R:14 on arrays: soil [6, ncell], wn [nt, ncell] -> dict of [nt, ncell]."""
     w, wp = _d(wn)
     nt, ncell = w.shape
@@ -359,9 +359,9 @@ def unSWC_grid(soil, uns_depth, wn):
         raise ValueError("soil must be [6, ncell]")
     out = {k: np.empty((nt, ncell)) for k in ("wn_z", "wtd", "theta_i")}
     err = C.create_string_buffer(512)
-    rc = lib.splash_unswc_run(ncell, nt, wp, sp, float(uns_depth),
-                              *[out[k].ctypes.data_as(_dp) for k in ("wn_z", "wtd", "theta_i")],
-                              err, 512)
+    rc = lib.splash_unswc_run_backend(_lib.backend_code(backend), ncell, nt, wp, sp, float(uns_depth),
+                                      *[out[k].ctypes.data_as(_dp) for k in ("wn_z", "wtd", "theta_i")],
+                                      err, 512)
     if rc:
         raise SplashError(f"splash_unswc_run failed ({rc}): {err.value.decode()}")
     return out

@@ -1201,11 +1201,17 @@ try {
 extern "C" int splash_host_backend_fma(void) { return host_backend_fma() ? 1 : 0; }
 
 // unSWC for host buffers: wn [nt][ncell], soil [6][ncell] -> wn_z, wtd, theta [nt][ncell]
-extern "C" int splash_unswc_run(size_t ncell, int nt, const double* wn, const double* soil,
-                                double uns_depth, double* wn_z, double* wtd, double* theta,
-                                char* err, size_t errlen)
+extern "C" int splash_unswc_run_backend(int backend, size_t ncell, int nt, const double* wn, const double* soil,
+                                        double uns_depth, double* wn_z, double* wtd, double* theta,
+                                        char* err, size_t errlen)
 try {
     if (!wn || !soil) return fail(SPLASH_EINVAL, err, errlen, "unswc_run: NULL input");
+    if (backend != SPLASH_BACKEND_HIP && backend != SPLASH_BACKEND_HOST)
+        return fail(SPLASH_EINVAL, err, errlen, "unswc_run: unknown backend %d", backend);
+    if (backend == SPLASH_BACKEND_HOST) { // explicit choice (ABI 6): the same two functions the kernel runs, on this thread
+        if (ncell && nt > 0) host_unswc(ncell, nt, wn, soil, uns_depth, wn_z, wtd, theta);
+        return SPLASH_OK;
+    }
     if (int rc = enter_device(err, errlen)) return rc;
     if (ncell == 0 || nt <= 0) return SPLASH_OK;
     const size_t n = ncell * (size_t)nt;
@@ -1228,6 +1234,12 @@ try {
     return SPLASH_OK;
 } catch (...) {
     return exception_code(err, errlen, "splash_unswc_run");
+}
+
+extern "C" int splash_unswc_run(size_t ncell, int nt, const double* wn, const double* soil, double uns_depth, double* wn_z,
+                                double* wtd, double* theta, char* err, size_t errlen)
+{
+    return splash_unswc_run_backend(SPLASH_BACKEND_HIP, ncell, nt, wn, soil, uns_depth, wn_z, wtd, theta, err, errlen);
 }
 
 // K2 on host buffers (ABI 5): the snowfall threshold of a tc series, for callers that process a long

@@ -7,6 +7,7 @@
 // the other 16.7 M.  This translation unit compiles the SAME device functions (splash_device.hpp: soil_hydro_cell,
 // cell_setup, day_prefetch, day_terms, visc_terms, day_update, rain_snow_split; splash_math.hpp) for the host and
 // drives them the way the kernels do:
+//     (unSWC, the epilogue of the README example, as well: splash_unswc.hpp)
 //     K1 soil_hydro -> K2 snow threshold -> K4 both spin-ups (records of the year formed once, exact-cycle
 //     detection as in k_spin_phase) -> K5 run_all + K6 sm_lim / monthly aggregation + K7 exact monthly totals.
 // It is an EXPLICIT option (splash_opts.backend, splash_point_run_backend, splash_mod_backend), never a fallback:
@@ -24,6 +25,7 @@
 #include <new>
 
 #include "splash_device.hpp"
+#include "splash_unswc.hpp"
 
 namespace splash {
 namespace host {
@@ -284,6 +286,25 @@ __attribute__((always_inline)) inline void mod_run_impl(const double* par, int n
     }
 }
 
+// unSWC (R/unsSWC.R:14-88) on host arrays: wn [nt][ncell], soil [6][ncell] -> wn_z, wtd, theta [nt][ncell] (any NULL)
+__attribute__((always_inline)) inline void unswc_impl(size_t ncell, int nt, const double* wn, const double* soil,
+                                                      double uns_depth, double* wn_z, double* wtd, double* theta)
+{
+    for (size_t i = 0; i < ncell; i++) {
+        UnswcCell u;
+        unswc_setup(soil[i], soil[ncell + i], soil[2 * ncell + i], soil[3 * ncell + i], soil[4 * ncell + i],
+                    soil[5 * ncell + i], uns_depth, u);
+        for (int t = 0; t < nt; t++) {
+            const size_t k = (size_t)t * ncell + i;
+            double a, b, c;
+            unswc_step(u, wn[k], a, b, c);
+            if (wn_z) wn_z[k] = a;
+            if (wtd) wtd[k] = b;
+            if (theta) theta[k] = c;
+        }
+    }
+}
+
 // Two builds of every driver: the generic x86-64 one and one for cores with FMA (every x86 server core since
 // 2013), chosen once at run time.  The Horner chains of splash_math.hpp are fma() calls: without the target
 // attribute each is a call into libm, with it one vfmadd instruction (measured on the Bourne site: see
@@ -316,6 +337,16 @@ SPL_FMA_TARGET void mod_run_fma(const double* par, int nt, const DayRec* days, c
     mod_run_impl(par, nt, days, sw, tc, pn, sf, st0, dst);
 }
 
+void unswc_generic(size_t ncell, int nt, const double* wn, const double* soil, double d, double* a, double* b, double* c)
+{
+    unswc_impl(ncell, nt, wn, soil, d, a, b, c);
+}
+SPL_FMA_TARGET void unswc_fma(size_t ncell, int nt, const double* wn, const double* soil, double d, double* a, double* b,
+                              double* c)
+{
+    unswc_impl(ncell, nt, wn, soil, d, a, b, c);
+}
+
 } // namespace
 
 bool host_backend_fma()
@@ -345,6 +376,13 @@ void host_mod_run_all(const double* par, int nt, const DayRec* days, const doubl
 {
     if (host_backend_fma()) mod_run_fma(par, nt, days, sw, tc, pn, snowfall, st0, dst);
     else mod_run_generic(par, nt, days, sw, tc, pn, snowfall, st0, dst);
+}
+
+void host_unswc(size_t ncell, int nt, const double* wn, const double* soil, double uns_depth, double* wn_z, double* wtd,
+                double* theta)
+{
+    if (host_backend_fma()) unswc_fma(ncell, nt, wn, soil, uns_depth, wn_z, wtd, theta);
+    else unswc_generic(ncell, nt, wn, soil, uns_depth, wn_z, wtd, theta);
 }
 
 double host_mod_moist_surf(double depth, double z, double bub_p, double wn, double SAT, double RES, double lambda)

@@ -167,6 +167,7 @@ static SEXP dot_call(const char* name, int nargs, SEXP* a)
     if (d->numArgs != nargs) { fprintf(stderr, "mock: %s registered with %d arguments, called with %d\n", name, d->numArgs, nargs); exit(5); }
     typedef SEXP (*F1)(SEXP);
     typedef SEXP (*F3)(SEXP, SEXP, SEXP);
+    typedef SEXP (*F4)(SEXP, SEXP, SEXP, SEXP);
     typedef SEXP (*F11)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
     typedef SEXP (*F12)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
     typedef SEXP (*F14)(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
@@ -176,6 +177,7 @@ static SEXP dot_call(const char* name, int nargs, SEXP* a)
     switch (nargs) {
     case 1: r = ((F1)d->fun)(a[0]); break;
     case 3: r = ((F3)d->fun)(a[0], a[1], a[2]); break;
+    case 4: r = ((F4)d->fun)(a[0], a[1], a[2], a[3]); break;
     case 11: r = ((F11)d->fun)(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10]); break;
     case 12: r = ((F12)d->fun)(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11]); break;
     case 14: r = ((F14)d->fun)(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13]); break;
@@ -326,6 +328,15 @@ int main(int argc, char** argv)
     memcpy(c_bad, c2, sizeof c2);
     c_bad[13] = R_NilValue; /* state0 without ai0 */
     bad += expect_error("C_splash_grid_chunk", 14, c_bad, "state0 and ai0 come together");
+    /* 5. unSWC on the host backend (the README example's second step): wn [1 x nt] of step 1, soil [1 x 6], 0.49 m */
+    SEXP wn_m = real_mat(REAL(VECTOR_ELT(r, 0)), 1, nt);
+    SEXP soil_m = real_mat(soil1, 1, 6);
+    SEXP u[4] = {wn_m, soil_m, scalar(REALSXP, 0.49), scalar(INTSXP, 1)};
+    SEXP ru = dot_call("C_splash_unswc_run", 4, u);
+    if (LENGTH(ru) != 3 || strcmp(ru->names[0], "wn_z") || strcmp(ru->names[2], "theta_i")) { fprintf(stderr, "mock: unswc result list\n"); bad++; }
+    for (int k = 0; k < 3; k++) fwrite(REAL(VECTOR_ELT(ru, k)), sizeof(double), (size_t)nt, o);
+    SEXP u_bad[4] = {wn_m, real_mat(soil1, 1, 5), u[2], u[3]};
+    bad += expect_error("C_splash_unswc_run", 4, u_bad, "soil must be [ncell x 6]");
     fclose(o);
     if (g_protect != 0) { fprintf(stderr, "mock: protection stack at %d at exit\n", g_protect); bad++; }
     printf("r_mock: %d problems; deepest protection stack %d\n", bad, g_protect_max);

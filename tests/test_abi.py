@@ -284,3 +284,10 @@ def test_r_shim_runs_against_a_mock_r_api(oracle, bourne, tmp_path):
         assert np.array_equal(gr[i], full[k], equal_nan=True), k
         assert np.array_equal(ch[i], full[k], equal_nan=True), "time chunks: " + k
     assert np.array_equal(se, full["state_end"], equal_nan=True)
+    at += 5 * n
+    un = got[at:at + 3 * nt].reshape(3, nt)                # unSWC of the site's wn to 0.49 m, host backend
+    at += 3 * nt
+    assert at == got.size
+    uref = api.unSWC(soil1, 0.49, ref["wn"], backend="host")
+    for i, k in enumerate(("wn_z", "wtd", "theta_i")):
+        assert np.array_equal(un[i], uref[k], equal_nan=True), k

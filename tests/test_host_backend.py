@@ -180,6 +180,39 @@ def test_no_cpp_exception_leaves_the_c_abi(api, oracle, monkeypatch, submit):
     assert np.isfinite(g["wn"]).all()
 
 
+def test_unswc_on_the_host(api, oracle, bourne):
+    """R/unsSWC.R:14-88 with backend="host" (ABI 6: the kernel's own two functions, splash_unswc.hpp, on the calling
+    thread): the README workflow (README.md:52-59: water to the 0.49 m sensor depth from the simulated column water)
+    and a synthetic grid, against the oracle's unSWC; the same comparison the GPU suite makes
+    (tests/test_gpu_parity.py::test_unswc_bourne_and_grid)."""
+    b, s = bourne, bourne["site"]
+    g = api.splash_point(b["sw_in"], b["Ta"], b["P"], s["latitude"], s["elev_m"], s["slop_250m"], s["asp_250m"], b["soil"],
+                         s["Aups_250m"], s["resolution"], time_index=b["dates"], backend="host")
+    got = api.unSWC(b["soil"], s["max_depth_sm"], g["wn"], backend="host")
+    ref = oracle.unswc(b["soil"], s["max_depth_sm"], g["wn"])
+    for k in ("wn_z", "wtd", "theta_i"):
+        tol = 1e-5 * np.abs(ref[k]) + 1e-9 + 1e-15 * ref["cond"] * np.abs(ref[k])
+        assert (np.abs(got[k] - ref[k]) <= tol).all(), k
+    assert np.all(got["wn_z"] > 0) and np.all(got["wtd"] <= b["soil"][5] + 1e-12)
+    H, W, nt = 6, 32, 120
+    rng = np.random.default_rng(9)
+    st = oracle.synth_statics(20221130, H, W, 0, H * W, 1)
+    soil = st["soil"]
+    sat = np.array([oracle.soil_info(soil[:, j], None, 250.0)[0][[0, 7]] for j in range(H * W)])
+    wn = sat[:, 1] + (sat[:, 0] - sat[:, 1]) * rng.uniform(0, 1, (nt, H * W))
+    wn[0], wn[1] = sat[:, 1], sat[:, 0]
+    got = api.unSWC_grid(soil, 0.3, wn, backend="host")
+    bad = 0
+    for j in range(H * W):
+        ref = oracle.unswc(soil[:, j], 0.3, wn[:, j])
+        for k in ("wn_z", "wtd", "theta_i"):
+            tol = 1e-5 * np.abs(ref[k]) + 1e-9 + 1e-14 * ref["cond"] * np.abs(ref[k])
+            bad += int((np.abs(got[k][:, j] - ref[k]) > tol).sum())
+    assert bad == 0
+    with pytest.raises(ValueError, match="backend"):
+        api.unSWC(b["soil"], 0.49, g["wn"], backend="cpu")
+
+
 def test_host_backend_is_explicit_and_unknown_backends_are_refused(api, bourne):
     import ctypes as C
     from rsplash_amd import _lib

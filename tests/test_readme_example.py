@@ -13,15 +13,16 @@ import pytest
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
 
 
-def test_readme_example_on_the_host_backend_follows_the_observed_snowpack():
+def test_readme_example_on_the_host_backend_follows_the_observed_snowpack_and_soil_water():
     import rsplash_amd
     rsplash_amd.build_library()
     import readme_bourne
-    res, run1 = readme_bourne.run("host", with_unswc=False)
-    swe = res["swe"]
-    print("SWE sim. vs obs.:", swe)
+    res, run1 = readme_bourne.run("host")
+    swe, swc = res["swe"], res["swc"]
+    print("sim. vs obs.:", res)
     assert swe["n"] == 2922
-    assert swe["r"] > 0.95 and swe["nse"] > 0.85 and abs(swe["bias"]) < 30.0, swe
+    assert swe["r"] > 0.95 and swe["nse"] > 0.85 and abs(swe["bias"]) < 30.0, swe              # measured 0.972, 0.914, +14 mm
+    assert swc["n"] > 2000 and swc["r"] > 0.8 and swc["nse"] > 0.4 and abs(swc["bias"]) < 20.0, swc   # 0.866, 0.60, -5.1 mm
     assert set(run1) >= {"wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "sm_lim"}   # R/splash.point.R:182-224
 
 
@@ -29,11 +30,12 @@ def test_readme_example_on_the_host_backend_follows_the_observed_snowpack():
 def test_readme_example_on_the_gpu_follows_the_observed_snowpack_and_soil_water(api):
     import readme_bourne
     res, _ = readme_bourne.run("hip", with_unswc=True)
-    host, _ = readme_bourne.run("host", with_unswc=False)
+    host, _ = readme_bourne.run("host")
     print("GPU:", res, "host:", host)
     swe, swc = res["swe"], res["swc"]
     assert swe["r"] > 0.95 and swe["nse"] > 0.85 and abs(swe["bias"]) < 30.0, swe
     assert abs(swe["r"] - host["swe"]["r"]) < 1e-6 and abs(swe["nse"] - host["swe"]["nse"]) < 1e-6
+    assert abs(swc["r"] - host["swc"]["r"]) < 1e-6 and abs(swc["nse"] - host["swc"]["nse"]) < 1e-6
     # soil water of the top 0.49 m against the sensors: the seasonal cycle is there (the README's second plot)
     assert swc["n"] > 2000 and swc["r"] > 0.8 and swc["nse"] > 0.4 and abs(swc["bias"]) < 20.0, swc   # measured: 0.866, 0.60, -5.1 mm
 
