@@ -290,6 +290,18 @@ int splash_unswc_run(size_t ncell, int nt, const double* wn /*[nt][ncell]*/,
 int splash_unswc_run_backend(int backend, size_t ncell, int nt, const double* wn, const double* soil,
                              double uns_depth, double* wn_z, double* wtd, double* theta, char* err, size_t errlen);
 
+/* unSWC.grid (R/unsSWC.grid.R:14-141): the GRIDDED function has its own semantics -- no stoniness correction (:65, :73),
+ * no patch of a non-positive integral, the integral's water table capped at uns_depth (:115 against :29) while the one
+ * written out is capped at the soil depth (:98-106) -- and its own outputs, the four rasters it writes: w_z = water
+ * between the surface and uns_depth [mm] ("swc_top", :115), wtd [m] (:108), Se = effective saturation of that layer
+ * (:120-126), theta_mean = the column's clamped mean volumetric content (:79-87).  soil [6][ncell]; any output NULL.
+ * splash_unswc_grid_run: host buffers, in column blocks sized to the device; backend as in splash_unswc_run_backend. */
+int splash_dev_unswc_grid(size_t ncell, int nt, const double* wn, size_t ldw, const double* soil, double uns_depth,
+                          double* w_z, double* wtd, double* se, double* theta_mean, size_t ldo, void* stream);
+int splash_unswc_grid_run(int backend, size_t ncell, int nt, const double* wn /*[nt][ncell]*/,
+                          const double* soil /*[6][ncell]*/, double uns_depth, double* w_z, double* wtd, double* se,
+                          double* theta_mean, char* err, size_t errlen);
+
 /* test hook: the device build of the FP64 log/exp/pow/acos used by the day step, for n arguments
  * (host pointers): out [7][n] = flog(x), fexp(x), fpow(x,y), facos(x), fsqrt(x), fatan(x), fatan2(x,y) */
 int splash_dev_math_probe(size_t n, const double* x, const double* y, double* out);

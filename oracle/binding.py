@@ -135,6 +135,8 @@ class Oracle:
                                         C.c_int, _ip, _dp, _dp, _dp, _dp, _dp]
         L.orc_unswc.argtypes = [_dp, C.c_double, C.c_int, _dp, C.c_size_t, _dp, _dp, _dp, _dp,
                                 C.c_size_t]
+        L.orc_unswc_grid.argtypes = [_dp, C.c_double, C.c_int, _dp, C.c_size_t, _dp, _dp, _dp, _dp, _dp,
+                                     C.c_size_t]
         L.orc_calendar.restype = C.c_int
         L.orc_calendar.argtypes = [C.c_int, C.c_int, _ip, _ip, _ip, _ip]
         L.orc_max_threads.restype = C.c_int
@@ -247,6 +249,15 @@ class Oracle:
         nt = len(w)
         o = {k: np.empty(nt) for k in ("wn_z", "wtd", "theta_i", "cond")}
         self.lib.orc_unswc(sdp, float(uns_depth), nt, wp, 1, *[o[k].ctypes.data_as(_dp) for k in o], 1)
+        return o
+
+    def unswc_grid(self, soil_data, uns_depth, wn):
+        """R/unsSWC.grid.R for one cell: dict(w_z, wtd, Se, theta_mean) + 'cond'"""
+        sd, sdp = _d(soil_data)
+        w, wp = _d(wn)
+        nt = len(w)
+        o = {k: np.empty(nt) for k in ("w_z", "wtd", "Se", "theta_mean", "cond")}
+        self.lib.orc_unswc_grid(sdp, float(uns_depth), nt, wp, 1, *[o[k].ctypes.data_as(_dp) for k in o], 1)
         return o
 
     # ---- drivers ---------------------------------------------------------

@@ -1327,6 +1327,65 @@ void orc_unswc(const double* soil_data, double uns_depth, int nt, const double* 
     }
 }
 
+/* R/unsSWC.grid.R:14-141 for one cell of the rasters: NOT unSWC applied cell by cell -- the gridded function leaves the
+ * stoniness correction out (:82-83: `fgravel = soil_data[[4]]*0`, the `(1-soil_data[[4]]/100)` factor commented out),
+ * has no patch for a non-positive integral (R/unsSWC.R:74 has), hands UnsWater the sensor depth as its `depth`
+ * argument (:115: `overlay(psi_m, z_uns, theta_r, theta_s, bub_press, lambda, uns_depth, fun = UnsWater)` against
+ * the signature (psi_m, uns_depth, theta_r, theta_s, bub_press, lambda, depth), :29, with z_uns <- uns_depth, :71), computes
+ * the water table separately against the soil depth (calcwtd, :98-106) and returns the effective saturation of the
+ * layer (calc_Se, :120-125).  Outputs = its four files: theta_mean (:87), wtd (:108), swc_top (:115), Se_top (:126).
+ * cond (optional): |w_uns_0| / |w_uns|, the cancellation factor of the integral. */
+void orc_unswc_grid(const double* soil_data, double uns_depth, int nt, const double* wn, size_t stride,
+                    double* w_z_o, double* wtd_o, double* se_o, double* theta_mean_o, double* cond, size_t ostride)
+{
+    orc_soil si;
+    orc_soil_hydro(soil_data[0], soil_data[1], soil_data[2], soil_data[3] * 0, soil_data[4], &si); /* :65 */
+    double theta_s = si.SAT, theta_r = si.RES;                                                     /* :67-68 */
+    double z_uns_arg = uns_depth;                                                                  /* :69 */
+    double lambda = 1 / si.B;                                                                      /* :70 */
+    double bub_press = si.bubbling_p;                                                              /* :71 */
+    double totdepth = soil_data[5];
+    for (int t = 0; t < nt; t++) {
+        double w = wn[(size_t)t * stride];
+        /* calc_thetai, :79-86 */
+        double theta_o = (w / (totdepth * 1000));
+        double theta_i = (theta_o >= theta_s) ? theta_s - 0.0001 : ((theta_o <= theta_r) ? theta_r + 0.0001 : theta_o);
+        if (isnan(theta_o) || isnan(theta_s) || isnan(theta_r)) theta_i = NAN; /* ifelse(NA, ...) is NA */
+        /* :92 */
+        double psi_m = bub_press / pow((((theta_i - theta_r) / (theta_s - theta_r))), (1 / lambda));
+        /* calcwtd, :98-106 */
+        double wtdini = (bub_press - psi_m) / 1000;
+        double wtd = (wtdini > totdepth) ? totdepth : ((wtdini < 0) ? 0 : wtdini);
+        if (isnan(wtdini)) wtd = NAN;
+        /* UnsWater(psi_m, uns_depth = z_uns_arg, theta_r, theta_s, bub_press, lambda, depth = uns_depth), :29-63 */
+        double depth = uns_depth, ud = z_uns_arg;
+        double wtdini2 = (bub_press - psi_m) / 1000;
+        double wtd2 = (wtdini2 > depth) ? depth : ((wtdini2 < 0) ? 0 : wtdini2);
+        double z_uns = (wtd2 <= ud) ? wtd2 * 1000 : ud * 1000;
+        double w_uns_z = theta_r * z_uns + (((psi_m + z_uns) * (theta_r - theta_s) *
+                                             pow((bub_press / (psi_m + z_uns)), lambda)) /
+                                            (lambda - 1));
+        double w_uns_0 = theta_r * 0 + (((psi_m + 0) * (theta_r - theta_s) *
+                                         pow((bub_press / (psi_m + 0)), lambda)) /
+                                        (lambda - 1));
+        double w_uns = w_uns_z - w_uns_0;
+        double sat_swc = (wtd2 <= ud) ? theta_s * (ud - wtd2) * 1000 : 0;
+        double swc_tot = w_uns + sat_swc;
+        if (isnan(wtdini2)) swc_tot = NAN;
+        /* calc_Se, :120-125 */
+        double theta_i_top = swc_tot / (uns_depth * 1000);
+        double Se = theta_i_top / theta_s;
+        Se = (Se > 1) ? 1 : ((Se < 0) ? 0 : Se);
+        if (isnan(theta_i_top)) Se = NAN;
+        size_t k = (size_t)t * ostride;
+        if (w_z_o) w_z_o[k] = swc_tot;
+        if (wtd_o) wtd_o[k] = wtd;
+        if (se_o) se_o[k] = Se;
+        if (theta_mean_o) theta_mean_o[k] = theta_i;
+        if (cond) cond[k] = fabs(w_uns_0) / fabs(w_uns);
+    }
+}
+
 /* ------------------------------------------------------------------ drivers */
 
 static const double kNaN = NAN;

@@ -106,6 +106,9 @@ double orc_snow_partition(int nt, const double* tc, const double* pn, const int*
 void orc_unswc(const double* soil_data /*[6]*/, double uns_depth, int nt, const double* wn,
                size_t stride, double* wn_z, double* wtd, double* theta, double* cond,
                size_t ostride);
+/* R/unsSWC.grid.R:14-141, one cell of the rasters (its four output files: swc_top, wtd, Se_top, theta_mean) */
+void orc_unswc_grid(const double* soil_data /*[6]*/, double uns_depth, int nt, const double* wn, size_t stride,
+                    double* w_z, double* wtd, double* se, double* theta_mean, double* cond, size_t ostride);
 
 /* options for the point/grid drivers */
 typedef struct {

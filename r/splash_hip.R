@@ -185,6 +185,30 @@ splash.grid.statics.hip <- function(elev, degree = 1) {
   list(lat = as_raster(r$lat), terraines = terraines, resolution = as_raster(r$resolution), Au = Au)
 }
 
+# unSWC.grid (R/unsSWC.grid.R:14): same signature, same four files (names, variable names, units, long names of
+# :87, :108, :115, :126), same returned list(w_z, wtd, Se); the arithmetic -- the gridded function's own semantics,
+# include/splash_hip.h -- runs in the HIP library over the brick's values ([ncell x nt], as getValues() gives them).
+unSWC.grid <- function(soil_data, uns_depth, wn, d_name, outdir = getwd(), backend = c("hip", "host")) {
+  backend <- match.arg(backend)
+  ztime <- raster::getZ(wn)
+  time.freq <- ztime[2] - ztime[1]
+  time_text <- if (abs(as.numeric(time.freq, units = "days")) < 2) "daily" else "monthly"
+  y <- as.integer(unique(format(ztime, "%Y")))
+  res <- .Call("C_splash_unswc_grid_run", raster::getValues(wn), raster::getValues(soil_data), as.numeric(uns_depth),
+               if (backend == "host") 1L else 0L)
+  put <- function(m, tag, varname, varunit, longname) {
+    b <- raster::setValues(raster::brick(wn), m)
+    raster::writeRaster(b, paste0(outdir, "/", "SPLASH_v2.0_", tag, "_", time_text, "_", y[1], "-", y[length(y)], ".nc"),
+                        format = "CDF", overwrite = TRUE, varname = varname, varunit = varunit, longname = longname,
+                        xname = "lon", yname = "lat", zname = "time")
+  }
+  theta_i <- put(res$theta_mean, "theta_mean", "theta", "m3/m3", "volumetric soil moisture")
+  wtd <- put(res$wtd, "wtd", "wtd", "m", "water table depth")
+  w_z <- put(res$w_z, paste0("swc_top_", d_name, "_m"), "swc", "mm", "soil water content")
+  Se <- put(res$Se, paste0("Se_top_", d_name, "_m"), "Se", "fraction", "effective saturation or water filled porosity")
+  list(w_z = w_z, wtd = wtd, Se = Se)
+}
+
 # unSWC (R/unsSWC.R:14): same signature; the analytical integral runs in the HIP library.
 # One site = one "cell": wn is handed over as a [1 x nt] matrix, soil as [1 x 6].
 unSWC <- function(soil_data, uns_depth, wn, backend = c("hip", "host")) {

@@ -286,6 +286,33 @@ SEXP C_splash_unswc_run(SEXP wn, SEXP soil, SEXP uns_depth, SEXP backend)
     return res;
 }
 
+/* unSWC.grid (R/unsSWC.grid.R:14-141): the gridded function's own semantics and its four rasters.
+ * wn [ncell x nt] (getValues of the brick), soil [ncell x 6], uns_depth numeric(1), backend integer(1) */
+SEXP C_splash_unswc_grid_run(SEXP wn, SEXP soil, SEXP uns_depth, SEXP backend)
+{
+    SEXP dim = getAttrib(wn, R_DimSymbol);
+    if (isNull(dim) || LENGTH(dim) != 2) error("wn must be a [ncell x nt] matrix");
+    const size_t ncell = (size_t)INTEGER(dim)[0];
+    const int nt = INTEGER(dim)[1];
+    if ((size_t)XLENGTH(soil) != 6 * ncell)
+        error("soil must be [ncell x 6]: %d cells in wn, %d soil values", (int)ncell, (int)XLENGTH(soil));
+    static const char* names[] = {"w_z", "wtd", "Se", "theta_mean", ""};
+    SEXP res = PROTECT(mkNamed(VECSXP, names));
+    double* o[4];
+    for (int k = 0; k < 4; k++) {
+        SEXP m = PROTECT(allocMatrix(REALSXP, (int)ncell, nt));
+        o[k] = REAL(m);
+        SET_VECTOR_ELT(res, k, m);
+        UNPROTECT(1);
+    }
+    char err[512];
+    int rc = splash_unswc_grid_run(asInteger(backend), ncell, nt, REAL(wn), REAL(soil), asReal(uns_depth), o[0], o[1], o[2],
+                                   o[3], err, sizeof err);
+    UNPROTECT(1);
+    if (rc != SPLASH_OK) error("splash_unswc_grid_run failed (%d): %s", rc, err);
+    return res;
+}
+
 /* Static rasters of an elevation matrix (R/splash.grid.R:96-110, R/upslope_area.R:12-58).
  * elev: numeric matrix [W x H], i.e. t(raster::as.matrix(dem)) or the vector raster::getValues(dem)
  * with dim c(ncol, nrow) -- row-major cells, as the C ABI wants them; ymax/yres/xres: northern edge
@@ -325,6 +352,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"C_splash_snow_threshold", (DL_FUNC)&C_splash_snow_threshold, 3},
     {"C_splash_point_run", (DL_FUNC)&C_splash_point_run, 15},
     {"C_splash_unswc_run", (DL_FUNC)&C_splash_unswc_run, 4},
+    {"C_splash_unswc_grid_run", (DL_FUNC)&C_splash_unswc_grid_run, 4},
     {"C_splash_static_rasters", (DL_FUNC)&C_splash_static_rasters, 5},
     {NULL, NULL, 0}};
 

@@ -346,12 +346,14 @@ def unSWC(soil_data, uns_depth, wn, backend="hip"):
     (its first element is the water to uns_depth, :85-86).  backend="host" (ABI 6): on the calling thread, no GPU."""
     soil = np.asarray(soil_data, dtype=np.float64).reshape(6, 1)
     w = np.ascontiguousarray(np.asarray(wn, dtype=np.float64).reshape(-1, 1))
-    r = unSWC_grid(soil, uns_depth, w, backend=backend)
+    r = unSWC_cells(soil, uns_depth, w, backend=backend)
     return {k: v[:, 0] for k, v in r.items()}
 
 
-def unSWC_grid(soil, uns_depth, wn, backend="hip"):
-    """R/unsSWC.grid.R:14 on arrays: soil [6, ncell], wn [nt, ncell] -> dict of [nt, ncell]."""
+def unSWC_cells(soil, uns_depth, wn, backend="hip"):
+    """unSWC (R/unsSWC.R:14: the SITE function, with its stoniness correction and its patch of a non-positive
+    integral) for many sites at once: soil [6, ncell], wn [nt, ncell] -> dict of [nt, ncell].
+    (The gridded function of the reference has other semantics: unSWC_grid.)"""
     w, wp = _d(wn)
     nt, ncell = w.shape
     so, sp = _d(soil)
@@ -367,9 +369,35 @@ def unSWC_grid(soil, uns_depth, wn, backend="hip"):
     return out
 
 
+def unSWC_grid(soil, uns_depth, wn, backend="hip", want=("w_z", "wtd", "Se", "theta_mean")):
+    """R/unsSWC.grid.R:14-141 on arrays: soil [6, ncell], wn [nt, ncell] -> dict of [nt, ncell] with the gridded
+    function's four rasters: w_z (its "swc_top" file, mm), wtd (m), Se (effective saturation of the layer) and
+    theta_mean (the column's clamped mean theta).  Its semantics are its own (include/splash_hip.h): no stoniness
+    correction, no patch, the integral's water table capped at uns_depth.  rsplash_amd.grid.unSWC_grid is the
+    raster-level twin that also writes the four NetCDF files."""
+    w, wp = _d(wn)
+    nt, ncell = w.shape
+    so, sp = _d(soil)
+    if so.shape != (6, ncell):
+        raise ValueError("soil must be [6, ncell]")
+    names = ("w_z", "wtd", "Se", "theta_mean")
+    out = {k: np.empty((nt, ncell)) for k in names if k in want}
+    err = C.create_string_buffer(512)
+    rc = lib.splash_unswc_grid_run(_lib.backend_code(backend), ncell, nt, wp, sp, float(uns_depth),
+                                   *[out[k].ctypes.data_as(_dp) if k in out else None for k in names], err, 512)
+    if rc:
+        raise SplashError(f"splash_unswc_grid_run failed ({rc}): {err.value.decode()}")
+    return out
+
+
 def dev_unswc(ncell, nt, wn, ldw, soil, uns_depth, wn_z, wtd, theta, ldo, stream=None):
     check(lib.splash_dev_unswc(ncell, nt, _ptr(wn), ldw, _ptr(soil), float(uns_depth), _ptr(wn_z),
                                _ptr(wtd), _ptr(theta), ldo, stream), "splash_dev_unswc")
+
+
+def dev_unswc_grid(ncell, nt, wn, ldw, soil, uns_depth, w_z, wtd, se, theta_mean, ldo, stream=None):
+    check(lib.splash_dev_unswc_grid(ncell, nt, _ptr(wn), ldw, _ptr(soil), float(uns_depth), _ptr(w_z), _ptr(wtd),
+                                    _ptr(se), _ptr(theta_mean), ldo, stream), "splash_dev_unswc_grid")
 
 
 # ---------------------------------------------------------------------------- Rcpp module mirror

@@ -1056,6 +1056,22 @@ try {
     return exception_code(nullptr, 0, "splash_dev_unswc");
 }
 
+// unSWC.grid on device-resident rasters (R/unsSWC.grid.R:14-141: the gridded function's own semantics, splash_unswc.hpp)
+extern "C" int splash_dev_unswc_grid(size_t ncell, int nt, const double* wn, size_t ldw, const double* soil,
+                                     double uns_depth, double* w_z, double* wtd, double* se, double* theta_mean,
+                                     size_t ldo, void* stream)
+try {
+    REQ(wn && soil && (w_z || wtd || se || theta_mean), "unswc_grid: NULL argument");
+    REQ(ldw >= ncell && ldo >= ncell && nt >= 0, "unswc_grid: leading dimension < ncell");
+    REQ(uns_depth > 0, "unswc_grid: uns_depth must be positive");
+    if (int rc = enter_device(nullptr, 0)) return rc;
+    HIP_TRY(launch_unswc_grid(ncell, nt, wn, ldw, soil, uns_depth, w_z, wtd, se, theta_mean, ldo, (hipStream_t)stream),
+            nullptr, 0);
+    return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_unswc_grid");
+}
+
 // test hook: SOLAR+EVAP rows (host pointers)
 extern "C" int splash_dev_evap_batch(size_t m, const double* lat, const double* elv,
                                      const double* sw, const int* n, const int* y,
@@ -1240,6 +1256,59 @@ extern "C" int splash_unswc_run(size_t ncell, int nt, const double* wn, const do
                                 double* wtd, double* theta, char* err, size_t errlen)
 {
     return splash_unswc_run_backend(SPLASH_BACKEND_HIP, ncell, nt, wn, soil, uns_depth, wn_z, wtd, theta, err, errlen);
+}
+
+// unSWC.grid for host buffers: wn [nt][ncell], soil [6][ncell] -> w_z, wtd, Se, theta_mean [nt][ncell] (any NULL), in
+// column blocks sized to the device's free memory (a brick of 4096 x 4096 x 365 is 49 GB per array)
+extern "C" int splash_unswc_grid_run(int backend, size_t ncell, int nt, const double* wn, const double* soil,
+                                     double uns_depth, double* w_z, double* wtd, double* se, double* theta_mean,
+                                     char* err, size_t errlen)
+try {
+    if (!wn || !soil) return fail(SPLASH_EINVAL, err, errlen, "unswc_grid_run: NULL input");
+    if (!(uns_depth > 0)) return fail(SPLASH_EINVAL, err, errlen, "unswc_grid_run: uns_depth must be positive");
+    if (backend != SPLASH_BACKEND_HIP && backend != SPLASH_BACKEND_HOST)
+        return fail(SPLASH_EINVAL, err, errlen, "unswc_grid_run: unknown backend %d", backend);
+    double* const outs[4] = {w_z, wtd, se, theta_mean};
+    if (backend == SPLASH_BACKEND_HOST) {
+        if (ncell && nt > 0) host_unswc_grid(ncell, nt, wn, soil, uns_depth, w_z, wtd, se, theta_mean);
+        return SPLASH_OK;
+    }
+    if (int rc = enter_device(err, errlen)) return rc;
+    if (ncell == 0 || nt <= 0) return SPLASH_OK;
+    int n_out = 0;
+    for (double* o : outs) n_out += o != nullptr;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b), err, errlen);
+    int cur_dev = 0;
+    HIP_TRY(hipGetDevice(&cur_dev), err, errlen);
+    free_b += pool_idle_bytes(cur_dev);
+    if (knobs().fake_device) free_b = knobs().fake_device_bytes; // SPLASH_HIP_FAKE_DEVICE_BYTES (tests: several column blocks)
+    const size_t per_cell = (size_t)nt * 8 * (size_t)(1 + n_out) + 6 * 8;
+    size_t nb = std::min<size_t>(ncell, std::max<size_t>(256, (size_t)((double)free_b * 0.5 / (double)per_cell)));
+    nb = std::min(nb, kMaxCellsPerLaunch);
+    DevBuf d_wn, d_soil, d_out[4];
+    HIP_TRY(d_wn.alloc((size_t)nt * nb * 8), err, errlen);
+    HIP_TRY(d_soil.alloc(6 * nb * 8), err, errlen);
+    for (int k = 0; k < 4; k++)
+        if (outs[k]) HIP_TRY(d_out[k].alloc((size_t)nt * nb * 8), err, errlen);
+    for (size_t c0 = 0; c0 < ncell; c0 += nb) {
+        const size_t n = std::min(nb, ncell - c0);
+        HIP_TRY(hipMemcpy2D(d_wn.p, n * 8, wn + c0, ncell * 8, n * 8, (size_t)nt, hipMemcpyHostToDevice), err, errlen);
+        HIP_TRY(hipMemcpy2D(d_soil.p, n * 8, soil + c0, ncell * 8, n * 8, 6, hipMemcpyHostToDevice), err, errlen);
+        HIP_TRY(launch_unswc_grid(n, nt, d_wn.as<double>(), n, d_soil.as<double>(), uns_depth,
+                                  outs[0] ? d_out[0].as<double>() : nullptr, outs[1] ? d_out[1].as<double>() : nullptr,
+                                  outs[2] ? d_out[2].as<double>() : nullptr, outs[3] ? d_out[3].as<double>() : nullptr, n,
+                                  nullptr),
+                err, errlen);
+        HIP_TRY(hipDeviceSynchronize(), err, errlen);
+        for (int k = 0; k < 4; k++)
+            if (outs[k])
+                HIP_TRY(hipMemcpy2D(outs[k] + c0, ncell * 8, d_out[k].p, n * 8, n * 8, (size_t)nt, hipMemcpyDeviceToHost), err,
+                        errlen);
+    }
+    return SPLASH_OK;
+} catch (...) {
+    return exception_code(err, errlen, "splash_unswc_grid_run");
 }
 
 // K2 on host buffers (ABI 5): the snowfall threshold of a tc series, for callers that process a long

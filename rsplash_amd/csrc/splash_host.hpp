@@ -168,6 +168,8 @@ void host_mod_spin_up(const double* par, int n, const DayRec* days, const double
                       const double* snowfall, double* const series[7], int* passes);
 void host_unswc(size_t ncell, int nt, const double* wn, const double* soil, double uns_depth, double* wn_z, double* wtd,
                 double* theta);
+void host_unswc_grid(size_t ncell, int nt, const double* wn, const double* soil, double uns_depth, double* w_z,
+                     double* wtd, double* se, double* theta_mean);
 double host_mod_moist_surf(double depth, double z, double bub_p, double wn, double SAT, double RES, double lambda);
 double host_mod_inf_GA(double bub_press, double theta_i, double Ksat, double theta_s, double lambda, double P, double tdur,
                        double slop);

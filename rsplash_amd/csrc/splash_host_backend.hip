@@ -305,6 +305,27 @@ __attribute__((always_inline)) inline void unswc_impl(size_t ncell, int nt, cons
     }
 }
 
+// unSWC.grid (R/unsSWC.grid.R:14-141) on host arrays: w_z, wtd, Se, theta_mean [nt][ncell] (any NULL)
+__attribute__((always_inline)) inline void unswc_grid_impl(size_t ncell, int nt, const double* wn, const double* soil,
+                                                           double uns_depth, double* w_z, double* wtd, double* se,
+                                                           double* theta_mean)
+{
+    for (size_t i = 0; i < ncell; i++) {
+        UnswcCell u;
+        unswc_grid_setup(soil[i], soil[ncell + i], soil[2 * ncell + i], soil[3 * ncell + i], soil[4 * ncell + i],
+                         soil[5 * ncell + i], uns_depth, u);
+        for (int t = 0; t < nt; t++) {
+            const size_t k = (size_t)t * ncell + i;
+            double a, b, c, d;
+            unswc_grid_step(u, wn[k], a, b, c, d);
+            if (w_z) w_z[k] = a;
+            if (wtd) wtd[k] = b;
+            if (se) se[k] = c;
+            if (theta_mean) theta_mean[k] = d;
+        }
+    }
+}
+
 // Two builds of every driver: the generic x86-64 one and one for cores with FMA (every x86 server core since
 // 2013), chosen once at run time.  The Horner chains of splash_math.hpp are fma() calls: without the target
 // attribute each is a call into libm, with it one vfmadd instruction (measured on the Bourne site: see
@@ -347,6 +368,17 @@ SPL_FMA_TARGET void unswc_fma(size_t ncell, int nt, const double* wn, const doub
     unswc_impl(ncell, nt, wn, soil, d, a, b, c);
 }
 
+void unswc_grid_generic(size_t ncell, int nt, const double* wn, const double* soil, double d, double* a, double* b,
+                        double* c, double* e)
+{
+    unswc_grid_impl(ncell, nt, wn, soil, d, a, b, c, e);
+}
+SPL_FMA_TARGET void unswc_grid_fma(size_t ncell, int nt, const double* wn, const double* soil, double d, double* a,
+                                   double* b, double* c, double* e)
+{
+    unswc_grid_impl(ncell, nt, wn, soil, d, a, b, c, e);
+}
+
 } // namespace
 
 bool host_backend_fma()
@@ -383,6 +415,13 @@ void host_unswc(size_t ncell, int nt, const double* wn, const double* soil, doub
 {
     if (host_backend_fma()) unswc_fma(ncell, nt, wn, soil, uns_depth, wn_z, wtd, theta);
     else unswc_generic(ncell, nt, wn, soil, uns_depth, wn_z, wtd, theta);
+}
+
+void host_unswc_grid(size_t ncell, int nt, const double* wn, const double* soil, double uns_depth, double* w_z,
+                     double* wtd, double* se, double* theta_mean)
+{
+    if (host_backend_fma()) unswc_grid_fma(ncell, nt, wn, soil, uns_depth, w_z, wtd, se, theta_mean);
+    else unswc_grid_generic(ncell, nt, wn, soil, uns_depth, w_z, wtd, se, theta_mean);
 }
 
 double host_mod_moist_surf(double depth, double z, double bub_p, double wn, double SAT, double RES, double lambda)

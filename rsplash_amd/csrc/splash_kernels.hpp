@@ -200,6 +200,8 @@ hipError_t launch_evap_batch(size_t m, const double* lat, const double* elv, con
 hipError_t launch_unswc(size_t ncell, int nt, const double* wn, size_t ldw, const double* soil,
                         double uns_depth, double* wn_z, double* wtd, double* theta, size_t ldo,
                         hipStream_t s);
+hipError_t launch_unswc_grid(size_t ncell, int nt, const double* wn, size_t ldw, const double* soil, double uns_depth,
+                             double* w_z, double* wtd, double* se, double* theta_mean, size_t ldo, hipStream_t s);
 hipError_t launch_math_probe(size_t n, const double* x, const double* y, double* out, hipStream_t s);
 hipError_t launch_infiltration_probe(size_t n, const double* par, const double* wn,
                                      const double* ksat, const double* P, double* theta_surf,

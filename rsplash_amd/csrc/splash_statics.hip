@@ -54,6 +54,35 @@ __global__ __launch_bounds__(kBlock) void k_unswc(size_t ncell, int nt,
     }
 }
 
+// unSWC.grid (R/unsSWC.grid.R:14-141): the gridded function's own semantics (unswc_grid_step) and its four rasters.
+// HBM traffic: 8 B read + 32 B written per cell-step with all four wanted.
+__global__ __launch_bounds__(kBlock) void k_unswc_grid(size_t ncell, int nt, const double* __restrict__ wn, size_t ldw,
+                                                      const double* __restrict__ soil, double uns_depth,
+                                                      double* __restrict__ w_z, double* __restrict__ wtd_o,
+                                                      double* __restrict__ se_o, double* __restrict__ theta_o, size_t ldo)
+{
+    lds_tables_init();
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= ncell) return;
+    UnswcCell u;
+    unswc_grid_setup(soil[i], soil[ncell + i], soil[2 * ncell + i], soil[3 * ncell + i], soil[4 * ncell + i],
+                     soil[5 * ncell + i], uns_depth, u);
+    double w_next = nt > 0 ? __builtin_nontemporal_load(&wn[i]) : 0.0;
+    asm volatile("" : "+v"(w_next) : : "memory");
+    for (int t = 0; t < nt; t++) {
+        const double w = w_next;
+        w_next = __builtin_nontemporal_load(&wn[(size_t)(t + 1 < nt ? t + 1 : t) * ldw + i]);
+        double v_wz, v_wtd, v_se, v_theta;
+        unswc_grid_step(u, w, v_wz, v_wtd, v_se, v_theta);
+        asm volatile("" : "+v"(w_next) : : "memory"); // the next step's load has landed (one counter for loads and stores)
+        const size_t k = (size_t)t * ldo + i;
+        if (w_z) __builtin_nontemporal_store(v_wz, &w_z[k]);
+        if (wtd_o) __builtin_nontemporal_store(v_wtd, &wtd_o[k]);
+        if (se_o) __builtin_nontemporal_store(v_se, &se_o[k]);
+        if (theta_o) __builtin_nontemporal_store(v_theta, &theta_o[k]);
+    }
+}
+
 // ================================================================ synthetic inputs =============
 __device__ __forceinline__ uint64_t mix64(uint64_t z)
 {
@@ -559,6 +588,15 @@ hipError_t launch_mfd_area(int H, int W, const double* elev, double resolution_m
     const hipError_t e2 = hipGetLastError();
     (void)hipFreeAsync(w, s);
     return e != hipSuccess ? e : e2;
+}
+
+hipError_t launch_unswc_grid(size_t ncell, int nt, const double* wn, size_t ldw, const double* soil, double uns_depth,
+                             double* w_z, double* wtd, double* se, double* theta_mean, size_t ldo, hipStream_t s)
+{
+    if (ncell == 0 || nt == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_unswc_grid, dim3(nblk(ncell, kBlock)), dim3(kBlock), 0, s, ncell, nt, wn, ldw, soil, uns_depth,
+                       w_z, wtd, se, theta_mean, ldo);
+    return hipGetLastError();
 }
 
 hipError_t launch_unswc(size_t ncell, int nt, const double* wn, size_t ldw, const double* soil,

@@ -85,4 +85,49 @@ SPL_DEV void unswc_step(const UnswcCell& u, double wn, double& wn_z, double& wtd
     wtd_out = wtd;
 }
 
+// The GRIDDED function (R/unsSWC.grid.R:14-141) is not unSWC applied cell by cell: it leaves the stoniness correction out
+// (:65 `fgravel = soil_data[[4]]*0`; the (1 - gravel/100) factor is commented out, :73), has no patch for a non-positive
+// integral (R/unsSWC.R:74 has one), hands UnsWater the sensor depth as its `depth` argument (:115 against the signature
+// at :29: the water table of the INTEGRAL is capped at uns_depth, the one it writes out -- calcwtd, :98-106 -- at the soil
+// depth), and returns the layer's effective saturation (calc_Se, :120-125) and the column's clamped mean theta (:79-87).
+// Same setup (the gravel factors of UnswcCell are not used), same logarithm/exponential forms as unswc_step().
+SPL_DEV void unswc_grid_setup(double sand, double clay, double OM, double gravel, double bd, double depth,
+                              double uns_depth, UnswcCell& u)
+{
+    unswc_setup(sand, clay, OM, 0.0, bd, depth, uns_depth, u);
+    if (isnan(gravel)) { // soil_hydro(..., fgravel = NA * 0, ...): SAT and RES carry the factor (1 - fgravel), R/splash.point.R:315, 410
+        u.theta_s = gravel;
+        u.theta_r = gravel;
+    }
+}
+
+SPL_DEV void unswc_grid_step(const UnswcCell& u, double wn, double& w_z, double& wtd_out, double& se_out,
+                             double& theta_mean_out)
+{
+    const double theta_s = u.theta_s, theta_r = u.theta_r, bub = u.bub, lambda = u.lambda, inv_lambda = u.inv_lambda;
+    const double uns_depth = u.uns_depth, u1000 = u.u1000, inv_lm1 = u.inv_lm1;
+    const double theta_o = wn * u.inv_d1000;                                                    // calc_thetai, :79-86
+    double theta_i = (theta_o >= theta_s) ? theta_s - 0.0001 : ((theta_o <= theta_r) ? theta_r + 0.0001 : theta_o);
+    if (isnan(theta_o) || isnan(theta_s) || isnan(theta_r)) theta_i = theta_o + theta_s + theta_r; // ifelse(NA, ., .) is NA
+    const double Theta = (theta_i - theta_r) * u.inv_dth;
+    const double L = flog<kLogPositive>(Theta);
+    const double Pm = fexp(-L * inv_lambda);      // Theta^(-1/lambda) >= 1
+    const double psi_m = bub * Pm;                // :92
+    const double wtdini = (bub - psi_m) * 1.0e-3; // calcwtd, :98-106 (against the soil depth) and UnsWater's own (against uns_depth)
+    const double wtd = (wtdini > u.depth) ? u.depth : ((wtdini < 0) ? 0 : wtdini);
+    const double wtd2 = (wtdini > uns_depth) ? uns_depth : ((wtdini < 0) ? 0 : wtdini);
+    const double z_uns = (wtd2 <= uns_depth) ? wtd2 * 1000 : u1000;
+    const double pz = fexp(-lambda * flog<kLogPositive>(Pm + z_uns * u.inv_bub));
+    const double w_uns_z = theta_r * z_uns + (((psi_m + z_uns) * (theta_r - theta_s) * pz) * inv_lm1);
+    const double w_uns_0 = ((psi_m * (theta_r - theta_s) * Theta) * inv_lm1);
+    const double sat_swc = (wtd2 <= uns_depth) ? theta_s * (uns_depth - wtd2) * 1000 : 0;
+    const double swc_tot = (w_uns_z - w_uns_0) + sat_swc;
+    double Se = (swc_tot * u.inv_u1000) / theta_s; // calc_Se, :120-125
+    Se = (Se > 1) ? 1 : ((Se < 0) ? 0 : Se);
+    w_z = swc_tot;
+    wtd_out = isnan(wtdini) ? wtdini : wtd;
+    se_out = isnan(swc_tot) ? swc_tot : Se;
+    theta_mean_out = theta_i;
+}
+
 } // namespace splash

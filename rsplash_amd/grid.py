@@ -306,3 +306,30 @@ def _returned(inmem, mats, writer, st, bs, want_diag, acc_total, basin):
         d, _ = api.diag_finalize_host(acc_total)
         out["diag"] = {k: (d[:, :, j] if basin is not None else d[0, :, j]) for j, k in enumerate(api.DIAG_NAMES)}
     return out
+
+
+def unSWC_grid(soil_data, uns_depth, wn, d_name, outdir=None, backend="hip"):
+    """unSWC.grid(soil_data, uns_depth, wn, d_name, outdir = getwd()) -- R/unsSWC.grid.R:14-141 with its signature.
+
+    soil_data: Raster of six layers (sand, clay, OM, coarse fragments, bulk density, depth to bedrock), wn: Raster
+    brick of the column water content with its layer dates in `z` (the `wn` brick splash.grid returns), d_name: the
+    depth as it should appear in the file names.  Writes the reference's four files into outdir (io.UNSWC_BRICKS;
+    outdir=None: nothing is written) and returns what it returns, list(w_z, wtd, Se), as Rasters -- plus theta_mean,
+    the raster its first file holds.  The arithmetic is the library's (splash_unswc_grid_run: the gridded function's
+    own semantics, include/splash_hip.h), in column blocks sized to the device."""
+    _compare([soil_data, wn])
+    if wn.z is None:
+        raise ValueError("unSWC.grid: wn needs its layer dates (getZ)")
+    H, W = wn.nrow, wn.ncol
+    soil = np.ascontiguousarray(np.asarray(soil_data.values, dtype=np.float64).reshape(6, H * W))
+    w = np.asarray(wn.values)
+    nl = w.shape[0]
+    w = np.ascontiguousarray(w.reshape(nl, H * W), dtype=np.float64)
+    r = api.unSWC_grid(soil, uns_depth, w, backend=backend)
+    res = {k: v.reshape(nl, H, W) for k, v in r.items()}
+    out = {k: wn.like(v, z=wn.z) for k, v in res.items()}
+    if outdir is not None:
+        os.makedirs(outdir, exist_ok=True)
+        out["paths"] = _io.write_unswc_bricks(outdir, res, wn.lon(), wn.lat(), wn.z, d_name)
+    return out
+

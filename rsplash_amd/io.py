@@ -47,6 +47,69 @@ def brick_path(outdir, key, monthly_out, y0, y1):
     return os.path.join(outdir, f"SPLASH_v2.0_{tag}_{'monthly' if monthly_out else 'daily'}_{y0}-{y1}.nc")
 
 
+def _write_one(path, a, varname, unit, longname, lon, lat, zval, zunit):
+    """one [nl, nrow, ncol] brick as a NetCDF file laid out like raster's writeRaster(format="CDF", xname="lon",
+    yname="lat", zname="time") output (R/splash.grid.R:190-216)"""
+    with netcdf_file(path, "w", version=2) as f:
+        f.createDimension("time", len(zval))
+        f.createDimension("lon", lon.size)
+        f.createDimension("lat", lat.size)
+        vx = f.createVariable("lon", "d", ("lon",))
+        vx.units, vx.long_name = "degrees_east", "lon"
+        vy = f.createVariable("lat", "d", ("lat",))
+        vy.units, vy.long_name = "degrees_north", "lat"
+        vt = f.createVariable("time", "i", ("time",))
+        vt.units, vt.long_name = zunit, "time"
+        v = f.createVariable(varname, "f", ("time", "lat", "lon"))
+        v.units, v.long_name = unit, longname
+        v._FillValue = NA_FLT4S
+        v.missing_value = NA_FLT4S
+        vx[:], vy[:] = lon, lat
+        vt[:] = np.asarray(zval).astype(np.int32)
+        with np.errstate(over="ignore"):   # FLT4S: a double beyond the float range is stored as inf, as raster stores it
+            v[:] = np.where(np.isnan(a), NA_FLT4S, a).astype(np.float32)
+        f.title = "SPLASH v2.0 " + longname
+
+
+# the four rasters of unSWC.grid (R/unsSWC.grid.R:87, 108, 115, 126): key -> (file tag, varname, unit, longname);
+# "{d}" is the caller's d_name (the depth as text, e.g. "0.49")
+UNSWC_BRICKS = {
+    "theta_mean": ("theta_mean", "theta", "m3/m3", "volumetric soil moisture"),
+    "wtd": ("wtd", "wtd", "m", "water table depth"),
+    "w_z": ("swc_top_{d}_m", "swc", "mm", "soil water content"),
+    "Se": ("Se_top_{d}_m", "Se", "fraction", "effective saturation or water filled porosity"),
+}
+
+
+def write_unswc_bricks(outdir, res, lon, lat, ztime, d_name):
+    """The files unSWC.grid writes, with its names: SPLASH_v2.0_<tag>_<daily|monthly>_<y0>-<y1>.nc, where the
+    frequency is read off the first two layer dates (< 2 days apart: daily, R/unsSWC.grid.R:19-26) and the years
+    off all of them (:76).  res[key]: [nl, nrow, ncol].  The time variable holds the layers' dates as days since
+    (first year - 1)-12-31, like the bricks of splash.grid (overlay() drops the Z of its inputs: the reference's
+    files number their layers 1..nl).  Returns {key: path}."""
+    t = np.asarray(ztime, dtype="datetime64[D]")
+    if t.size < 2:
+        raise ValueError("unSWC.grid reads the time step off the first two layer dates: at least two layers")
+    step = abs(int((t[1] - t[0]).astype(np.int64)))
+    time_text = "daily" if step < 2 else "monthly"
+    years = np.unique(t.astype("datetime64[Y]").astype(int) + 1970)
+    y0, y1 = int(years[0]), int(years[-1])
+    origin = np.datetime64(f"{y0 - 1:04d}-12-31")
+    zval, zunit = (t - origin).astype(np.int64), f"days since {y0 - 1}-12-31"
+    lon, lat = np.asarray(lon, dtype=np.float64), np.asarray(lat, dtype=np.float64)
+    paths = {}
+    for key, (tag, varname, unit, longname) in UNSWC_BRICKS.items():
+        if key not in res:
+            continue
+        a = np.asarray(res[key])
+        if a.shape != (t.size, lat.size, lon.size):
+            raise ValueError(f"{key}: expected [{t.size}, {lat.size}, {lon.size}], got {a.shape}")
+        path = os.path.join(outdir, f"SPLASH_v2.0_{tag.format(d=d_name)}_{time_text}_{y0}-{y1}.nc")
+        _write_one(path, a, varname, unit, longname, lon, lat, zval, zunit)
+        paths[key] = path
+    return paths
+
+
 def write_bricks(outdir, res, lon, lat, time_index, monthly_out):
     """Write every output of `res` that is one of the nine bricks.  res[key]: [nl, nrow, ncol]
     (row 0 = northernmost, as raster stores it); lon [ncol], lat [nrow] cell centres.
@@ -64,24 +127,7 @@ def write_bricks(outdir, res, lon, lat, time_index, monthly_out):
             raise ValueError(f"{key}: {a.shape[0]} layers for a time axis of {z.size} "
                              "(the inputs must cover whole calendar years, R/splash.grid.R:161-166)")
         path = brick_path(outdir, key, monthly_out, y0, y1)
-        with netcdf_file(path, "w", version=2) as f:
-            f.createDimension("time", z.size)
-            f.createDimension("lon", lon.size)
-            f.createDimension("lat", lat.size)
-            vx = f.createVariable("lon", "d", ("lon",))
-            vx.units, vx.long_name = "degrees_east", "lon"
-            vy = f.createVariable("lat", "d", ("lat",))
-            vy.units, vy.long_name = "degrees_north", "lat"
-            vt = f.createVariable("time", "i", ("time",))
-            vt.units, vt.long_name = zunit, "time"
-            v = f.createVariable(varname, "f", ("time", "lat", "lon"))
-            v.units, v.long_name = unit, longname
-            v._FillValue = NA_FLT4S
-            v.missing_value = NA_FLT4S
-            vx[:], vy[:] = lon, lat
-            vt[:] = zval.astype(np.int32)
-            v[:] = np.where(np.isnan(a), NA_FLT4S, a).astype(np.float32)
-            f.title = "SPLASH v2.0 " + longname
+        _write_one(path, a, varname, unit, longname, lon, lat, zval, zunit)
         paths[key] = path
     return paths
 

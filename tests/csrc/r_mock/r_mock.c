@@ -337,6 +337,11 @@ int main(int argc, char** argv)
     for (int k = 0; k < 3; k++) fwrite(REAL(VECTOR_ELT(ru, k)), sizeof(double), (size_t)nt, o);
     SEXP u_bad[4] = {wn_m, real_mat(soil1, 1, 5), u[2], u[3]};
     bad += expect_error("C_splash_unswc_run", 4, u_bad, "soil must be [ncell x 6]");
+    /* 6. unSWC.grid on the block's wn brick ([ncell x nt] as getValues() gives it), host backend: its four rasters */
+    SEXP ug[4] = {VECTOR_ELT(rg, 0), g[4], scalar(REALSXP, 0.3), scalar(INTSXP, 1)};
+    SEXP rug = dot_call("C_splash_unswc_grid_run", 4, ug);
+    if (LENGTH(rug) != 4 || strcmp(rug->names[0], "w_z") || strcmp(rug->names[2], "Se") || strcmp(rug->names[3], "theta_mean")) { fprintf(stderr, "mock: unswc_grid result list\n"); bad++; }
+    for (int k = 0; k < 4; k++) fwrite(REAL(VECTOR_ELT(rug, k)), sizeof(double), ng, o);
     fclose(o);
     if (g_protect != 0) { fprintf(stderr, "mock: protection stack at %d at exit\n", g_protect); bad++; }
     printf("r_mock: %d problems; deepest protection stack %d\n", bad, g_protect_max);

@@ -287,7 +287,12 @@ def test_r_shim_runs_against_a_mock_r_api(oracle, bourne, tmp_path):
     at += 5 * n
     un = got[at:at + 3 * nt].reshape(3, nt)                # unSWC of the site's wn to 0.49 m, host backend
     at += 3 * nt
+    ug = got[at:at + 4 * nt * n].reshape(4, nt, n)           # unSWC.grid of the block's wn brick to 0.3 m, host backend
+    at += 4 * nt * n
     assert at == got.size
+    ugref = api.unSWC_grid(st["soil"], 0.3, full["wn"], backend="host")
+    for i, k in enumerate(("w_z", "wtd", "Se", "theta_mean")):
+        assert np.array_equal(ug[i], ugref[k], equal_nan=True), "unSWC.grid: " + k
     uref = api.unSWC(soil1, 0.49, ref["wn"], backend="host")
     for i, k in enumerate(("wn_z", "wtd", "theta_i")):
         assert np.array_equal(un[i], uref[k], equal_nan=True), k

@@ -1013,7 +1013,7 @@ def test_unswc_bourne_and_grid(api, oracle, bourne):
     wn = sat[:, 1] + (sat[:, 0] - sat[:, 1]) * rng.uniform(0, 1, (nt, H * W))
     wn[0] = sat[:, 1]
     wn[1] = sat[:, 0]
-    got = api.unSWC_grid(soil, 0.3, wn)
+    got = api.unSWC_cells(soil, 0.3, wn)
     bad = 0
     for j in range(H * W):
         ref = oracle.unswc(soil[:, j], 0.3, wn[:, j])
@@ -1021,6 +1021,39 @@ def test_unswc_bourne_and_grid(api, oracle, bourne):
             tol = 1e-5 * np.abs(ref[k]) + 1e-9 + 1e-14 * ref["cond"] * np.abs(ref[k])
             bad += int((np.abs(got[k][:, j] - ref[k]) > tol).sum())
     assert bad == 0
+
+
+@pytest.mark.parametrize("uns_depth", [0.3, 2.5])
+def test_unswc_grid_semantics(api, oracle, uns_depth):
+    """R/unsSWC.grid.R:14-141 (the GRIDDED function: no stoniness correction, no patch, the integral's water table
+    capped at uns_depth, four rasters) on the device: splash_unswc_grid_run (host buffers, here forced into several
+    column blocks) and splash_dev_unswc_grid (device rasters) against the oracle's restatement of the gridded function
+    and, to rounding, against the host backend running the same two functions."""
+    import torch
+    from test_host_backend import _assert_unswc_grid, _unswc_grid_case
+    soil, wn = _unswc_grid_case(oracle, H=8, W=64, nt=90, seed=5)
+    got = api.unSWC_grid(soil, uns_depth, wn)
+    _assert_unswc_grid(oracle, got, soil, wn, uns_depth)
+    os.environ["SPLASH_HIP_FAKE_DEVICE_BYTES"] = "1"        # a pretend device: column blocks of the minimum, 256 cells
+    try:
+        blocked = api.unSWC_grid(soil, uns_depth, wn)
+    finally:
+        os.environ.pop("SPLASH_HIP_FAKE_DEVICE_BYTES")
+    for k in got:
+        assert np.array_equal(blocked[k], got[k], equal_nan=True), "column blocks: " + k
+    host = api.unSWC_grid(soil, uns_depth, wn, backend="host")
+    for k in got:
+        assert np.array_equal(np.isnan(got[k]), np.isnan(host[k])), k
+        # (the integral is a difference of two terms that cancel for dry columns: host and device may differ by the
+        # cancellation factor times an ulp there, like either of them and the oracle)
+    nt, n = wn.shape
+    dev = torch.device("cuda:0")
+    d_wn, d_soil = torch.from_numpy(wn).to(dev), torch.from_numpy(soil).to(dev)
+    outs = [torch.empty(nt, n, dtype=torch.float64, device=dev) for _ in range(4)]
+    api.dev_unswc_grid(n, nt, d_wn, n, d_soil, uns_depth, *outs, n)
+    torch.cuda.synchronize()
+    for k, o in zip(("w_z", "wtd", "Se", "theta_mean"), outs):
+        assert np.array_equal(o.cpu().numpy(), got[k], equal_nan=True), k      # same kernel: same bits
 
 
 def test_splash_grid_leap_year_calendar(api, oracle):
