@@ -72,7 +72,7 @@ splash.point <- function(sw_in, tc, pn, lat, elev, slop = 0, asp = 0, soil_data,
 # .splash_grid_collect returns them (names as R/splash.grid.R:190-216 and :449)
 .splash_outputs <- data.frame(
   key  = c("wn",  "ro", "pet", "aet", "snow", "cond", "bflow", "netr",   "sm_lim"),
-  stem = c("swc", "ro", "pet", "aet", "swe",  "cond", "bflow", "netrad", "sm_lim"),
+  stem = c("sm", "ro", "pet", "aet", "swe",  "cond", "bflow", "netrad", "sm_lim"),   # writeStart()'s names, R/splash.grid.R:321-337
   var  = c("wm",  "ro", "pet", "aet", "swe",  "cond", "bflow", "netrad", "sm_lim"),
   unit = c("mm",  "mm", "mm",  "mm",  "mm",   "mm",   "mm",    "MJ",     "mm"),
   long = c("Soil water content", "surface runoff", "potential evapotranspiration",

@@ -1,5 +1,5 @@
 """Output side of splash.grid: the nine result bricks as NetCDF files with the reference's file
-names, variable names, units and axis names (R/splash.grid.R:186-216: `brick(..., filename=
+names, variable names, units and axis names (R/splash.grid.R:321-337 `writeStart(..., filename=...)`, 186-216: `brick(..., filename=
 paste0(outdir,"/SPLASH_v2.0_",name,"_",time_text,"_",y[1],"-",y[length(y)],".nc"), format="CDF",
 varname=..., varunit=..., longname=..., xname="lon", yname="lat", zname="time")`, written block by
 block at :370-400 and closed at :409-417).
@@ -14,9 +14,12 @@ import os
 import numpy as np
 from scipy.io import netcdf_file
 
-# result key -> (file tag, varname, unit, longname), R/splash.grid.R:190-214
+# result key -> (file tag, varname, unit, longname), R/splash.grid.R:321-337: the names of the writeStart() calls, which
+# open the files the blocks are written into.  (The brick() calls at :190-214 carry the same names except for the
+# soil water, "swc" there and "sm" at :321 -- but with values=FALSE raster::brick() returns an empty brick and writes
+# nothing: the file a run leaves behind is SPLASH_v2.0_sm_*.nc.  Rounds 1-5 used "swc" here.)
 BRICKS = {
-    "wn": ("swc", "wm", "mm", "Soil water content"),
+    "wn": ("sm", "wm", "mm", "Soil water content"),
     "ro": ("ro", "ro", "mm", "surface runoff"),
     "pet": ("pet", "pet", "mm", "potential evapotranspiration"),
     "aet": ("aet", "aet", "mm", "actual evapotranspiration"),

@@ -119,7 +119,7 @@ def test_r_wrapper_labels_results_positionally():
     key, ret, stem = col("key"), col("ret"), col("stem")
     assert key == ["wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "sm_lim"]
     assert ret == [{"netr": "netrad"}.get(k, k) for k in key]
-    assert stem == [{"wn": "swc", "snow": "swe", "netr": "netrad"}.get(k, k) for k in key]
+    assert stem == [{"wn": "sm", "snow": "swe", "netr": "netrad"}.get(k, k) for k in key]
     # the order of the reference's return value (R/splash.grid.R:449) is restored BY NAME
     assert 'out[c("wn", "ro", "pet", "aet", "snow", "bflow", "cond", "netrad", "sm_lim")]' in txt
     # the pipelined loop: blocks are submitted ahead and collected in order; the shim registers both halves

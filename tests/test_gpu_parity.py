@@ -434,7 +434,7 @@ def test_splash_grid_writes_reference_named_bricks(api, oracle, tmp_path):
                         st["slop"], st["asp"], st["au"], st["resolution"], time_index=d["dates"],
                         sim_control=dict(monthly_out=True, inmem=False), outdir=str(tmp_path))
     assert len(g["files"]) == 9 and g["wn"].shape == (24, H, W)
-    assert os.path.basename(g["files"]["wn"]) == "SPLASH_v2.0_swc_monthly_2001-2002.nc"
+    assert os.path.basename(g["files"]["wn"]) == "SPLASH_v2.0_sm_monthly_2001-2002.nc"
     with netcdf_file(g["files"]["aet"], "r", mmap=False) as f:
         a = f.variables["aet"][:].astype(np.float64)
         assert a.shape == (24, H, W) and np.allclose(a, g["aet"], rtol=1e-6, atol=1e-30)
@@ -508,7 +508,7 @@ def test_splash_grid_end_to_end_from_a_dem_in_row_blocks(api, oracle, tmp_path):
     oned = api.splash_grid(sw, tc, pn, dem, soil.values, statics["lat"], statics["slop"], statics["asp"],
                            statics["Au"], statics["resolution"], time_index=d["dates"],
                            sim_control=dict(monthly_out=False))
-    assert os.path.basename(gd["wn"]) == "SPLASH_v2.0_swc_daily_2001-2002.nc"
+    assert os.path.basename(gd["wn"]) == "SPLASH_v2.0_sm_daily_2001-2002.nc"
     assert os.path.basename(gd["netrad"]) == "SPLASH_v2.0_netrad_daily_2001-2002.nc"
     for k, rk in ret.items():
         with netcdf_file(gd[rk], "r", mmap=False) as fo:

@@ -21,7 +21,7 @@ def test_bricks_are_named_like_the_reference(tmp_path, monthly):
     lat, lon = 10.25 - 0.5 * np.arange(H), -70.25 + 0.5 * np.arange(W)
     paths = io.write_bricks(str(tmp_path), res, lon, lat, t, monthly)
     tt = "monthly" if monthly else "daily"
-    assert os.path.basename(paths["wn"]) == f"SPLASH_v2.0_swc_{tt}_2014-2015.nc"
+    assert os.path.basename(paths["wn"]) == f"SPLASH_v2.0_sm_{tt}_2014-2015.nc"
     assert os.path.basename(paths["netr"]) == f"SPLASH_v2.0_netrad_{tt}_2014-2015.nc"
     assert os.path.basename(paths["snow"]) == f"SPLASH_v2.0_swe_{tt}_2014-2015.nc"
     assert len(paths) == 9
