@@ -185,6 +185,11 @@ splash.grid.statics.hip <- function(elev, degree = 1) {
   list(lat = as_raster(r$lat), terraines = terraines, resolution = as_raster(r$resolution), Au = Au)
 }
 
+# upslope_area (R/upslope_area.R:12) from the HIP library: the same RasterStack(areacatch, ncellin, ncellout).  The
+# reference hands sinkfill()/topidx() the MEAN of its resolution raster (:14); the library forms that mean itself
+# from the cell areas, so the argument is accepted for the signature's sake only.
+upslope_area.hip <- function(dem, resolution = NULL) splash.grid.statics.hip(dem)$Au
+
 # unSWC.grid (R/unsSWC.grid.R:14): same signature, same four files (names, variable names, units, long names of
 # :87, :108, :115, :126), same returned list(w_z, wtd, Se); the arithmetic -- the gridded function's own semantics,
 # include/splash_hip.h -- runs in the HIP library over the brick's values ([ncell x nt], as getValues() gives them).
