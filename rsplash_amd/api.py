@@ -76,6 +76,17 @@ def month_ids(year, month):
 
 
 # ---------------------------------------------------------------------------- splash.point
+def _refuse_monthly_inputs(time_index):
+    """R/splash.point.R:56, 66-86: a series whose first two dates are more than 20 days apart is taken to be MONTHLY
+    and disaggregated -- tc and sw_in by linear interpolation, the rain by month2day_rain() (:460-516), which draws the
+    wet days and their amounts from R's unseeded RNG (out of scope).  Such a series is refused here
+    rather than run as if it were daily."""
+    t = np.asarray(time_index, dtype="datetime64[D]")
+    if t.size >= 2 and abs(int((t[1] - t[0]).astype(np.int64))) > 20:
+        raise ValueError("monthly inputs: disaggregate to daily first -- the reference draws the daily rain of a monthly "
+                         "series from an unseeded RNG (R/splash.point.R:66-86, month2day_rain), which has no reproducible twin")
+
+
 def splash_point(sw_in, tc, pn, lat, elev, slop=0.0, asp=0.0, soil_data=None, Au=0.0,
                  resolution=250.0, time_index=None, monthly_out=False, backend="hip"):
     """R/splash.point.R:29.  Daily series in, dict of the 9 reference outputs out
@@ -91,6 +102,7 @@ def splash_point(sw_in, tc, pn, lat, elev, slop=0.0, asp=0.0, soil_data=None, Au
         raise ValueError("soil_data = c(sand, clay, OM, gravel, bulk density (may be NaN), depth)")
     doy, year, month = time_fields(time_index)
     nt = len(doy)
+    _refuse_monthly_inputs(time_index)
     f = [_d(x) for x in (sw_in, tc, pn)]
     if any(len(x[0]) != nt for x in f):
         raise ValueError("sw_in, tc, pn and time_index must have the same length")
@@ -154,6 +166,7 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
     nt = sw.shape[0]
     ncell = int(np.prod(shp))
     doy, year, month = time_fields(time_index)
+    _refuse_monthly_inputs(time_index)
     if len(doy) != nt:
         raise ValueError("time_index length differs from the rasters' time dimension")
 

@@ -299,6 +299,11 @@ def test_host_backend_is_explicit_and_unknown_backends_are_refused(api, bourne):
     with pytest.raises(ValueError, match="backend"):
         api.splash_point(b["sw_in"], b["Ta"], b["P"], s["latitude"], s["elev_m"], 0, 0, b["soil"], 0.0, 250.0,
                          time_index=b["dates"], backend="cpu")
+    # a monthly series (first two dates > 20 days apart, R/splash.point.R:56, 66) is refused, not run as if daily
+    monthly = np.arange("2008-01", "2011-01", dtype="datetime64[M]").astype("datetime64[D]")
+    with pytest.raises(ValueError, match="monthly inputs"):
+        api.splash_point(np.ones(36), np.ones(36), np.ones(36), s["latitude"], s["elev_m"], 0, 0, b["soil"], 0.0, 250.0,
+                         time_index=monthly, backend="host")
     assert _lib.lib.splash_mod_backend(7) == -1          # SPLASH_EINVAL, setting unchanged
     assert _lib.lib.splash_mod_backend(0) in (0, 1)
     assert _lib.lib.splash_host_backend_fma() in (0, 1)

@@ -8,7 +8,8 @@
                               America grid, 72 % NA (ocean), stored as float32 (the rasters are FLT4S)
 
 These are DATA the reference ships, not reference source.  The monthly tc/pn/sw_in bricks of SA_cru
-are not converted: no code path of the reference consumes monthly forcing.
+are not converted: the reference's path for monthly forcing is the stochastic disaggregation of
+R/splash.point.R:66-86 (month2day_rain draws from R's unseeded RNG; SURVEY.md 2 #15: out of scope).
 """
 import datetime
 import json
