@@ -924,6 +924,8 @@ try {
     a.monthly = out->monthly;
     a.month0 = cal->host[t0].month_id;
     a.head_partial = (t0 > 0 && cal->host[t0 - 1].month_id == a.month0) ? 1 : 0;
+    // the last month of this call goes on in the calendar after the call's last day (a later call completes it)
+    a.tail_continues = (t0 + nt < cal->nt && cal->host[t0 + nt].month_id == cal->host[t0 + nt - 1].month_id) ? 1 : 0;
     a.nmonth = cal->host[t0 + nt - 1].month_id - a.month0 + 1;
     a.diag_acc = (long long*)out->diag_acc;
     a.basin = out->basin;

@@ -162,6 +162,7 @@ __attribute__((always_inline)) inline int cell_impl(const HostCellIn& in, HostCe
     // K5 run_all (src/SPLASH.cpp:1833-1916) + K6 sm_lim and monthly aggregation (R/splash.point.R:197-214) + K7
     const double lim_den = par[P_WMAXR] - c.RES;
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int na_days[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double dg[4] = {0, 0, 0, 0};
     const bool in_basin = out.diag_rec != nullptr;
     for (int t = 0; t < nt; t++) {
@@ -182,8 +183,11 @@ __attribute__((always_inline)) inline int cell_impl(const HostCellIn& in, HostCe
                 if (out.out[q]) out.out[q][row] = v[q];
                 else if (out.out32[q]) out.out32[q][row] = (float)v[q];
             }
-        } else {
-            for (int q = 0; q < 9; q++) acc[q] += v[q];
+        } else { // ctapply(..., FUN = mean | sum, na.rm = T), R/splash.point.R:210-211: NA days are left out of their month
+            for (int q = 0; q < 9; q++) {
+                acc[q] += (v[q] == v[q]) ? v[q] : 0.0;
+                na_days[q] += (v[q] != v[q]);
+            }
         }
         if (in_basin) {
             dg[0] += rain + snf;
@@ -195,13 +199,14 @@ __attribute__((always_inline)) inline int cell_impl(const HostCellIn& in, HostCe
         if (month_end || t == nt - 1) {
             const int m = d.month_id - in.days[0].month_id;
             if (in.monthly) {
-                const double inv_n = 1.0 / (double)d.mdays;
                 const size_t k = (size_t)m * out.ldo;
                 for (int q = 0; q < 9; q++) {
-                    const double x = (q == 0 || q == 4 || q == 8) ? acc[q] * inv_n : acc[q];
+                    // mean over the days that have a value (0 of 0: NaN, as mean(numeric(0))); sum of them
+                    const double x = (q == 0 || q == 4 || q == 8) ? acc[q] * (1.0 / (double)(d.mdays - na_days[q])) : acc[q];
                     if (out.out[q]) out.out[q][k] = x;
                     else if (out.out32[q]) out.out32[q][k] = (float)x;
                     acc[q] = 0.0;
+                    na_days[q] = 0;
                 }
             }
             if (in_basin) { // exact fixed-point limbs, as diag_add() forms them (splash_kernels.hip)

@@ -925,6 +925,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
     }
 
     double acc[9]; // monthly accumulators in output order
+    unsigned nan_days = 0u; // NA days of wn / snow / sm_lim in the current month (MONTHLY): see the month's end
     // monthly flux totals of the water balance (precip, aet, ro, bflow) accumulate in LDS, one
     // slot per lane: the day loop is register bound (256 VGPRs, spilling), and four running sums
     // kept in registers cost more in spills than four LDS adds per day do
@@ -1007,8 +1008,13 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
                             x[q], reinterpret_cast<double*>(reinterpret_cast<char*>(a.extra[q] + row) + ooff));
             }
         } else {
+            // fastmatch::ctapply(x, ind.mont, FUN = mean | sum, na.rm = T), R/splash.point.R:210-211: a NA day (a gap in
+            // the forcing and everything after it, SURVEY trap 3) is left out of its month -- the mean is over the
+            // days that have a value, the sum over them, an all-NA month is NaN (mean) or 0 (sum)
 #pragma unroll
-            for (int q = 0; q < 9; q++) acc[q] += v[q];
+            for (int q = 0; q < 9; q++) acc[q] += (v[q] == v[q]) ? v[q] : 0.0;
+            // NA days of the three means (wn, snow, sm_lim) in one register: a byte each (a month has <= 31)
+            nan_days += (v[0] != v[0] ? 1u : 0u) | (v[4] != v[4] ? 0x100u : 0u) | (v[8] != v[8] ? 0x10000u : 0u);
         }
 #ifndef SPL_DIAG_NODAY
         if (DIAG) {
@@ -1028,18 +1034,37 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
                 // mean of storages (wn, snow, sm_lim), sum of fluxes (R/splash.point.R:210-211);
                 // a month split over two calls is completed by adding to the stored partial
                 const bool partial_head = (m == 0) && a.head_partial;
-                const double inv_n = 1.0 / (double)d.mdays;
+                const bool partial_tail = !month_end; // the call ends inside the month (the series may go on: tail_continues)
                 size_t k = (size_t)m * a.ldo + co;
 #pragma unroll
                 for (int q = 0; q < 9; q++) {
                     if ((omask & (1u << q)) && (SUBSET ? valid : in_range)) { // (a skipped cell's months are written
                                                                                //  by the later call in list mode)
-                        double x = (q == 0 || q == 4 || q == 8) ? acc[q] * inv_n : acc[q];
-                        if (partial_head) x += a.out[q][k];
+                        double x = acc[q];
+                        if (q == 0 || q == 4 || q == 8) {
+                            // mean over the days that have a value: mdays - NA days (0 of 0: NaN, as mean(numeric(0)))
+                            const int na = (int)((nan_days >> (q == 0 ? 0 : (q == 4 ? 8 : 16))) & 0xFFu);
+                            const double inv_n = 1.0 / (double)(d.mdays - na);
+                            if (!partial_head) {
+                                x = acc[q] * inv_n;
+                                // a month that a later call completes: that call adds its days to this slot and knows
+                                // mdays but not this part's NA days -- with any, the month's mean cannot be completed
+                                // from one stored number: NaN (never the case for chunks that end with a month, as
+                                // splash.grid's year chunks do; without NA days: acc/mdays as before)
+                                if (partial_tail && na != 0 && a.tail_continues) x = u2d(0x7FF8000000000000ull);
+                            } else {
+                                // completing the month: stored = (first part's sum) / mdays
+                                const double prev = a.out[q][k];
+                                x = na == 0 ? acc[q] * inv_n + prev : (prev * (double)d.mdays + acc[q]) * inv_n;
+                            }
+                        } else if (partial_head) {
+                            x += a.out[q][k];
+                        }
                         a.out[q][k] = x;
                     }
                     acc[q] = 0.0;
                 }
+                nan_days = 0u;
             }
 #ifndef SPL_DIAG_NOMONTH
             if constexpr (DIAG) {

@@ -110,6 +110,7 @@ struct RunArgs {
     int monthly;
     int month0;       // month_id of day t0
     int head_partial; // month0 began before t0 (add to the stored partial)
+    int tail_continues; // the call's last month goes on after its last day (a later call adds its days to the slot)
     int nmonth;       // months touched by [t0, t0+nt)
     // K7 water-balance totals (see include/splash_hip.h): exact fixed-point limbs, added with
     // integer atomics into acc[basin][month_id][SPLASH_NDIAG+1][2]

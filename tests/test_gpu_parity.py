@@ -824,6 +824,24 @@ def test_gaps_in_the_forcing_propagate_like_NA_in_R(api, oracle):
     print(r)
 
 
+def test_monthly_aggregation_leaves_na_days_out(api, oracle):
+    """R/splash.point.R:210-211, na.rm = T (tests/test_host_backend.py has the host backend's twin of this test): the
+    month a gap falls in keeps the mean / sum of its other days, all-NA months are NaN (means) or 0 (sums) -- the
+    device's monthly outputs against the oracle's and, for the NaN pattern, the host backend's."""
+    from test_host_backend import _assert_monthly_with_gaps, _gap_case
+    d = _gap_case(oracle)
+    st = d["st"]
+    g = api.splash_grid(d["sw"], d["tc"], d["pn"], st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"],
+                        st["resolution"], time_index=d["dates"], sim_control=dict(monthly_out=True))
+    o, aux = oracle.grid(d["doy"], d["year"], d["month"], d["mid"], d["nm"], d["sw"], d["tc"], d["pn"], st["lat"],
+                         st["elev"], st["slop"], st["asp"], st["soil"], st["au"], st["resolution"], monthly_out=True)
+    _assert_monthly_with_gaps(g, o)
+    host = api.splash_grid(d["sw"], d["tc"], d["pn"], st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"],
+                           st["resolution"], time_index=d["dates"], sim_control=dict(monthly_out=True), backend="host")
+    for k in o:
+        assert np.array_equal(np.isnan(g[k]), np.isnan(host[k])), k
+
+
 def test_soil_hydro_cellpar_direct(api, oracle, sa_cru):
     """K1 alone: dev_soil_hydro's cellpar rows against orc_soil_info for every land cell of the
     reference's bundled South America soils (up to 45 % organic matter, 51 % gravel) and for

@@ -292,6 +292,43 @@ def test_unswc_grid_writes_the_references_four_files(api, oracle, tmp_path):
     assert r2["paths"]["Se"].endswith("SPLASH_v2.0_Se_top_0.3_m_monthly_2003-2003.nc")
 
 
+def _gap_case(oracle, H=1, W=16, nt=450, seed=99):
+    doy, year, month, mid, nm = oracle.calendar(2001, nt)
+    st = oracle.synth_statics(seed, H, W, 0, H * W, 1)
+    sw, tc, pn = oracle.synth_forcing(seed, H, W, 0, H * W, 0, doy, st["lat"], st["elev"])
+    tc[400, 3] = np.nan     # a gap in tc: Tt is NA, rain and snowfall NA on every possible-snow day from the start
+    sw[420, 5] = np.nan     # one day without radiation: that day's fluxes NA, the state after it NA for good
+    pn[380, 6] = np.nan
+    tc[100, 7] = np.nan     # inside the spin-up year
+    return dict(doy=doy, year=year, month=month, mid=mid, nm=nm, st=st, sw=sw, tc=tc, pn=pn,
+                dates=np.datetime64("2001-01-01") + np.arange(nt))
+
+
+def _assert_monthly_with_gaps(g, o):
+    for k in o:
+        assert np.array_equal(np.isnan(g[k]), np.isnan(o[k])), f"{k}: NaN pattern of the months differs"
+        close(g[k], o[k], "monthly with gaps." + k)
+    gaps = [3, 5, 6]
+    # the month the gap falls in has a value (the mean / sum of the days before it), the months after it NaN (means) or 0 (sums)
+    assert np.isfinite(o["wn"][13, 3]) and np.isnan(o["wn"][14, 3]) and o["pet"][14, 3] == 0.0
+    assert np.isfinite(o["wn"][13, 5]) and np.isnan(o["wn"][14, 5]) and o["pet"][14, 5] > 0.0   # (pet needs no state)
+    assert np.isfinite(g["wn"][:12, gaps]).all()
+
+
+def test_monthly_aggregation_leaves_na_days_out(api, oracle):
+    """R/splash.point.R:210-211: ctapply(x, ind.mont, FUN = mean | sum, na.rm = T) -- a day without a value (a gap in
+    the forcing, and every day after the state has turned NA) is left out of its month: the month of the gap keeps
+    the mean / sum of its other days, an all-NA month is NaN (means: wn, snow, sm_lim) or 0 (sums).  Rounds 1-5
+    summed the NaN in: every month from the gap on was NaN.  Host backend against the oracle, all nine series."""
+    d = _gap_case(oracle)
+    st = d["st"]
+    g = api.splash_grid(d["sw"], d["tc"], d["pn"], st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"],
+                        st["resolution"], time_index=d["dates"], sim_control=dict(monthly_out=True), backend="host")
+    o, aux = oracle.grid(d["doy"], d["year"], d["month"], d["mid"], d["nm"], d["sw"], d["tc"], d["pn"], st["lat"],
+                         st["elev"], st["slop"], st["asp"], st["soil"], st["au"], st["resolution"], monthly_out=True)
+    _assert_monthly_with_gaps(g, o)
+
+
 def test_host_backend_is_explicit_and_unknown_backends_are_refused(api, bourne):
     import ctypes as C
     from rsplash_amd import _lib
