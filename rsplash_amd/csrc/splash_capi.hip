@@ -1218,67 +1218,28 @@ try {
 
 extern "C" int splash_host_backend_fma(void) { return host_backend_fma() ? 1 : 0; }
 
-// unSWC for host buffers: wn [nt][ncell], soil [6][ncell] -> wn_z, wtd, theta [nt][ncell]
-extern "C" int splash_unswc_run_backend(int backend, size_t ncell, int nt, const double* wn, const double* soil,
-                                        double uns_depth, double* wn_z, double* wtd, double* theta,
-                                        char* err, size_t errlen)
-try {
-    if (!wn || !soil) return fail(SPLASH_EINVAL, err, errlen, "unswc_run: NULL input");
-    if (backend != SPLASH_BACKEND_HIP && backend != SPLASH_BACKEND_HOST)
-        return fail(SPLASH_EINVAL, err, errlen, "unswc_run: unknown backend %d", backend);
-    if (backend == SPLASH_BACKEND_HOST) { // explicit choice (ABI 6): the same two functions the kernel runs, on this thread
-        if (ncell && nt > 0) host_unswc(ncell, nt, wn, soil, uns_depth, wn_z, wtd, theta);
-        return SPLASH_OK;
-    }
-    if (int rc = enter_device(err, errlen)) return rc;
-    if (ncell == 0 || nt <= 0) return SPLASH_OK;
-    const size_t n = ncell * (size_t)nt;
-    DevBuf dw, ds, dz, dt_, dh;
-    HIP_TRY(dw.alloc(n * 8), err, errlen);
-    HIP_TRY(ds.alloc(6 * ncell * 8), err, errlen);
-    HIP_TRY(hipMemcpy(dw.p, wn, n * 8, hipMemcpyHostToDevice), err, errlen);
-    HIP_TRY(hipMemcpy(ds.p, soil, 6 * ncell * 8, hipMemcpyHostToDevice), err, errlen);
-    if (wn_z) HIP_TRY(dz.alloc(n * 8), err, errlen);
-    if (wtd) HIP_TRY(dt_.alloc(n * 8), err, errlen);
-    if (theta) HIP_TRY(dh.alloc(n * 8), err, errlen);
-    int rc = splash_dev_unswc(ncell, nt, dw.as<double>(), ncell, ds.as<double>(), uns_depth,
-                              wn_z ? dz.as<double>() : nullptr, wtd ? dt_.as<double>() : nullptr,
-                              theta ? dh.as<double>() : nullptr, ncell, nullptr);
-    if (rc) return fail(rc, err, errlen, "%s", g_err.c_str());
-    HIP_TRY(hipDeviceSynchronize(), err, errlen);
-    if (wn_z) HIP_TRY(hipMemcpy(wn_z, dz.p, n * 8, hipMemcpyDeviceToHost), err, errlen);
-    if (wtd) HIP_TRY(hipMemcpy(wtd, dt_.p, n * 8, hipMemcpyDeviceToHost), err, errlen);
-    if (theta) HIP_TRY(hipMemcpy(theta, dh.p, n * 8, hipMemcpyDeviceToHost), err, errlen);
-    return SPLASH_OK;
-} catch (...) {
-    return exception_code(err, errlen, "splash_unswc_run");
-}
-
-extern "C" int splash_unswc_run(size_t ncell, int nt, const double* wn, const double* soil, double uns_depth, double* wn_z,
-                                double* wtd, double* theta, char* err, size_t errlen)
+// unSWC / unSWC.grid for host buffers: wn [nt][ncell], soil [6][ncell] -> up to four [nt][ncell] arrays (any NULL), in
+// column blocks sized to the device's free memory (a brick of 4096 x 4096 x 365 is 49 GB per array).
+// grid_form = false: the site function (R/unsSWC.R: wn_z, wtd, theta); true: the gridded one (R/unsSWC.grid.R: w_z, wtd,
+// Se, theta_mean) -- splash_unswc.hpp has the two semantics.
+static int unswc_host_buffers(bool grid_form, const char* who, int backend, size_t ncell, int nt, const double* wn,
+                              const double* soil, double uns_depth, double* const outs[4], char* err, size_t errlen)
 {
-    return splash_unswc_run_backend(SPLASH_BACKEND_HIP, ncell, nt, wn, soil, uns_depth, wn_z, wtd, theta, err, errlen);
-}
-
-// unSWC.grid for host buffers: wn [nt][ncell], soil [6][ncell] -> w_z, wtd, Se, theta_mean [nt][ncell] (any NULL), in
-// column blocks sized to the device's free memory (a brick of 4096 x 4096 x 365 is 49 GB per array)
-extern "C" int splash_unswc_grid_run(int backend, size_t ncell, int nt, const double* wn, const double* soil,
-                                     double uns_depth, double* w_z, double* wtd, double* se, double* theta_mean,
-                                     char* err, size_t errlen)
-try {
-    if (!wn || !soil) return fail(SPLASH_EINVAL, err, errlen, "unswc_grid_run: NULL input");
-    if (!(uns_depth > 0)) return fail(SPLASH_EINVAL, err, errlen, "unswc_grid_run: uns_depth must be positive");
+    if (!wn || !soil) return fail(SPLASH_EINVAL, err, errlen, "%s: NULL input", who);
+    if (!(uns_depth > 0)) return fail(SPLASH_EINVAL, err, errlen, "%s: uns_depth must be positive", who);
     if (backend != SPLASH_BACKEND_HIP && backend != SPLASH_BACKEND_HOST)
-        return fail(SPLASH_EINVAL, err, errlen, "unswc_grid_run: unknown backend %d", backend);
-    double* const outs[4] = {w_z, wtd, se, theta_mean};
-    if (backend == SPLASH_BACKEND_HOST) {
-        if (ncell && nt > 0) host_unswc_grid(ncell, nt, wn, soil, uns_depth, w_z, wtd, se, theta_mean);
+        return fail(SPLASH_EINVAL, err, errlen, "%s: unknown backend %d", who, backend);
+    if (backend == SPLASH_BACKEND_HOST) { // explicit choice (ABI 6): the same functions the kernels run, on this thread
+        if (ncell && nt > 0) {
+            if (grid_form) host_unswc_grid(ncell, nt, wn, soil, uns_depth, outs[0], outs[1], outs[2], outs[3]);
+            else host_unswc(ncell, nt, wn, soil, uns_depth, outs[0], outs[1], outs[2]);
+        }
         return SPLASH_OK;
     }
     if (int rc = enter_device(err, errlen)) return rc;
     if (ncell == 0 || nt <= 0) return SPLASH_OK;
     int n_out = 0;
-    for (double* o : outs) n_out += o != nullptr;
+    for (int k = 0; k < 4; k++) n_out += outs[k] != nullptr;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b), err, errlen);
     int cur_dev = 0;
@@ -1293,15 +1254,17 @@ try {
     HIP_TRY(d_soil.alloc(6 * nb * 8), err, errlen);
     for (int k = 0; k < 4; k++)
         if (outs[k]) HIP_TRY(d_out[k].alloc((size_t)nt * nb * 8), err, errlen);
+    auto dp = [&](int k) { return outs[k] ? d_out[k].as<double>() : nullptr; };
     for (size_t c0 = 0; c0 < ncell; c0 += nb) {
         const size_t n = std::min(nb, ncell - c0);
         HIP_TRY(hipMemcpy2D(d_wn.p, n * 8, wn + c0, ncell * 8, n * 8, (size_t)nt, hipMemcpyHostToDevice), err, errlen);
         HIP_TRY(hipMemcpy2D(d_soil.p, n * 8, soil + c0, ncell * 8, n * 8, 6, hipMemcpyHostToDevice), err, errlen);
-        HIP_TRY(launch_unswc_grid(n, nt, d_wn.as<double>(), n, d_soil.as<double>(), uns_depth,
-                                  outs[0] ? d_out[0].as<double>() : nullptr, outs[1] ? d_out[1].as<double>() : nullptr,
-                                  outs[2] ? d_out[2].as<double>() : nullptr, outs[3] ? d_out[3].as<double>() : nullptr, n,
-                                  nullptr),
-                err, errlen);
+        if (grid_form)
+            HIP_TRY(launch_unswc_grid(n, nt, d_wn.as<double>(), n, d_soil.as<double>(), uns_depth, dp(0), dp(1), dp(2), dp(3),
+                                      n, nullptr), err, errlen);
+        else
+            HIP_TRY(launch_unswc(n, nt, d_wn.as<double>(), n, d_soil.as<double>(), uns_depth, dp(0), dp(1), dp(2), n, nullptr),
+                    err, errlen);
         HIP_TRY(hipDeviceSynchronize(), err, errlen);
         for (int k = 0; k < 4; k++)
             if (outs[k])
@@ -1309,6 +1272,30 @@ try {
                         errlen);
     }
     return SPLASH_OK;
+}
+
+extern "C" int splash_unswc_run_backend(int backend, size_t ncell, int nt, const double* wn, const double* soil,
+                                        double uns_depth, double* wn_z, double* wtd, double* theta,
+                                        char* err, size_t errlen)
+try {
+    double* const outs[4] = {wn_z, wtd, theta, nullptr};
+    return unswc_host_buffers(false, "unswc_run", backend, ncell, nt, wn, soil, uns_depth, outs, err, errlen);
+} catch (...) {
+    return exception_code(err, errlen, "splash_unswc_run");
+}
+
+extern "C" int splash_unswc_run(size_t ncell, int nt, const double* wn, const double* soil, double uns_depth, double* wn_z,
+                                double* wtd, double* theta, char* err, size_t errlen)
+{
+    return splash_unswc_run_backend(SPLASH_BACKEND_HIP, ncell, nt, wn, soil, uns_depth, wn_z, wtd, theta, err, errlen);
+}
+
+extern "C" int splash_unswc_grid_run(int backend, size_t ncell, int nt, const double* wn, const double* soil,
+                                     double uns_depth, double* w_z, double* wtd, double* se, double* theta_mean,
+                                     char* err, size_t errlen)
+try {
+    double* const outs[4] = {w_z, wtd, se, theta_mean};
+    return unswc_host_buffers(true, "unswc_grid_run", backend, ncell, nt, wn, soil, uns_depth, outs, err, errlen);
 } catch (...) {
     return exception_code(err, errlen, "splash_unswc_grid_run");
 }

@@ -1032,6 +1032,14 @@ def test_unswc_bourne_and_grid(api, oracle, bourne):
     wn[0] = sat[:, 1]
     wn[1] = sat[:, 0]
     got = api.unSWC_cells(soil, 0.3, wn)
+    os.environ["SPLASH_HIP_FAKE_DEVICE_BYTES"] = "1"        # a pretend device: column blocks of 256 cells (192 here: one)
+    try:
+        wide = np.concatenate([wn] * 3, axis=1)              # 576 cells: three blocks
+        blocked = api.unSWC_cells(np.concatenate([soil] * 3, axis=1), 0.3, wide)
+    finally:
+        os.environ.pop("SPLASH_HIP_FAKE_DEVICE_BYTES")
+    for k in got:
+        assert np.array_equal(blocked[k], np.concatenate([got[k]] * 3, axis=1), equal_nan=True), "column blocks: " + k
     bad = 0
     for j in range(H * W):
         ref = oracle.unswc(soil[:, j], 0.3, wn[:, j])
