@@ -1056,6 +1056,7 @@ __global__ __launch_bounds__(kBlock, SPLASH_RUNALL_WPE) void k_run_all(RunArgs a
                                 // completing the month: stored = (first part's sum) / mdays
                                 const double prev = a.out[q][k];
                                 x = na == 0 ? acc[q] * inv_n + prev : (prev * (double)d.mdays + acc[q]) * inv_n;
+                                if (partial_tail && na != 0 && a.tail_continues) x = u2d(0x7FF8000000000000ull); // (a third part follows)
                             }
                         } else if (partial_head) {
                             x += a.out[q][k];
