@@ -720,6 +720,33 @@ def test_device_pipeline_chunking_and_generator(api, oracle):
             cnt = torch.bincount(midt, minlength=nm).to(torch.float64)
             agg = agg / cnt[:, None]
         assert torch.allclose(mon[k], agg, rtol=1e-12, atol=1e-12), k
+    # (iv) NA days (R/splash.point.R:210-211, na.rm = T) in a month that two calls share (cut at t = 45: February has
+    # days 31..58): a NA day in the SECOND part (t = 50, cells 0..9) -- the month's means are over the days that have a
+    # value, as in one call; a NA day in the FIRST part (t = 40, cells 10..19) cannot be carried in the one stored
+    # number: those means are NaN (the sums of the fluxes before the gap still add up, and the months before too)
+    pn2 = pn.clone()
+    pn2[50, 0:10] = float("nan")
+    pn2[40, 10:20] = float("nan")
+    res = {}
+    for cuts in (((0, nt),), ((0, 45), (45, nt))):
+        state.copy_(state0)
+        mon2 = {k: torch.zeros(nm, n, **f64) for k in names}
+        for t0, t1 in cuts:
+            m0 = int(mid[t0])
+            api.dev_run_all(cal, t0, t1 - t0, n, sw[t0:], tc[t0:], pn2[t0:], n, Tt, par, n, state, n,
+                            {k: mon2[k][m0:] for k in names}, n, monthly=True)
+        torch.cuda.synchronize()
+        res[len(cuts)] = {k: v.cpu().numpy() for k, v in mon2.items()}
+    a, b = res[1], res[2]
+    for k in names:
+        assert np.isfinite(a[k][1, :20]).all(), k                                  # one call: February has a value everywhere
+        assert np.allclose(a[k][:, 20:], b[k][:, 20:], rtol=1e-12, atol=1e-12), k  # cells without a gap: as before
+        assert np.allclose(a[k][:, :10], b[k][:, :10], rtol=1e-12, atol=1e-12, equal_nan=True), k   # gap in the second part
+        assert np.allclose(a[k][0, 10:20], b[k][0, 10:20], rtol=1e-12), k          # January of the others
+        if k in ("wn", "snow"):
+            assert np.isnan(b[k][1, 10:20]).all(), k                               # gap in the first part: the mean is given up
+        else:
+            assert np.allclose(a[k][1, 10:20], b[k][1, 10:20], rtol=1e-12, atol=1e-12), k   # ... the sums are not
     # row-block partition == whole grid (what each rank of a multi-GPU run computes)
     state.copy_(state0)
     half = n // 2
