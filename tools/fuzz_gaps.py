@@ -40,6 +40,18 @@ for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
             msgs.append(f"NaN pattern of {k}: gpu {int(np.isnan(a).sum())} oracle {int(np.isnan(b).sum())}")
         elif _bad(np.nan_to_num(a), np.nan_to_num(b)).any():
             msgs.append(f"{k} out of tolerance on a gappy cell")
+    # the same gaps through the monthly aggregation (R/splash.point.R:210-211, na.rm = T: NA days are left out of their
+    # month -- the month of a gap keeps the mean / sum of its other days, all-NA months are NaN or 0), all nine series
+    gm = api.splash_grid(sw, tc, pn, st["elev"], st["soil"], st["lat"], st["slop"], st["asp"], st["au"],
+                         st["resolution"], time_index=dates, sim_control=dict(monthly_out=True), backend=backend)
+    refm, _ = o.grid(doy, year, month, mid, nm, sw, tc, pn, st["lat"], st["elev"], st["slop"], st["asp"],
+                     st["soil"], st["au"], st["resolution"], monthly_out=True)
+    for k in refm:
+        a, b = gm[k][:, cells], refm[k][:, cells]
+        if not np.array_equal(np.isnan(a), np.isnan(b)):
+            msgs.append(f"monthly NaN pattern of {k}: product {int(np.isnan(a).sum())} oracle {int(np.isnan(b).sum())}")
+        elif _bad(np.nan_to_num(a), np.nan_to_num(b)).any():
+            msgs.append(f"monthly {k} out of tolerance on a gappy cell")
     bad += len(msgs)
     print(f"case {case}: {nt} d, NaN cell-days in outputs {int(np.isnan(ref['wn'][:, cells]).sum())}: {'ok' if not msgs else msgs}", flush=True)
 print("problems", bad)
