@@ -418,6 +418,10 @@ int splash_grid_run(const splash_grid_in* in, const splash_opts* opt, const spla
  * processed in time chunks is the maximum of the chunks' thresholds (NaN if any is NaN). */
 int splash_snow_threshold_run(size_t ncell, int nt, const double* tc, const float* tc_f32,
                               const double* lat, const double* elev, double* tt, char* err, size_t errlen);
+/* (ABI 6) the same with the backend chosen by the caller (SPLASH_BACKEND_HOST: on the calling thread, for a series in
+ * time chunks on the host backend; splash_snow_threshold_run == backend HIP) */
+int splash_snow_threshold_run_backend(int backend, size_t ncell, int nt, const double* tc, const float* tc_f32,
+                                      const double* lat, const double* elev, double* tt, char* err, size_t errlen);
 
 typedef struct splash_grid_job splash_grid_job;
 int splash_grid_submit(const splash_grid_in* in, const splash_opts* opt, const splash_grid_out* out,

@@ -60,7 +60,8 @@ splash.point <- function(sw_in, tc, pn, lat, elev, slop = 0, asp = 0, soil_data,
 # later one continues from res$state_end of the chunk before with ai0 = aux[, 2] of the FIRST chunk.  Chunks of
 # whole calendar years give the monthly outputs of the undivided run, bit for bit (tested on the Python twin,
 # rsplash_amd/grid.py: chunk_years).
-.splash_snow_threshold <- function(tc, lat, elev) .Call("C_splash_snow_threshold", tc, as.numeric(lat), as.numeric(elev))
+.splash_snow_threshold <- function(tc, lat, elev, backend = 0L)      # backend = 1L with devices = -1L: the host backend
+  .Call("C_splash_snow_threshold", tc, as.numeric(lat), as.numeric(elev), as.integer(backend))
 .splash_grid_chunk <- function(sw_in, tc, pn, stat, soil, Au, ztime, monthly_out, tt, state0 = NULL, ai0 = NULL,
                                devices = 0L) {
   tf <- .time_fields(ztime)

@@ -203,8 +203,8 @@ SEXP C_splash_grid_chunk(SEXP sw_in, SEXP tc, SEXP pn, SEXP stat, SEXP soil, SEX
     return res;
 }
 
-/* the snowfall threshold of one chunk of tc ([ncell x nt] matrix): numeric(ncell) */
-SEXP C_splash_snow_threshold(SEXP tc, SEXP lat, SEXP elev)
+/* the snowfall threshold of one chunk of tc ([ncell x nt] matrix): numeric(ncell); backend 0 = HIP, 1 = host (ABI 6) */
+SEXP C_splash_snow_threshold(SEXP tc, SEXP lat, SEXP elev, SEXP backend)
 {
     SEXP dim = getAttrib(tc, R_DimSymbol);
     if (isNull(dim) || LENGTH(dim) != 2 || !isReal(tc)) error("tc must be a numeric [ncell x nt] matrix");
@@ -213,7 +213,8 @@ SEXP C_splash_snow_threshold(SEXP tc, SEXP lat, SEXP elev)
     if ((size_t)XLENGTH(lat) != ncell || (size_t)XLENGTH(elev) != ncell) error("lat and elev must be numeric(ncell)");
     SEXP res = PROTECT(allocVector(REALSXP, (R_xlen_t)ncell));
     char err[512];
-    int rc = splash_snow_threshold_run(ncell, nt, REAL(tc), NULL, REAL(lat), REAL(elev), REAL(res), err, sizeof err);
+    int rc = splash_snow_threshold_run_backend(asInteger(backend), ncell, nt, REAL(tc), NULL, REAL(lat), REAL(elev), REAL(res),
+                                               err, sizeof err);
     UNPROTECT(1);
     if (rc != SPLASH_OK) error("splash_snow_threshold_run failed (%d): %s", rc, err);
     return res;
@@ -349,7 +350,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"C_splash_grid_submit", (DL_FUNC)&C_splash_grid_submit, 12},
     {"C_splash_grid_wait", (DL_FUNC)&C_splash_grid_wait, 1},
     {"C_splash_grid_chunk", (DL_FUNC)&C_splash_grid_chunk, 14},
-    {"C_splash_snow_threshold", (DL_FUNC)&C_splash_snow_threshold, 3},
+    {"C_splash_snow_threshold", (DL_FUNC)&C_splash_snow_threshold, 4},
     {"C_splash_point_run", (DL_FUNC)&C_splash_point_run, 15},
     {"C_splash_unswc_run", (DL_FUNC)&C_splash_unswc_run, 4},
     {"C_splash_unswc_grid_run", (DL_FUNC)&C_splash_unswc_grid_run, 4},

@@ -257,10 +257,11 @@ def splash_grid(sw_in, tc, pn, elev, soil, lat, slop, asp, Au=None, resolution=2
                          want_diag, diag, acc, basin)
 
 
-def snow_threshold(tc, lat, elev):
+def snow_threshold(tc, lat, elev, backend="hip"):
     """K2 on host arrays (splash_snow_threshold_run): Tt [ncell] = max(tc[p_snow >= 0.5]) of the series
     tc [nt, ...] (R/splash.point.R:120-122); -inf where no day qualifies, NaN where tc has a gap.  The
-    threshold of a series processed in time chunks is np.maximum over the chunks' thresholds."""
+    threshold of a series processed in time chunks is np.maximum over the chunks' thresholds.
+    backend="host" (ABI 6): on the calling thread."""
     f32 = getattr(tc, "dtype", None) == np.float32
     a = np.ascontiguousarray(np.asarray(tc, dtype=np.float32 if f32 else np.float64))
     nt, shp = a.shape[0], a.shape[1:]
@@ -269,9 +270,9 @@ def snow_threshold(tc, lat, elev):
     ea, el = _d(np.broadcast_to(np.asarray(elev, dtype=np.float64), shp).reshape(n))
     out = np.empty(n)
     err = C.create_string_buffer(256)
-    rc = lib.splash_snow_threshold_run(n, nt, None if f32 else a.ctypes.data_as(_dp),
-                                       a.ctypes.data_as(C.POINTER(C.c_float)) if f32 else None, ll, el,
-                                       out.ctypes.data_as(_dp), err, 256)
+    rc = lib.splash_snow_threshold_run_backend(_lib.backend_code(backend), n, nt, None if f32 else a.ctypes.data_as(_dp),
+                                               a.ctypes.data_as(C.POINTER(C.c_float)) if f32 else None, ll, el,
+                                               out.ctypes.data_as(_dp), err, 256)
     if rc:
         raise SplashError(f"splash_snow_threshold_run failed ({rc}): {err.value.decode()}")
     return out.reshape(shp)

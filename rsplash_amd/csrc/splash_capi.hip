@@ -1302,12 +1302,19 @@ try {
 
 // K2 on host buffers (ABI 5): the snowfall threshold of a tc series, for callers that process a long
 // series in time chunks -- the threshold of the whole series is the maximum of the chunks' (R/splash.point.R:120-122).
-extern "C" int splash_snow_threshold_run(size_t ncell, int nt, const double* tc, const float* tc_f32,
-                                         const double* lat, const double* elev, double* tt, char* err, size_t errlen)
+extern "C" int splash_snow_threshold_run_backend(int backend, size_t ncell, int nt, const double* tc, const float* tc_f32,
+                                                 const double* lat, const double* elev, double* tt, char* err,
+                                                 size_t errlen)
 try {
     if (!lat || !elev || !tt || ((tc != nullptr) == (tc_f32 != nullptr)) || nt < 1)
         return fail(SPLASH_EINVAL, err, errlen,
                     "snow_threshold_run: NULL argument, nt < 1, or not exactly one of tc / tc_f32");
+    if (backend != SPLASH_BACKEND_HIP && backend != SPLASH_BACKEND_HOST)
+        return fail(SPLASH_EINVAL, err, errlen, "snow_threshold_run: unknown backend %d", backend);
+    if (backend == SPLASH_BACKEND_HOST) { // explicit choice (ABI 6): a series in time chunks without a GPU
+        host_snow_threshold(ncell, nt, tc, tc_f32, lat, elev, tt);
+        return SPLASH_OK;
+    }
     if (int rc = enter_device(err, errlen)) return rc;
     if (ncell == 0) return SPLASH_OK;
     size_t free_b = 0, total_b = 0;
@@ -1341,6 +1348,12 @@ try {
     return SPLASH_OK;
 } catch (...) {
     return exception_code(err, errlen, "splash_snow_threshold_run");
+}
+
+extern "C" int splash_snow_threshold_run(size_t ncell, int nt, const double* tc, const float* tc_f32, const double* lat,
+                                         const double* elev, double* tt, char* err, size_t errlen)
+{
+    return splash_snow_threshold_run_backend(SPLASH_BACKEND_HIP, ncell, nt, tc, tc_f32, lat, elev, tt, err, errlen);
 }
 
 // static rasters on host buffers: R/splash.grid.R:96-110 + upslope_area() (R/upslope_area.R:12-58)

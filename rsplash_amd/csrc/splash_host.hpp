@@ -166,6 +166,8 @@ int host_cell_run(const HostCellIn& in, HostCellOut& out);
 bool host_backend_fma();
 void host_mod_spin_up(const double* par, int n, const DayRec* days, const double* sw, const double* tc, const double* pn,
                       const double* snowfall, double* const series[7], int* passes);
+void host_snow_threshold(size_t ncell, int nt, const double* tc, const float* tc32, const double* lat, const double* elev,
+                         double* tt);
 void host_unswc(size_t ncell, int nt, const double* wn, const double* soil, double uns_depth, double* wn_z, double* wtd,
                 double* theta);
 void host_unswc_grid(size_t ncell, int nt, const double* wn, const double* soil, double uns_depth, double* w_z,

@@ -331,6 +331,25 @@ __attribute__((always_inline)) inline void unswc_grid_impl(size_t ncell, int nt,
     }
 }
 
+// K2 on host arrays (R/splash.point.R:120-122; k_snow_threshold): Tt = max(tc[p_snow >= 0.5]) per cell, NA if any tc is
+template <class T>
+__attribute__((always_inline)) inline void snow_threshold_impl(size_t ncell, int nt, const T* tc, const double* lat,
+                                                               const double* elev, double* tt)
+{
+    for (size_t i = 0; i < ncell; i++) {
+        const double e1 = elev[i] * 0.0004596581, e2 = std::fabs(lat[i]) * 0.0110592101;
+        double best = -std::numeric_limits<double>::infinity();
+        bool gap = false;
+        for (int t = 0; t < nt; t++) {
+            const double v = (double)tc[(size_t)t * ncell + i];
+            const double x = snow_logit(v, e1, e2);
+            if (x <= kSnowLogitMax && v > best) best = v;
+            gap |= (x != x);
+        }
+        tt[i] = gap ? std::numeric_limits<double>::quiet_NaN() : best;
+    }
+}
+
 // Two builds of every driver: the generic x86-64 one and one for cores with FMA (every x86 server core since
 // 2013), chosen once at run time.  The Horner chains of splash_math.hpp are fma() calls: without the target
 // attribute each is a call into libm, with it one vfmadd instruction (measured on the Bourne site: see
@@ -384,6 +403,19 @@ SPL_FMA_TARGET void unswc_grid_fma(size_t ncell, int nt, const double* wn, const
     unswc_grid_impl(ncell, nt, wn, soil, d, a, b, c, e);
 }
 
+void snow_threshold_generic(size_t ncell, int nt, const double* tc, const float* tc32, const double* lat,
+                            const double* elev, double* tt)
+{
+    if (tc) snow_threshold_impl(ncell, nt, tc, lat, elev, tt);
+    else snow_threshold_impl(ncell, nt, tc32, lat, elev, tt);
+}
+SPL_FMA_TARGET void snow_threshold_fma(size_t ncell, int nt, const double* tc, const float* tc32, const double* lat,
+                                       const double* elev, double* tt)
+{
+    if (tc) snow_threshold_impl(ncell, nt, tc, lat, elev, tt);
+    else snow_threshold_impl(ncell, nt, tc32, lat, elev, tt);
+}
+
 } // namespace
 
 bool host_backend_fma()
@@ -413,6 +445,13 @@ void host_mod_run_all(const double* par, int nt, const DayRec* days, const doubl
 {
     if (host_backend_fma()) mod_run_fma(par, nt, days, sw, tc, pn, snowfall, st0, dst);
     else mod_run_generic(par, nt, days, sw, tc, pn, snowfall, st0, dst);
+}
+
+void host_snow_threshold(size_t ncell, int nt, const double* tc, const float* tc32, const double* lat, const double* elev,
+                         double* tt)
+{
+    if (host_backend_fma()) snow_threshold_fma(ncell, nt, tc, tc32, lat, elev, tt);
+    else snow_threshold_generic(ncell, nt, tc, tc32, lat, elev, tt);
 }
 
 void host_unswc(size_t ncell, int nt, const double* wn, const double* soil, double uns_depth, double* wn_z, double* wtd,

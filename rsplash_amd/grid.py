@@ -128,7 +128,7 @@ def year_chunks(ztime, chunk_years):
 
 def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control=None, *,
                 devices=None, inflight=2, block_rows=None, statics=None, out_dtype=np.float64,
-                want_diag=False, basin=None, n_basin=0, progress=None, chunk_years=None):
+                want_diag=False, basin=None, n_basin=0, progress=None, chunk_years=None, backend="hip"):
     """R/splash.grid.R:28.  sw_in, tc, pn: Raster bricks [nl, H, W] with layer dates (`z`, taken from
     pn like getZ(pn), :144); elev: Raster [H, W]; soil: Raster [6, H, W] (sand, clay, OM, gravel, bulk
     density, depth).  sim_control = dict(monthly_out=True, inmem=False) as the reference's default.
@@ -145,7 +145,10 @@ def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control
     snowfall threshold of the whole series (the maximum of the chunks'), the first chunk runs with the
     spin-up, every later one continues from the state the one before ended in (splash_grid_in.state0 /
     ai0 / tt, ABI 5) while the results of the one before are being written -- bit for bit the undivided
-    run."""
+    run.
+    backend="host" (ABI 6): every block on CPU threads, the library's own day step compiled for the host -- for grids
+    of a few thousand cells, and for running THIS loop (blocks in flight, chunks, bricks) where there is no GPU.  The
+    static rasters are device kernels: pass `statics` (lat, slop, asp, resolution, Au) then.  Never chosen for you."""
     ctl = dict(monthly_out=True, inmem=False)
     ctl.update(sim_control or {})
     monthly, inmem = bool(ctl["monthly_out"]), bool(ctl["inmem"])
@@ -159,6 +162,9 @@ def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control
     if np.shape(soil.values)[0] != 6:
         raise ValueError("soil needs six layers: sand, clay, OM, gravel, bulk density, depth")
     H, W = elev.nrow, elev.ncol
+    if statics is None and backend != "hip":
+        raise ValueError("backend='host': the static rasters (terrain, upslope area) are device kernels -- pass statics=dict("
+                         "lat, slop, asp, resolution, Au)")
     st = statics or grid_statics(elev)
     z_out, _, _, y0, y1 = _io.output_time_axis(ztime, monthly)
     nl = z_out.size
@@ -192,7 +198,7 @@ def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control
             cut(st["lat"]), cut(st["slop"]), cut(st["asp"]), cut(st["Au"]), cut(st["resolution"]),
             time_index=ztime, sim_control=dict(monthly_out=monthly), devices=devices, submit=True,
             mem_fraction=0.8 / inflight, want_state=False, out_dtype=out_dtype, want_diag=want_diag,
-            basin=None if basin is None else cut(np.asarray(basin).reshape(H, W)), n_basin=n_basin)
+            basin=None if basin is None else cut(np.asarray(basin).reshape(H, W)), n_basin=n_basin, backend=backend)
 
     def store(res, r0, nr, t0_out, m0):
         nonlocal acc_total
@@ -221,7 +227,7 @@ def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control
                 ev, so = elev.rows(r0, r1), soil.rows(r0, r1)
                 tt = None
                 for t0, t1 in tcs:   # Tt = max(tc[p_snow >= 0.5]) over the WHOLE series (R/splash.point.R:120-122)
-                    tk = api.snow_threshold(tc.rows(r0, r1, t0, t1), st_b["lat"], ev)
+                    tk = api.snow_threshold(tc.rows(r0, r1, t0, t1), st_b["lat"], ev, backend=backend)
                     tt = tk if tt is None else np.maximum(tt, tk)
                 bas = None if basin is None else cut(np.asarray(basin).reshape(H, W))
                 state = ai = None
@@ -237,7 +243,7 @@ def splash_grid(sw_in, tc, pn, elev, soil, outdir=None, tmpdir=None, sim_control
                         st_b["lat"], st_b["slop"], st_b["asp"], st_b["Au"], st_b["resolution"],
                         time_index=ztime[t0:t1], sim_control=dict(monthly_out=monthly), devices=devices, submit=True,
                         mem_fraction=0.8, want_state=True, want_aux=True, out_dtype=out_dtype, want_diag=want_diag,
-                        basin=bas, n_basin=n_basin, tt=tt, state0=state, ai0=ai)
+                        basin=bas, n_basin=n_basin, tt=tt, state0=state, ai0=ai, backend=backend)
                     jobs.append(job)
                     if prev is not None:   # written while this chunk computes
                         store(res_p, r0, nr, prev[1], prev[2])
