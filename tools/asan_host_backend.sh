@@ -16,4 +16,4 @@ done
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 echo "# sanitized host build: $SRC"
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:verify_asan_link_order=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
-  SPLASH_HIP_LIBRARY=$D/librsplash_hip.so python -m pytest tests/test_host_backend.py -q -k "not cpp_host_mirror" 2>&1 | tail -5
+  SPLASH_HIP_LIBRARY=$D/librsplash_hip.so python -m pytest tests/test_host_backend.py tests/test_grid_host.py tests/test_readme_example.py -q -m "not gpu" -k "not cpp_host_mirror" 2>&1 | tail -5
