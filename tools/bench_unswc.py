@@ -59,3 +59,27 @@ dt = time.perf_counter() - t0
 line["cpu_baseline"] = {"value": 64 * nt * 50 / dt, "unit": "cell-steps/s", "cores": 1, "kind": "port",
                         "sample": f"64 cells x {nt*50} steps"}
 print(json.dumps(line))
+# the gridded function (R/unsSWC.grid.R: its own semantics and four rasters, k_unswc_grid): 8 B read + 32 B written
+outs4 = outs + [torch.empty(nt, n, **f64)]
+for _ in range(2):
+    api.dev_unswc_grid(n, nt, wn, n, soil, 0.3, *outs4, n, stream=st.cuda_stream)
+torch.cuda.synchronize()
+ev = []
+for _ in range(5):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(st)
+    api.dev_unswc_grid(n, nt, wn, n, soil, 0.3, *outs4, n, stream=st.cuda_stream)
+    b.record(st)
+    ev.append((a, b))
+torch.cuda.synchronize()
+ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+line2 = {"kernel": "k_unswc_grid", "cells": n, "steps": nt, "avg_launch_ms": ms, "cell_steps_per_s": units / ms * 1e3,
+         "roofline": {"bound": "hbm", "alg_bytes_per_unit": 40.0, "achieved": 40.0 * units / ms / 1e6, "peak": 8000.0,
+                      "unit": "GB/s", "frac": 40.0 * units / ms / 1e6 / 8000.0}}
+t0 = time.perf_counter()
+for j in range(64):
+    o.unswc_grid(hs[:, j], 0.3, np.tile(hw[:, j], 50))
+dt = time.perf_counter() - t0
+line2["cpu_baseline"] = {"value": 64 * nt * 50 / dt, "unit": "cell-steps/s", "cores": 1, "kind": "port",
+                         "sample": f"64 cells x {nt*50} steps"}
+print(json.dumps(line2))
