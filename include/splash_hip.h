@@ -302,6 +302,21 @@ int splash_unswc_grid_run(int backend, size_t ncell, int nt, const double* wn /*
                           const double* soil /*[6][ncell]*/, double uns_depth, double* w_z, double* wtd, double* se,
                           double* theta_mean, char* err, size_t errlen);
 
+/* The names SURVEY.md 8(b) lists for the core library that the entry points above do not already carry:
+ * splash_hip_version == splash_hip_abi_version; two test hooks on host arrays, both on the calling thread's module
+ * backend (splash_mod_backend):
+ * splash_day_step: ONE day step of one cell = SPLASH::run_one_day (src/SPLASH.cpp:920-1588; splash_mod_run_all with
+ *   nt = 1).  state_in[5]: wn, snow, qin, td, nd of the day before; out[11]: wn, ro, pet, aet, snow, cond, bflow, netr,
+ *   qin, tdrain, snwage.  soil_info as for splash_mod_run_all.
+ * splash_soil_hydro: K1 alone -- soil_hydro and the soil_info vector (R/splash.point.R:96-115, 232-416) -> cellpar
+ *   [SPLASH_NPAR][ncell]; soil [6][ncell]; au [3][ncell] or NULL (Au = 0, 3 cells in, 3 out). */
+int splash_hip_version(void);
+int splash_day_step(double lat, double elv, int n, int y, double sw_in, double tc, double pn, double snowfall,
+                    double slop, double asp, const double* soil_info, const double* state_in, double* out);
+int splash_soil_hydro(size_t ncell, const double* lat, const double* elev, const double* slop, const double* asp,
+                      const double* resolution, const double* soil, const double* au, double* cellpar, char* err,
+                      size_t errlen);
+
 /* test hook: the device build of the FP64 log/exp/pow/acos used by the day step, for n arguments
  * (host pointers): out [7][n] = flog(x), fexp(x), fpow(x,y), facos(x), fsqrt(x), fatan(x), fatan2(x,y) */
 int splash_dev_math_probe(size_t n, const double* x, const double* y, double* out);

@@ -354,6 +354,47 @@ def _grid_results(res, shp, lat, lon, outdir, time_index, monthly, want_state, s
 
 
 # ---------------------------------------------------------------------------- unSWC
+def day_step(lat, elv, n, y, sw_in, tc, pn, snowfall, slop, asp, soil_info, state, backend="hip"):
+    """test hook splash_day_step: ONE day step of one cell = SPLASH::run_one_day (src/SPLASH.cpp:920-1588).
+    state = (wn, snow, qin, td, nd) of the day before; returns dict(wn, ro, pet, aet, snow, cond, bflow, netr, qin,
+    tdrain, snwage)."""
+    si, sip = _d(soil_info)
+    st, stp = _d(state)
+    out = np.empty(11)
+    prev = lib.splash_mod_backend(_lib.backend_code(backend))
+    try:
+        check(lib.splash_day_step(float(lat), float(elv), int(n), int(y), float(sw_in), float(tc), float(pn),
+                                  float(snowfall), float(slop), float(asp), sip, stp, out.ctypes.data_as(_dp)),
+              "splash_day_step")
+    finally:
+        lib.splash_mod_backend(prev)
+    return dict(zip(("wn", "ro", "pet", "aet", "snow", "cond", "bflow", "netr", "qin", "tdrain", "snwage"), out))
+
+
+def soil_hydro(lat, elev, slop, asp, resolution, soil, au=None, backend="hip"):
+    """test hook splash_soil_hydro: K1 alone on host arrays -> cellpar [NPAR, ncell] (rows: include/splash_hip.h)"""
+    a = [_d(np.atleast_1d(x)) for x in (lat, elev, slop, asp, resolution)]
+    n = a[0][0].size
+    so, sop = _d(soil)
+    if so.shape != (6, n):
+        raise ValueError("soil must be [6, ncell]")
+    aup = None
+    if au is not None:
+        aua, aup = _d(au)
+        if aua.shape != (3, n):
+            raise ValueError("au must be [3, ncell]")
+    par = np.empty((NPAR, n))
+    err = C.create_string_buffer(256)
+    prev = lib.splash_mod_backend(_lib.backend_code(backend))
+    try:
+        rc = lib.splash_soil_hydro(n, *[x[1] for x in a], sop, aup, par.ctypes.data_as(_dp), err, 256)
+    finally:
+        lib.splash_mod_backend(prev)
+    if rc:
+        raise SplashError(f"splash_soil_hydro failed ({rc}): {err.value.decode()}")
+    return par
+
+
 def unSWC(soil_data, uns_depth, wn, backend="hip"):
     """R/unsSWC.R:14.  soil_data = c(sand, clay, OM, gravel, bulk density, depth); wn: series of
     column water content [mm].  Returns dict(wn_z, wtd, theta_i) like the reference's list

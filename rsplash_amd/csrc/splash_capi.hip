@@ -64,6 +64,7 @@ int exception_code(char* err, size_t errlen, const char* where) noexcept
 } // namespace splash
 
 extern "C" int splash_hip_abi_version(void) { return SPLASH_ABI_VERSION; }
+extern "C" int splash_hip_version(void) { return SPLASH_ABI_VERSION; } // the name SURVEY.md 8(b) gives it
 
 extern "C" int splash_hip_device_count(void)
 {
@@ -1689,4 +1690,48 @@ try {
     return SPLASH_OK;
 } catch (...) {
     return exception_code(nullptr, 0, "splash_mod_inf_GA");
+}
+
+// ------------------------------------------------------------------ test hooks named in SURVEY.md 8(b)
+// ONE day step of one cell = SPLASH::run_one_day (src/SPLASH.cpp:920-1588): splash_mod_run_all with nt = 1, on the
+// calling thread's module backend (splash_mod_backend).  state_in: wn, snow, qin, td, nd of the day before;
+// out[11]: wn, ro, pet, aet, snow, cond, bflow, netr, qin, tdrain, snwage.
+extern "C" int splash_day_step(double lat, double elv, int n, int y, double sw_in, double tc, double pn, double snowfall,
+                               double slop, double asp, const double* soil_info, const double* state_in, double* out)
+{
+    if (!soil_info || !state_in || !out) return fail(SPLASH_EINVAL, nullptr, 0, "day_step: NULL argument");
+    return splash_mod_run_all(lat, elv, 1, &n, &y, &sw_in, &tc, &pn, state_in[0], slop, asp, state_in[1], &snowfall,
+                              soil_info, state_in[2], state_in[3], state_in[4], out + 0, out + 1, out + 2, out + 3, out + 4,
+                              out + 5, out + 6, out + 7, out + 8, out + 9, out + 10);
+}
+
+// soil_hydro + the soil_info vector of R/splash.point.R:96-115, 232-416 for host arrays: cellpar [SPLASH_NPAR][ncell]
+// (K1 alone), on the calling thread's module backend.  au [3][ncell] or NULL (Au = 0, 3 cells in, 3 out: :106-110).
+extern "C" int splash_soil_hydro(size_t ncell, const double* lat, const double* elev, const double* slop, const double* asp,
+                                 const double* resolution, const double* soil, const double* au, double* cellpar, char* err,
+                                 size_t errlen)
+try {
+    if (!lat || !elev || !slop || !asp || !resolution || !soil || !cellpar)
+        return fail(SPLASH_EINVAL, err, errlen, "soil_hydro: NULL argument");
+    if (ncell == 0) return SPLASH_OK;
+    if (t_mod_backend == SPLASH_BACKEND_HOST) {
+        host_soil_hydro(ncell, lat, elev, slop, asp, resolution, soil, au, cellpar);
+        return SPLASH_OK;
+    }
+    if (int rc = enter_device(err, errlen)) return rc;
+    DevBuf d_in, d_par;
+    const size_t nin = 5 + 6 + (au ? 3 : 0);
+    HIP_TRY(d_in.alloc(nin * ncell * 8), err, errlen);
+    HIP_TRY(d_par.alloc((size_t)SPLASH_NPAR * ncell * 8), err, errlen);
+    double* p = d_in.as<double>();
+    const double* src[5] = {lat, elev, slop, asp, resolution};
+    for (int k = 0; k < 5; k++) HIP_TRY(hipMemcpy(p + (size_t)k * ncell, src[k], ncell * 8, hipMemcpyHostToDevice), err, errlen);
+    HIP_TRY(hipMemcpy(p + 5 * ncell, soil, 6 * ncell * 8, hipMemcpyHostToDevice), err, errlen);
+    if (au) HIP_TRY(hipMemcpy(p + 11 * ncell, au, 3 * ncell * 8, hipMemcpyHostToDevice), err, errlen);
+    HIP_TRY(launch_soil_hydro(ncell, p, p + ncell, p + 2 * ncell, p + 3 * ncell, p + 4 * ncell, p + 5 * ncell,
+                              au ? p + 11 * ncell : nullptr, d_par.as<double>(), nullptr), err, errlen);
+    HIP_TRY(hipMemcpy(cellpar, d_par.p, (size_t)SPLASH_NPAR * ncell * 8, hipMemcpyDeviceToHost), err, errlen);
+    return SPLASH_OK;
+} catch (...) {
+    return exception_code(err, errlen, "splash_soil_hydro");
 }

@@ -168,6 +168,8 @@ void host_mod_spin_up(const double* par, int n, const DayRec* days, const double
                       const double* snowfall, double* const series[7], int* passes);
 void host_snow_threshold(size_t ncell, int nt, const double* tc, const float* tc32, const double* lat, const double* elev,
                          double* tt);
+void host_soil_hydro(size_t ncell, const double* lat, const double* elev, const double* slop, const double* asp,
+                     const double* resolution, const double* soil, const double* au, double* cellpar);
 void host_unswc(size_t ncell, int nt, const double* wn, const double* soil, double uns_depth, double* wn_z, double* wtd,
                 double* theta);
 void host_unswc_grid(size_t ncell, int nt, const double* wn, const double* soil, double uns_depth, double* w_z,

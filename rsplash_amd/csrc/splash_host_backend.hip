@@ -454,6 +454,19 @@ void host_snow_threshold(size_t ncell, int nt, const double* tc, const float* tc
     else snow_threshold_generic(ncell, nt, tc, tc32, lat, elev, tt);
 }
 
+// K1 on host arrays: cellpar [P_NPAR][ncell] (soil_hydro_cell is the function k_soil_hydro runs)
+void host_soil_hydro(size_t ncell, const double* lat, const double* elev, const double* slop, const double* asp,
+                     const double* resolution, const double* soil, const double* au, double* cellpar)
+{
+    for (size_t i = 0; i < ncell; i++) {
+        double col[P_NPAR];
+        soil_hydro_cell(lat[i], elev[i], slop[i], asp[i], resolution[i], soil[i], soil[ncell + i], soil[2 * ncell + i],
+                        soil[3 * ncell + i], soil[4 * ncell + i], soil[5 * ncell + i], au ? au[i] : 0.0,
+                        au ? au[ncell + i] : 3.0, au ? au[2 * ncell + i] : 3.0, col);
+        for (int k = 0; k < P_NPAR; k++) cellpar[(size_t)k * ncell + i] = col[k];
+    }
+}
+
 void host_unswc(size_t ncell, int nt, const double* wn, const double* soil, double uns_depth, double* wn_z, double* wtd,
                 double* theta)
 {

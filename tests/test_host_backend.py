@@ -329,6 +329,50 @@ def test_monthly_aggregation_leaves_na_days_out(api, oracle):
     _assert_monthly_with_gaps(g, o)
 
 
+def test_survey_named_hooks_on_the_host(api, oracle, bourne, sa_cru):
+    """the test hooks SURVEY.md 8(b) names, with the host backend: splash_day_step == SPLASH::run_one_day
+    (src/SPLASH.cpp:920-1588) against the oracle's, state and fluxes, on days of the Bourne series from the oracle's own
+    states; splash_soil_hydro (K1 alone) against orc_soil_info on every land cell of the reference's South America
+    soils; splash_hip_version"""
+    from rsplash_amd import _lib
+    assert _lib.lib.splash_hip_version() == _lib.lib.splash_hip_abi_version() == 6
+    b, s = bourne, bourne["site"]
+    si, wmax_r = oracle.soil_info(b["soil"], [s["Aups_250m"], 3, 3], s["resolution"])
+    Tt, rain, snowf = oracle.snow_partition(b["Ta"], b["P"], b["month"], s["latitude"], s["elev_m"])
+    asp = s["asp_250m"] - 180
+    state = np.array([si[0] * 0.6, 40.0, 0.0, 0.0, 3.0])      # wn, snow, qin, td, nd
+    worst = 0.0
+    for t in range(0, 400, 7):
+        smr, etr = oracle.run_one_day(s["latitude"], s["elev_m"], int(b["doy"][t]), int(b["year"][t]), state[0], b["sw_in"][t],
+                                      b["Ta"][t], rain[t], s["slop_250m"], asp, state[1], snowf[t], si, state[2], state[3],
+                                      state[4])
+        g = api.day_step(s["latitude"], s["elev_m"], int(b["doy"][t]), int(b["year"][t]), b["sw_in"][t], b["Ta"][t], rain[t],
+                         snowf[t], s["slop_250m"], asp, si, state, backend="host")
+        pairs = dict(wn=smr["sm"], ro=smr["ro"], snow=smr["swe"], bflow=smr["bflow"], qin=smr["sqout"], tdrain=smr["tdr"],
+                     snwage=smr["nd"], pet=etr["pet"], aet=etr["aet"], cond=etr["cond"])
+        for k, ref in pairs.items():
+            worst = max(worst, close(np.array([g[k]]), np.array([ref]), f"day_step[{t}].{k}"))
+        state = np.array([smr["sm"], smr["swe"], smr["sqout"], smr["tdr"], smr["nd"]])
+    print("splash_day_step vs orc_run_one_day, 58 days: max rel err", worst)
+    land = ~np.isnan(sa_cru["elev"])
+    soil = sa_cru["soil"][:, land].astype(np.float64)
+    n = soil.shape[1]
+    rng = np.random.default_rng(2)
+    au = np.stack([rng.uniform(0, 1e7, n), rng.integers(1, 4, n).astype(float), np.full(n, 3.0)])
+    res = rng.uniform(100, 60000, n)
+    lat, elev, slop, asp_ = rng.uniform(-60, 60, n), rng.uniform(0, 4000, n), rng.uniform(0, 40, n), rng.uniform(0, 360, n)
+    par = api.soil_hydro(lat, elev, slop, asp_, res, soil, au, backend="host")
+    assert par.shape == (api.NPAR, n) and n > 6000
+    assert np.array_equal(par[0], lat) and np.array_equal(par[3], asp_ - 180)
+    ref = np.empty((13, n))
+    for i in range(n):
+        si_i, wmax = oracle.soil_info(soil[:, i], au[:, i], res[i])
+        ref[:12, i], ref[12, i] = si_i, wmax
+    for k in range(12):
+        close(par[4 + k], ref[k], f"soil_info[{k}]", rtol=1e-12)
+    close(par[16], ref[12], "Wmax", rtol=1e-12)
+
+
 def test_host_backend_is_explicit_and_unknown_backends_are_refused(api, bourne):
     import ctypes as C
     from rsplash_amd import _lib
