@@ -1109,6 +1109,36 @@ def test_unswc_grid_semantics(api, oracle, uns_depth):
         assert np.array_equal(o.cpu().numpy(), got[k], equal_nan=True), k      # same kernel: same bits
 
 
+def test_survey_named_hooks_on_the_device(api, oracle, bourne, sa_cru):
+    """splash_day_step and splash_soil_hydro (the test hooks SURVEY.md 8(b) names) with the HIP backend: the device's
+    day step against the oracle's run_one_day on days of the Bourne series, K1 against the host backend's (the same
+    function compiled twice) on the reference's South America soils.  tests/test_host_backend.py has the host twin."""
+    b, s = bourne, bourne["site"]
+    si, _ = oracle.soil_info(b["soil"], [s["Aups_250m"], 3, 3], s["resolution"])
+    Tt, rain, snowf = oracle.snow_partition(b["Ta"], b["P"], b["month"], s["latitude"], s["elev_m"])
+    asp = s["asp_250m"] - 180
+    state = np.array([si[0] * 0.6, 40.0, 0.0, 0.0, 3.0])
+    for t in range(0, 200, 9):
+        smr, etr = oracle.run_one_day(s["latitude"], s["elev_m"], int(b["doy"][t]), int(b["year"][t]), state[0], b["sw_in"][t],
+                                      b["Ta"][t], rain[t], s["slop_250m"], asp, state[1], snowf[t], si, state[2], state[3],
+                                      state[4])
+        g = api.day_step(s["latitude"], s["elev_m"], int(b["doy"][t]), int(b["year"][t]), b["sw_in"][t], b["Ta"][t], rain[t],
+                         snowf[t], s["slop_250m"], asp, si, state)
+        for k, ref in dict(wn=smr["sm"], ro=smr["ro"], snow=smr["swe"], bflow=smr["bflow"], qin=smr["sqout"],
+                           snwage=smr["nd"], pet=etr["pet"], aet=etr["aet"], cond=etr["cond"]).items():
+            close(np.array([g[k]]), np.array([ref]), f"day_step[{t}].{k}")
+        state = np.array([smr["sm"], smr["swe"], smr["sqout"], smr["tdr"], smr["nd"]])
+    land = ~np.isnan(sa_cru["elev"])
+    soil = sa_cru["soil"][:, land].astype(np.float64)
+    n = soil.shape[1]
+    rng = np.random.default_rng(2)
+    args = (rng.uniform(-60, 60, n), rng.uniform(0, 4000, n), rng.uniform(0, 40, n), rng.uniform(0, 360, n),
+            rng.uniform(100, 60000, n), soil)
+    dev, host = api.soil_hydro(*args), api.soil_hydro(*args, backend="host")
+    for k in range(api.NPAR):
+        close(dev[k], host[k], f"cellpar[{k}]", rtol=1e-12)
+
+
 def test_splash_grid_leap_year_calendar(api, oracle):
     """calendar crossing a leap year (2003-2005: doy 366, kN = 366 in the orbit, months of 29 days)
     on flat terrain, monthly output (the reference's default for splash.grid)"""
