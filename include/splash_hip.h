@@ -273,6 +273,18 @@ int splash_static_rasters_run(int H, int W, const double* elev, double ymax, dou
                               int na_to_zero, double degree, const splash_static_out* out,
                               char* err, size_t errlen);
 
+/* The reference's LARGE-GRID terrain (R/splash.grid.R:77-94: grids of more than 1e7 cells or of 0.1-1 degree): the DEM
+ * is written as 16-bit integers (R/upslope_area.R:64) and `gdaldem slope -s 111120 -compute_edges`, `gdaldem aspect
+ * -zero_for_flat -compute_edges` give slope and aspect (:83-84): Horn's formula with ONE metres-per-degree scale for
+ * both axes, aspect as an azimuth with flat = 0, edge cells and cells next to NA computed (no NA ring to zero).  GDAL is
+ * a system tool, in neither tree nor image: gdaldem's published algorithm restated, parity unpinned.  elev [H][W]
+ * row-major, north row first, NaN = NA; xres, yres in degrees; scale = 111120 for the reference's call; round_int != 0
+ * rounds the elevations to whole metres first (the INT2S file).  Either output may be NULL. */
+int splash_dev_terrain_gdal(int H, int W, const double* elev, double xres, double yres, double scale, int round_int,
+                            double* slope_deg, double* aspect_deg, void* stream);
+int splash_terrain_gdal_run(int H, int W, const double* elev, double xres, double yres, double scale, int round_int,
+                            double* slope_deg, double* aspect_deg, char* err, size_t errlen);
+
 /* ---------------------------------------------------------------- unSWC epilogue */
 /* R/unsSWC.R:14-88 / R/unsSWC.grid.R: from the column water content wn [mm] (output of the path
  * above), the water held between the surface and uns_depth [m] (wn_z, mm), the water-table depth

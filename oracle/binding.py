@@ -135,6 +135,7 @@ class Oracle:
                                         C.c_int, _ip, _dp, _dp, _dp, _dp, _dp]
         L.orc_unswc.argtypes = [_dp, C.c_double, C.c_int, _dp, C.c_size_t, _dp, _dp, _dp, _dp,
                                 C.c_size_t]
+        L.orc_terrain_gdal.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_double, C.c_double, C.c_int, _dp, _dp]
         L.orc_unswc_grid.argtypes = [_dp, C.c_double, C.c_int, _dp, C.c_size_t, _dp, _dp, _dp, _dp, _dp,
                                      C.c_size_t]
         L.orc_calendar.restype = C.c_int
@@ -250,6 +251,15 @@ class Oracle:
         o = {k: np.empty(nt) for k in ("wn_z", "wtd", "theta_i", "cond")}
         self.lib.orc_unswc(sdp, float(uns_depth), nt, wp, 1, *[o[k].ctypes.data_as(_dp) for k in o], 1)
         return o
+
+    def terrain_gdal(self, elev, xres, yres, scale=111120.0, round_int=True):
+        """the reference's large-grid terrain (gdaldem on the INT2S DEM, R/splash.grid.R:83-84): slope, aspect [H, W]"""
+        e, ep = _d(elev)
+        H, W = e.shape
+        sl, asp = np.empty((H, W)), np.empty((H, W))
+        self.lib.orc_terrain_gdal(H, W, ep, float(xres), float(yres), float(scale), int(bool(round_int)),
+                                  sl.ctypes.data_as(_dp), asp.ctypes.data_as(_dp))
+        return sl, asp
 
     def unswc_grid(self, soil_data, uns_depth, wn):
         """R/unsSWC.grid.R for one cell: dict(w_z, wtd, Se, theta_mean) + 'cond'"""

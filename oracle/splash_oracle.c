@@ -1795,6 +1795,86 @@ void orc_terrain(int H, int W, const double* elev, double ymax, double yres, dou
     }
 }
 
+/* The LARGE-GRID terrain of the reference (R/splash.grid.R:77-94, ncell > 1e7 or 0.1 < res < 1 degree): the DEM is written
+ * as 16-bit integers (`writeRaster(dem, "rawdem.tif", datatype = 'INT2S')`, R/upslope_area.R:64) and
+ *     gdaldem slope  -s 111120 -compute_edges rawdem.tif slope_deg.tif
+ *     gdaldem aspect -zero_for_flat -compute_edges rawdem.tif aspect_deg.tif          (R/splash.grid.R:83-84)
+ * PARITY UNPINNED: GDAL is a system tool of unknown version, absent from tree and image.  This restates gdaldem's
+ * published algorithm (gdaldem_lib.cpp, Horn's formula, the default): window 0 1 2 / 3 4 5 / 6 7 8 from the north-west;
+ *   slope  = atan( sqrt(dx^2 + dy^2) / (8 * scale) ),  dx = ((w0+2w3+w6) - (w2+2w5+w8)) / ewres, dy = ((w6+2w7+w8) - (w0+2w1+w2)) / nsres
+ *            -- ONE scale for both axes at every latitude (-s 111120: metres per degree), resolutions in degrees;
+ *   aspect = atan2(dy', -dx') with dx' = (w2+2w5+w8) - (w0+2w3+w6), dy' = (w6+2w7+w8) - (w0+2w1+w2) (no cell sizes),
+ *            as an azimuth (> 90: 450 - a, else 90 - a; 360 -> 0); flat (dx' = dy' = 0): 0 with -zero_for_flat;
+ *   -compute_edges: on the first / last LINE the missing row is 2 * line - next line with the column index clamped,
+ *            on the first / last COLUMN of the other lines the missing column is 2 * column - next column; a
+ *            missing (nodata) neighbour takes the centre's value; a missing centre is nodata.
+ * round_int != 0: elevations rounded to whole metres first (the INT2S file; R's round(): half to even). */
+static double gd_interpol(double a, double b) { return (isnan(a) || isnan(b)) ? NAN : 2 * a - b; }
+void orc_terrain_gdal(int H, int W, const double* elev, double xres, double yres, double scale, int round_int,
+                      double* slope, double* aspect)
+{
+    double* z = (double*)malloc(sizeof(double) * (size_t)H * W);
+    for (size_t i = 0; i < (size_t)H * W; i++) z[i] = round_int ? nearbyint(elev[i]) : elev[i];
+#define Z(r, c) z[(size_t)(r) * W + (c)]
+    for (int r = 0; r < H; r++) {
+        for (int c = 0; c < W; c++) {
+            size_t i = (size_t)r * W + c;
+            double w[9];
+            int cm = c > 0 ? c - 1 : c, cp = c < W - 1 ? c + 1 : c; /* clamped (first / last line) */
+            if (H < 2 || W < 2) {
+                for (int q = 0; q < 9; q++) w[q] = Z(r, c);
+            } else if (r == 0 || r == H - 1) {
+                int rn = r == 0 ? 1 : H - 2; /* the line next to the edge */
+                double mid[3] = {Z(r, cm), Z(r, c), Z(r, cp)}, nxt[3] = {Z(rn, cm), Z(rn, c), Z(rn, cp)}, ext[3];
+                for (int q = 0; q < 3; q++) ext[q] = gd_interpol(mid[q], nxt[q]);
+                for (int q = 0; q < 3; q++) {
+                    w[3 + q] = mid[q];
+                    w[r == 0 ? q : 6 + q] = ext[q];
+                    w[r == 0 ? 6 + q : q] = nxt[q];
+                }
+            } else {
+                for (int dr = -1; dr <= 1; dr++) {
+                    double l, m = Z(r + dr, c), rt;
+                    if (c == 0) {
+                        rt = Z(r + dr, 1);
+                        l = gd_interpol(m, rt);
+                    } else if (c == W - 1) {
+                        l = Z(r + dr, W - 2);
+                        rt = gd_interpol(m, l);
+                    } else {
+                        l = Z(r + dr, c - 1);
+                        rt = Z(r + dr, c + 1);
+                    }
+                    w[3 * (dr + 1)] = l;
+                    w[3 * (dr + 1) + 1] = m;
+                    w[3 * (dr + 1) + 2] = rt;
+                }
+            }
+            double sl = NAN, as = NAN;
+            if (!isnan(w[4])) {
+                for (int q = 0; q < 9; q++)
+                    if (isnan(w[q])) w[q] = w[4];
+                double dx = ((w[0] + w[3] + w[3] + w[6]) - (w[2] + w[5] + w[5] + w[8])) / xres;
+                double dy = ((w[6] + w[7] + w[7] + w[8]) - (w[0] + w[1] + w[1] + w[2])) / yres;
+                sl = atan(sqrt(dx * dx + dy * dy) / (8 * scale)) / G_pir;
+                double ax = ((w[2] + w[5] + w[5] + w[8]) - (w[0] + w[3] + w[3] + w[6]));
+                double ay = ((w[6] + w[7] + w[7] + w[8]) - (w[0] + w[1] + w[1] + w[2]));
+                if (ax == 0 && ay == 0) {
+                    as = 0.0; /* -zero_for_flat */
+                } else {
+                    as = atan2(ay, -ax) / G_pir;
+                    as = as > 90.0 ? 450.0 - as : 90.0 - as;
+                    if (as == 360.0) as = 0.0;
+                }
+            }
+            if (slope) slope[i] = sl;
+            if (aspect) aspect[i] = as;
+        }
+    }
+#undef Z
+    free(z);
+}
+
 /* R/upslope_area.R:140-165 (compare() under raster::focal with a 3x3 window of ones) */
 void orc_ncellflow(int H, int W, const double* fd, const double* codes9, int pad, double* out)
 {

@@ -181,6 +181,10 @@ double* orc_debug_ptr(void);
 void orc_terrain(int H, int W, const double* elev, double ymax, double yres, double xres,
                  int na_to_zero, double* slope, double* aspect, double* lat, double* resolution,
                  double* flowdir);
+/* the reference's large-grid terrain: gdaldem slope -s <scale> -compute_edges / gdaldem aspect -zero_for_flat -compute_edges
+ * on the (optionally integer-rounded) DEM, R/splash.grid.R:83-84 (restated from gdaldem's published algorithm) */
+void orc_terrain_gdal(int H, int W, const double* elev, double xres, double yres, double scale, int round_int,
+                      double* slope, double* aspect);
 void orc_ncellflow(int H, int W, const double* flowdir, const double* codes9, int pad, double* out);
 void orc_mfd_area(int H, int W, const double* z, double res, double* area);
 void orc_sinkfill(int H, int W, const double* z, double resolution_m, double degree, double* w);

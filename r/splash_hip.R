@@ -175,10 +175,18 @@ splash.grid.statics <- function(elev, tmpdir = tempdir()) {
 # The same rasters from the HIP library (Horn slope/aspect, latitude, resolution, sink fill, D8
 # contributing area, cells draining in/out: include/splash_hip.h, splash_static_rasters_run); a
 # lon/lat grid is assumed, as raster::area() and the rest of splash.grid do.
-splash.grid.statics.hip <- function(elev, degree = 1) {
+# terrain = "gdal": slope and aspect as the reference's large-grid branch gets them (R/splash.grid.R:83-84: gdaldem on
+# the INT2S DEM; published algorithm restated in the library), "raster" (default): raster::terrain's, at every size.
+splash.grid.statics.hip <- function(elev, degree = 1, terrain = c("raster", "gdal")) {
+  terrain <- match.arg(terrain)
   z <- matrix(raster::getValues(elev), nrow = ncol(elev), ncol = nrow(elev))   # [ncol x nrow]: row-major cells
   r <- .Call("C_splash_static_rasters", z, as.numeric(raster::ymax(elev)), as.numeric(raster::yres(elev)),
              as.numeric(raster::xres(elev)), as.numeric(degree))
+  if (terrain == "gdal") {
+    g <- .Call("C_splash_terrain_gdal", z, as.numeric(raster::xres(elev)), as.numeric(raster::yres(elev)), 111120, 1L)
+    r$slope <- g$slope
+    r$aspect <- g$aspect
+  }
   as_raster <- function(m) raster::setValues(raster::raster(elev), as.vector(m))
   terraines <- raster::stack(as_raster(r$slope), as_raster(r$aspect))
   names(terraines) <- c("slope", "aspect")

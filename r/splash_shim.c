@@ -314,6 +314,30 @@ SEXP C_splash_unswc_grid_run(SEXP wn, SEXP soil, SEXP uns_depth, SEXP backend)
     return res;
 }
 
+/* The terrain of the reference's large-grid branch (gdaldem on the INT2S DEM, R/splash.grid.R:83-84): elev [W x H] as for
+ * C_splash_static_rasters, xres / yres in degrees -> list(slope, aspect) of [W x H] matrices */
+SEXP C_splash_terrain_gdal(SEXP elev, SEXP xres, SEXP yres, SEXP scale, SEXP round_int)
+{
+    SEXP dim = getAttrib(elev, R_DimSymbol);
+    if (isNull(dim) || LENGTH(dim) != 2 || !isReal(elev)) error("elev must be a numeric [ncol x nrow] matrix");
+    const int W = INTEGER(dim)[0], H = INTEGER(dim)[1];
+    static const char* names[] = {"slope", "aspect", ""};
+    SEXP res = PROTECT(mkNamed(VECSXP, names));
+    double* o[2];
+    for (int k = 0; k < 2; k++) {
+        SEXP m = PROTECT(allocMatrix(REALSXP, W, H));
+        o[k] = REAL(m);
+        SET_VECTOR_ELT(res, k, m);
+        UNPROTECT(1);
+    }
+    char err[512];
+    int rc = splash_terrain_gdal_run(H, W, REAL(elev), asReal(xres), asReal(yres), asReal(scale), asInteger(round_int), o[0],
+                                     o[1], err, sizeof err);
+    UNPROTECT(1);
+    if (rc != SPLASH_OK) error("splash_terrain_gdal_run failed (%d): %s", rc, err);
+    return res;
+}
+
 /* Static rasters of an elevation matrix (R/splash.grid.R:96-110, R/upslope_area.R:12-58).
  * elev: numeric matrix [W x H], i.e. t(raster::as.matrix(dem)) or the vector raster::getValues(dem)
  * with dim c(ncol, nrow) -- row-major cells, as the C ABI wants them; ymax/yres/xres: northern edge
@@ -354,6 +378,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"C_splash_point_run", (DL_FUNC)&C_splash_point_run, 15},
     {"C_splash_unswc_run", (DL_FUNC)&C_splash_unswc_run, 4},
     {"C_splash_unswc_grid_run", (DL_FUNC)&C_splash_unswc_grid_run, 4},
+    {"C_splash_terrain_gdal", (DL_FUNC)&C_splash_terrain_gdal, 5},
     {"C_splash_static_rasters", (DL_FUNC)&C_splash_static_rasters, 5},
     {NULL, NULL, 0}};
 

@@ -120,6 +120,9 @@ def _load():
                                    C.c_char_p, C.c_size_t]
     L.splash_unswc_run_backend.argtypes = [C.c_int, C.c_size_t, C.c_int, _dp, _dp, C.c_double, _dp, _dp, _dp,
                                            C.c_char_p, C.c_size_t]
+    L.splash_terrain_gdal_run.argtypes = [C.c_int, C.c_int, _dp, C.c_double, C.c_double, C.c_double, C.c_int, _dp, _dp,
+                                          C.c_char_p, C.c_size_t]
+    L.splash_dev_terrain_gdal.argtypes = [C.c_int, C.c_int, _vp, C.c_double, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp]
     L.splash_day_step.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int] + [C.c_double] * 6 + [_dp, _dp, _dp]
     L.splash_soil_hydro.argtypes = [C.c_size_t] + [_dp] * 8 + [C.c_char_p, C.c_size_t]
     L.splash_unswc_grid_run.argtypes = [C.c_int, C.c_size_t, C.c_int, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp,
@@ -167,7 +170,7 @@ SYMBOLS = (
     "splash_dev_infiltration_probe", "splash_dev_terrain", "splash_dev_ncellflow",
     "splash_dev_sinkfill", "splash_dev_flow_accumulation", "splash_dev_mfd_area", "splash_static_rasters_run",
     "splash_dev_run_all", "splash_dev_synth_statics", "splash_dev_synth_forcing",
-    "splash_dev_evap_batch", "splash_dev_math_probe", "splash_dev_unswc", "splash_unswc_run", "splash_unswc_run_backend", "splash_hip_version", "splash_day_step", "splash_soil_hydro", "splash_unswc_grid_run", "splash_dev_unswc_grid",
+    "splash_dev_evap_batch", "splash_dev_math_probe", "splash_dev_unswc", "splash_unswc_run", "splash_unswc_run_backend", "splash_hip_version", "splash_terrain_gdal_run", "splash_dev_terrain_gdal", "splash_day_step", "splash_soil_hydro", "splash_unswc_grid_run", "splash_dev_unswc_grid",
     "splash_snow_threshold_run", "splash_snow_threshold_run_backend", "splash_grid_run", "splash_grid_submit", "splash_grid_wait", "splash_point_run", "splash_mod_spin_up",
     "splash_mod_run_all", "splash_mod_run_one_year", "splash_mod_moist_surf", "splash_mod_inf_GA",
     "splash_point_run_backend", "splash_host_backend_fma", "splash_mod_backend",

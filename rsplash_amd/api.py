@@ -827,6 +827,21 @@ def static_rasters(elev, ymax, yres, xres, na_to_zero=True, degree=1.0, want=Non
     return o
 
 
+def terrain_gdal(elev, xres, yres, scale=111120.0, round_int=True):
+    """The reference's LARGE-GRID terrain (R/splash.grid.R:83-84: `gdaldem slope -s 111120 -compute_edges`, `gdaldem
+    aspect -zero_for_flat -compute_edges` on the DEM written as INT2S): elev [H, W] -> (slope, aspect) in degrees.
+    gdaldem's published algorithm restated (include/splash_hip.h); parity unpinned."""
+    e = np.ascontiguousarray(elev, dtype=np.float64)
+    H, W = e.shape
+    sl, asp = np.empty((H, W)), np.empty((H, W))
+    buf = C.create_string_buffer(256)
+    rc = lib.splash_terrain_gdal_run(H, W, e.ctypes.data_as(_dp), float(xres), float(yres), float(scale),
+                                     int(bool(round_int)), sl.ctypes.data_as(_dp), asp.ctypes.data_as(_dp), buf, 256)
+    if rc:
+        raise SplashError(f"splash_terrain_gdal_run failed ({rc}): {buf.value.decode()}")
+    return sl, asp
+
+
 def terrain(elev, ymax, yres, xres, na_to_zero=True):
     """host arrays: elev [H, W] -> dict(slope, aspect, lat, resolution, flowdir, ncellin, ncellout),
     the static rasters splash.grid prepares before its loop (the upslope area: upslope_area())"""

@@ -988,6 +988,45 @@ try {
     return exception_code(nullptr, 0, "splash_dev_terrain");
 }
 
+// the reference's large-grid terrain (gdaldem on the INT2S DEM, R/splash.grid.R:83-84): device rasters
+extern "C" int splash_dev_terrain_gdal(int H, int W, const double* elev, double xres, double yres, double scale,
+                                       int round_int, double* slope_deg, double* aspect_deg, void* stream)
+try {
+    REQ(elev && H > 0 && W > 0, "terrain_gdal: NULL elevation or empty grid");
+    REQ(yres > 0 && xres > 0 && scale > 0, "terrain_gdal: cell size and scale must be positive");
+    REQ(slope_deg || aspect_deg, "terrain_gdal: no output requested");
+    if (int rc = enter_device(nullptr, 0)) return rc;
+    HIP_TRY(launch_terrain_gdal(H, W, elev, xres, yres, scale, round_int, slope_deg, aspect_deg, (hipStream_t)stream), nullptr,
+            0);
+    return SPLASH_OK;
+} catch (...) {
+    return exception_code(nullptr, 0, "splash_dev_terrain_gdal");
+}
+
+// ... host arrays
+extern "C" int splash_terrain_gdal_run(int H, int W, const double* elev, double xres, double yres, double scale,
+                                       int round_int, double* slope_deg, double* aspect_deg, char* err, size_t errlen)
+try {
+    if (!elev || H <= 0 || W <= 0 || !(slope_deg || aspect_deg))
+        return fail(SPLASH_EINVAL, err, errlen, "terrain_gdal_run: NULL argument or empty grid");
+    if (!(xres > 0 && yres > 0 && scale > 0)) return fail(SPLASH_EINVAL, err, errlen, "terrain_gdal_run: cell size and scale must be positive");
+    if (int rc = enter_device(err, errlen)) return rc;
+    const size_t nb = (size_t)H * W * 8;
+    DevBuf de, ds, da;
+    HIP_TRY(de.alloc(nb), err, errlen);
+    if (slope_deg) HIP_TRY(ds.alloc(nb), err, errlen);
+    if (aspect_deg) HIP_TRY(da.alloc(nb), err, errlen);
+    HIP_TRY(hipMemcpy(de.p, elev, nb, hipMemcpyHostToDevice), err, errlen);
+    HIP_TRY(launch_terrain_gdal(H, W, de.as<double>(), xres, yres, scale, round_int, slope_deg ? ds.as<double>() : nullptr,
+                                aspect_deg ? da.as<double>() : nullptr, nullptr), err, errlen);
+    HIP_TRY(hipDeviceSynchronize(), err, errlen);
+    if (slope_deg) HIP_TRY(hipMemcpy(slope_deg, ds.p, nb, hipMemcpyDeviceToHost), err, errlen);
+    if (aspect_deg) HIP_TRY(hipMemcpy(aspect_deg, da.p, nb, hipMemcpyDeviceToHost), err, errlen);
+    return SPLASH_OK;
+} catch (...) {
+    return exception_code(err, errlen, "splash_terrain_gdal_run");
+}
+
 extern "C" int splash_dev_ncellflow(int H, int W, const double* flowdir, const double* codes9,
                                     int pad, double* ncell, void* stream)
 try {

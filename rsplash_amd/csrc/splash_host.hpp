@@ -23,6 +23,10 @@
 #include "splash_kernels.hpp"
 
 namespace splash {
+// (splash_statics.hip; declared here rather than in splash_kernels.hpp, whose text is part of the hash that ties the PMC
+// constants of profiles/traffic.json to the day-loop kernels' sources)
+hipError_t launch_terrain_gdal(int H, int W, const double* elev, double xres, double yres, double scale, int round_int,
+                               double* slope, double* aspect, hipStream_t s);
 namespace host {
 
 // text of the calling thread's last failure (splash_hip_last_error)

@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "splash_kernels.hpp"
+#include "splash_host.hpp"
 
 #include "splash_device.hpp"
 #include "splash_unswc.hpp"
@@ -772,6 +773,94 @@ __global__ __launch_bounds__(kBlock) void k_terrain(int H, int W, const double* 
     }
     }
 }
+// The reference's LARGE-GRID terrain (R/splash.grid.R:77-94: ncell > 1e7 or 0.1 < res < 1 degree): `gdaldem slope -s 111120
+// -compute_edges` and `gdaldem aspect -zero_for_flat -compute_edges` on the DEM written as 16-bit integers
+// (R/upslope_area.R:64).  GDAL is a system tool, not vendored: this restates gdaldem's published algorithm (Horn's
+// formula; ONE metres-per-degree scale for both axes at every latitude; aspect from the raw differences as an azimuth,
+// flat = 0; -compute_edges: on the first / last line the missing row is 2 * line - next with the column index clamped,
+// on the first / last column of the other lines the missing column is 2 * column - next; a missing neighbour takes the
+// centre's value, a missing centre is NA) -- parity unpinned.  One lane per cell, the nine
+// reads hit the L2; 8 B in + 16 B out per cell.
+__device__ __forceinline__ double gd_z(const double* __restrict__ e, int W, int r, int c, int round_int)
+{
+    const double v = e[(size_t)r * W + c];
+    return round_int ? rint(v) : v; // the INT2S file: R's round(), half to even (NaN stays NaN)
+}
+__device__ __forceinline__ double gd_interpol(double a, double b) { return 2.0 * a - b; } // NaN if either is
+
+__global__ __launch_bounds__(kBlock) void k_terrain_gdal(int H, int W, const double* __restrict__ elev, double xres,
+                                                        double yres, double scale, int round_int,
+                                                        double* __restrict__ slope, double* __restrict__ aspect)
+{
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (size_t)H * W) return;
+    const int r = (int)(i / (size_t)W), c = (int)(i % (size_t)W);
+    double w[9];
+    if (H < 2 || W < 2) {
+        const double z = gd_z(elev, W, r, c, round_int);
+#pragma unroll
+        for (int q = 0; q < 9; q++) w[q] = z;
+    } else if (r == 0 || r == H - 1) {
+        const int cm = c > 0 ? c - 1 : c, cp = c < W - 1 ? c + 1 : c, rn = r == 0 ? 1 : H - 2;
+        const int cc[3] = {cm, c, cp};
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const double mid = gd_z(elev, W, r, cc[q], round_int), nxt = gd_z(elev, W, rn, cc[q], round_int);
+            const double ext = gd_interpol(mid, nxt);
+            w[3 + q] = mid;
+            w[r == 0 ? q : 6 + q] = ext;
+            w[r == 0 ? 6 + q : q] = nxt;
+        }
+    } else {
+#pragma unroll
+        for (int dr = -1; dr <= 1; dr++) {
+            const double m = gd_z(elev, W, r + dr, c, round_int);
+            double l, rt;
+            if (c == 0) {
+                rt = gd_z(elev, W, r + dr, 1, round_int);
+                l = gd_interpol(m, rt);
+            } else if (c == W - 1) {
+                l = gd_z(elev, W, r + dr, W - 2, round_int);
+                rt = gd_interpol(m, l);
+            } else {
+                l = gd_z(elev, W, r + dr, c - 1, round_int);
+                rt = gd_z(elev, W, r + dr, c + 1, round_int);
+            }
+            w[3 * (dr + 1)] = l;
+            w[3 * (dr + 1) + 1] = m;
+            w[3 * (dr + 1) + 2] = rt;
+        }
+    }
+    double sl = __builtin_nan(""), as = __builtin_nan("");
+    if (w[4] == w[4]) {
+#pragma unroll
+        for (int q = 0; q < 9; q++)
+            if (w[q] != w[q]) w[q] = w[4];
+        const double ax = ((w[2] + w[5] + w[5] + w[8]) - (w[0] + w[3] + w[3] + w[6]));
+        const double ay = ((w[6] + w[7] + w[7] + w[8]) - (w[0] + w[1] + w[1] + w[2]));
+        const double dx = -ax / xres, dy = ay / yres;
+        sl = atan(sqrt(dx * dx + dy * dy) / (8.0 * scale)) * (1.0 / kPir);
+        if (ax == 0.0 && ay == 0.0) {
+            as = 0.0; // -zero_for_flat
+        } else {
+            as = atan2(ay, -ax) * (1.0 / kPir);
+            as = as > 90.0 ? 450.0 - as : 90.0 - as;
+            if (as == 360.0) as = 0.0;
+        }
+    }
+    if (slope) slope[i] = sl;
+    if (aspect) aspect[i] = as;
+}
+
+hipError_t launch_terrain_gdal(int H, int W, const double* elev, double xres, double yres, double scale, int round_int,
+                               double* slope, double* aspect, hipStream_t s)
+{
+    if (H <= 0 || W <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_terrain_gdal, dim3(nblk((size_t)H * W, kBlock)), dim3(kBlock), 0, s, H, W, elev, xres, yres, scale,
+                       round_int, slope, aspect);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(kBlock) void k_ncellflow(int H, int W, const double* __restrict__ fd,
                                                      const double* __restrict__ codes, int pad,
                                                      double* __restrict__ out)

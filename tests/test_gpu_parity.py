@@ -1139,6 +1139,45 @@ def test_survey_named_hooks_on_the_device(api, oracle, bourne, sa_cru):
         close(dev[k], host[k], f"cellpar[{k}]", rtol=1e-12)
 
 
+def test_gdaldem_terrain_vs_oracle(api, oracle):
+    """splash_terrain_gdal_run / splash_dev_terrain_gdal (the reference's large-grid terrain, R/splash.grid.R:83-84,
+    restated from gdaldem's published algorithm) against the oracle's restatement on a rough DEM with NA patches, a
+    plateau and fractional elevations -- interior, edges, corners, cells next to NA --, with and without the rounding to
+    whole metres; grid_statics(terrain="gdal" / "reference") hands it to splash.grid."""
+    import torch
+    from rsplash_amd import grid
+    H, W = 157, 203
+    rng = np.random.default_rng(17)
+    yy, xx = np.mgrid[0:H, 0:W]
+    dem = 800 + 500 * np.sin(xx / 17.0) * np.cos(yy / 11.0) + 3.0 * yy + rng.uniform(0, 40, (H, W))
+    dem[rng.random((H, W)) < 0.03] = np.nan
+    dem[40:60, 70:95] = 1234.0                                  # a plateau: flat cells
+    dem[100:110, 150:170] = np.nan
+    dem[0, 5] = dem[H - 1, W - 1] = np.nan                      # NA on the edge lines and in a corner
+    for rnd in (True, False):
+        sl, asp = api.terrain_gdal(dem, 0.05, 0.05, 111120.0, round_int=rnd)
+        rsl, rasp = oracle.terrain_gdal(dem, 0.05, 0.05, 111120.0, round_int=rnd)
+        assert np.array_equal(np.isnan(sl), np.isnan(dem)) and np.array_equal(np.isnan(asp), np.isnan(dem))
+        assert np.allclose(sl, rsl, rtol=1e-12, atol=1e-12, equal_nan=True)
+        assert np.allclose(asp, rasp, rtol=1e-12, atol=1e-9, equal_nan=True)
+        assert (asp[45:55, 75:90] == 0).all() and (sl[45:55, 75:90] == 0).all()
+    dev = torch.device("cuda:0")
+    d = torch.from_numpy(dem).to(dev)
+    o1, o2 = torch.empty(H, W, dtype=torch.float64, device=dev), torch.empty(H, W, dtype=torch.float64, device=dev)
+    api.check(api.lib.splash_dev_terrain_gdal(H, W, d.data_ptr(), 0.05, 0.05, 111120.0, 0, o1.data_ptr(), o2.data_ptr(), None),
+              "splash_dev_terrain_gdal")
+    torch.cuda.synchronize()
+    assert np.array_equal(o1.cpu().numpy(), sl, equal_nan=True) and np.array_equal(o2.cpu().numpy(), asp, equal_nan=True)
+    R = grid.Raster(dem, ymax=46.5, xmin=7.0, yres=0.05, xres=0.05)
+    g_ref = grid.grid_statics(R, terrain="reference")            # 0.05 degree < 0.1: the small-grid branch
+    g_gd = grid.grid_statics(R, terrain="gdal")
+    assert g_ref["terrain"] == "raster" and g_gd["terrain"] == "gdal"
+    assert np.allclose(g_gd["slop"], api.terrain_gdal(dem, 0.05, 0.05)[0], equal_nan=True)
+    assert np.array_equal(g_gd["lat"], g_ref["lat"], equal_nan=True) and np.array_equal(g_gd["Au"], g_ref["Au"], equal_nan=True)
+    R2 = grid.Raster(dem, ymax=46.5, xmin=7.0, yres=0.25, xres=0.25)
+    assert grid.grid_statics(R2, terrain="reference")["terrain"] == "gdal"      # 0.1 < res < 1: the large-grid branch
+
+
 def test_splash_grid_leap_year_calendar(api, oracle):
     """calendar crossing a leap year (2003-2005: doy 366, kN = 366 in the orbit, months of 29 days)
     on flat terrain, monthly output (the reference's default for splash.grid)"""

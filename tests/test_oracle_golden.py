@@ -441,3 +441,39 @@ def test_mfd_area_hand_cases(oracle):
                     z3[max(0, dr):z3.shape[0] - max(0, -dr), max(0, dc):z3.shape[1] - max(0, -dc)]
                 lower |= zz < z3
     assert np.isclose(a3[~lower].sum(), z3.size * 625.0, rtol=1e-12)  # cells without a lower neighbour hold it all
+
+
+def test_gdaldem_terrain_hand_cases(oracle):
+    """the reference's large-grid terrain (R/splash.grid.R:83-84: gdaldem slope -s 111120 -compute_edges, gdaldem aspect
+    -zero_for_flat -compute_edges on the INT2S DEM), restated from gdaldem's published algorithm (orc_terrain_gdal):
+    what can be computed by hand.  An inclined plane has its gradient's slope -- with ONE scale at every latitude -- and
+    aspect at every cell whose window is extrapolated linearly (all but the four corners, whose column index is clamped
+    on the edge lines: half the east-west gradient there); flat cells have aspect 0; a missing neighbour takes the
+    centre's value; a missing centre is NA; elevations are rounded to whole metres first."""
+    H, W = 6, 8
+    rows, cols = np.mgrid[0:H, 0:W].astype(float)
+    res = 0.01
+    sl, asp = oracle.terrain_gdal(100 + 10.0 * cols, res, res)          # rising 10 m per cell towards the east
+    want = np.degrees(np.arctan(10.0 / (res * 111120.0)))
+    inner = np.ones((H, W), bool)
+    inner[[0, 0, -1, -1], [0, -1, 0, -1]] = False
+    assert np.allclose(sl[inner], want, rtol=1e-13) and (asp == 270.0).all()       # downslope faces west
+    assert np.allclose(sl[~inner], np.degrees(np.arctan(5.0 / (res * 111120.0))), rtol=1e-13)
+    sl, asp = oracle.terrain_gdal(100 + 4.0 * rows, res, res)           # rising towards the south: faces north
+    assert np.allclose(sl, np.degrees(np.arctan(4.0 / (res * 111120.0))), rtol=1e-13) and (asp == 0.0).all()
+    sl, asp = oracle.terrain_gdal(100 - 3.0 * rows + 3.0 * cols, res, res)   # rising to the north-east: faces south-west
+    assert np.allclose(asp[inner], 225.0) and np.allclose(sl[inner], np.degrees(np.arctan(3.0 * np.sqrt(2) / (res * 111120.0))))
+    sl, asp = oracle.terrain_gdal(np.full((H, W), 312.4), res, res)     # flat: slope 0, aspect 0 (-zero_for_flat)
+    assert (sl == 0).all() and (asp == 0).all()
+    z = 100 + 10.0 * cols
+    z[2, 3] = np.nan
+    sl, asp = oracle.terrain_gdal(z, res, res)
+    assert np.isnan(sl[2, 3]) and np.isnan(asp[2, 3]) and np.isfinite(np.delete(sl.ravel(), 2 * W + 3)).all()
+    # the cell east of the hole: its west neighbour takes the centre's value -> (2*(z-z) + ...) a weaker gradient
+    g = ((z[1, 5] - z[1, 3]) + 2 * (z[2, 5] - z[2, 4]) + (z[3, 5] - z[3, 3])) / (8 * res * 111120.0)
+    assert np.isclose(sl[2, 4], np.degrees(np.arctan(g)), rtol=1e-13)
+    # whole metres first (the INT2S file; half to even, as R's round())
+    a = oracle.terrain_gdal(np.array([[0.5, 1.5, 2.5], [0.49, 1.51, 2.5], [0.2, 0.9, 2.4]]), res, res)
+    b = oracle.terrain_gdal(np.array([[0.0, 2.0, 2.0], [0.0, 2.0, 2.0], [0.0, 1.0, 2.0]]), res, res, round_int=False)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
