@@ -176,9 +176,12 @@ splash.grid.statics <- function(elev, tmpdir = tempdir()) {
 # contributing area, cells draining in/out: include/splash_hip.h, splash_static_rasters_run); a
 # lon/lat grid is assumed, as raster::area() and the rest of splash.grid do.
 # terrain = "gdal": slope and aspect as the reference's large-grid branch gets them (R/splash.grid.R:83-84: gdaldem on
-# the INT2S DEM; published algorithm restated in the library), "raster" (default): raster::terrain's, at every size.
-splash.grid.statics.hip <- function(elev, degree = 1, terrain = c("raster", "gdal")) {
+# the INT2S DEM; published algorithm restated in the library), "raster": raster::terrain's; "reference" (default):
+# whichever the reference takes for the grid's size (:77).
+splash.grid.statics.hip <- function(elev, degree = 1, terrain = c("reference", "raster", "gdal")) {
   terrain <- match.arg(terrain)
+  if (terrain == "reference")
+    terrain <- if (raster::ncell(elev) > 1e7 | (raster::res(elev)[1] > 0.1 & raster::res(elev)[1] < 1)) "gdal" else "raster"
   z <- matrix(raster::getValues(elev), nrow = ncol(elev), ncol = nrow(elev))   # [ncol x nrow]: row-major cells
   r <- .Call("C_splash_static_rasters", z, as.numeric(raster::ymax(elev)), as.numeric(raster::yres(elev)),
              as.numeric(raster::xres(elev)), as.numeric(degree))

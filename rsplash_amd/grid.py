@@ -100,17 +100,18 @@ def row_blocks(nrow, ncol, bytes_per_cell, target_bytes=2 << 30, minblocks=2, bl
     return [(r, min(block_rows, nrow - r)) for r in range(0, nrow, block_rows)]
 
 
-def grid_statics(elev, degree=1.0, method=None, terrain="raster"):
+def grid_statics(elev, degree=1.0, method=None, terrain="reference"):
     """R/splash.grid.R:76-110 from the elevation raster alone: latitude, slope/aspect (NA slopes of
     valid cells are flats, :107), resolution = sqrt(cell area) and the Au stack (contributing area,
     cells draining in, cells draining out; R/upslope_area.R:56).  Like the reference, large or coarse
     grids (ncell > 1e7, or 0.1 < resolution < 1 degree) take the D8 area of `upslope_areav2`, the others
     the multiple-flow-direction area of `upslope_area` (:76-77); `method` ("tau" / "top") overrides.
-    terrain: "raster" (default, every size) = raster::terrain's slope and aspect, the small-grid branch's
-    (:104-107: spacing from the row's latitude, NA ring set to 0); "gdal" = the large-grid branch's (:83-84: `gdaldem
-    slope -s 111120 -compute_edges` / `gdaldem aspect -zero_for_flat -compute_edges` on the DEM rounded to whole metres:
-    one scale at every latitude, edges computed, flat aspect 0 -- api.terrain_gdal, restated from gdaldem's published
-    algorithm); "reference" = whichever of the two the reference would take for this grid's size."""
+    terrain: "reference" (default) = whichever of the two the reference takes for this grid's size: "raster" =
+    raster::terrain's slope and aspect, the small-grid branch's (:104-107: spacing from the row's latitude, NA ring set
+    to 0); "gdal" = the large-grid branch's (:83-84: `gdaldem slope -s 111120 -compute_edges` / `gdaldem aspect
+    -zero_for_flat -compute_edges` on the DEM rounded to whole metres: one scale at every latitude, edges computed, flat
+    aspect 0 -- api.terrain_gdal, restated from gdaldem's published algorithm).  ("raster" on a large grid is the
+    better terrain -- the scale of "gdal" understates east-west gradients by cos(latitude) -- but not the reference's.)"""
     e = np.ascontiguousarray(np.asarray(elev.values, dtype=np.float64))
     large = bool(e.size > 1e7 or 0.1 < elev.xres < 1)
     if method is None:

@@ -1169,13 +1169,14 @@ def test_gdaldem_terrain_vs_oracle(api, oracle):
     torch.cuda.synchronize()
     assert np.array_equal(o1.cpu().numpy(), sl, equal_nan=True) and np.array_equal(o2.cpu().numpy(), asp, equal_nan=True)
     R = grid.Raster(dem, ymax=46.5, xmin=7.0, yres=0.05, xres=0.05)
-    g_ref = grid.grid_statics(R, terrain="reference")            # 0.05 degree < 0.1: the small-grid branch
+    g_ref = grid.grid_statics(R)                                 # the default follows the reference: 0.05 degree < 0.1, the small-grid branch
     g_gd = grid.grid_statics(R, terrain="gdal")
     assert g_ref["terrain"] == "raster" and g_gd["terrain"] == "gdal"
     assert np.allclose(g_gd["slop"], api.terrain_gdal(dem, 0.05, 0.05)[0], equal_nan=True)
     assert np.array_equal(g_gd["lat"], g_ref["lat"], equal_nan=True) and np.array_equal(g_gd["Au"], g_ref["Au"], equal_nan=True)
     R2 = grid.Raster(dem, ymax=46.5, xmin=7.0, yres=0.25, xres=0.25)
-    assert grid.grid_statics(R2, terrain="reference")["terrain"] == "gdal"      # 0.1 < res < 1: the large-grid branch
+    assert grid.grid_statics(R2)["terrain"] == "gdal"            # 0.1 < res < 1: the large-grid branch
+    assert grid.grid_statics(R2, terrain="raster")["terrain"] == "raster"
 
 
 def test_splash_grid_leap_year_calendar(api, oracle):
