@@ -121,8 +121,16 @@ def grid_statics(elev, degree=1.0, method=None, terrain="reference"):
     if terrain == "reference":
         terrain = "gdal" if large else "raster"
     area_key = "ups_area" if method == "tau" else "ups_area_mfd"
-    s = api.static_rasters(e, elev.ymax, elev.yres, elev.xres, na_to_zero=True, degree=degree,
-                           want=("slope", "aspect", "lat", "resolution", area_key, "ncellin", "ncellout"))
+    graph = (area_key, "ncellin", "ncellout")
+    if method == "tau" and not np.array_equal(np.rint(e), e, equal_nan=True):
+        # upslope_areav2 hands TauDEM the DEM as 16-bit integers (R/upslope_area.R:64): pits, flow directions and the
+        # contributing area come from elevations rounded to whole metres; latitude, resolution and raster::terrain do not
+        s = api.static_rasters(e, elev.ymax, elev.yres, elev.xres, na_to_zero=True, degree=degree,
+                               want=("slope", "aspect", "lat", "resolution"))
+        s.update(api.static_rasters(np.rint(e), elev.ymax, elev.yres, elev.xres, na_to_zero=True, degree=degree, want=graph))
+    else:
+        s = api.static_rasters(e, elev.ymax, elev.yres, elev.xres, na_to_zero=True, degree=degree,
+                               want=("slope", "aspect", "lat", "resolution") + graph)
     if terrain == "gdal":
         s["slope"], s["aspect"] = api.terrain_gdal(e, elev.xres, elev.yres, 111120.0, round_int=True)
     return dict(lat=s["lat"], slop=s["slope"], asp=s["aspect"], resolution=s["resolution"],

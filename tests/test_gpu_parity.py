@@ -1177,6 +1177,11 @@ def test_gdaldem_terrain_vs_oracle(api, oracle):
     R2 = grid.Raster(dem, ymax=46.5, xmin=7.0, yres=0.25, xres=0.25)
     assert grid.grid_statics(R2)["terrain"] == "gdal"            # 0.1 < res < 1: the large-grid branch
     assert grid.grid_statics(R2, terrain="raster")["terrain"] == "raster"
+    # the large-grid branch's AREA comes from the DEM as 16-bit integers (R/upslope_area.R:64): whole metres
+    g2 = grid.grid_statics(R2)
+    Rint = grid.Raster(np.rint(dem), ymax=46.5, xmin=7.0, yres=0.25, xres=0.25)
+    assert g2["method"] == "tau" and np.array_equal(g2["Au"], grid.grid_statics(Rint)["Au"], equal_nan=True)
+    assert not np.array_equal(g2["Au"][0], grid.grid_statics(R2, method="top")["Au"][0], equal_nan=True)
 
 
 def test_splash_grid_leap_year_calendar(api, oracle):
