@@ -180,11 +180,18 @@ splash.grid.statics <- function(elev, tmpdir = tempdir()) {
 # whichever the reference takes for the grid's size (:77).
 splash.grid.statics.hip <- function(elev, degree = 1, terrain = c("reference", "raster", "gdal")) {
   terrain <- match.arg(terrain)
-  if (terrain == "reference")
-    terrain <- if (raster::ncell(elev) > 1e7 | (raster::res(elev)[1] > 0.1 & raster::res(elev)[1] < 1)) "gdal" else "raster"
+  large <- raster::ncell(elev) > 1e7 | (raster::res(elev)[1] > 0.1 & raster::res(elev)[1] < 1)     # R/splash.grid.R:77
+  if (terrain == "reference") terrain <- if (large) "gdal" else "raster"
   z <- matrix(raster::getValues(elev), nrow = ncol(elev), ncol = nrow(elev))   # [ncol x nrow]: row-major cells
   r <- .Call("C_splash_static_rasters", z, as.numeric(raster::ymax(elev)), as.numeric(raster::yres(elev)),
              as.numeric(raster::xres(elev)), as.numeric(degree))
+  if (large) {   # upslope_areav2: D8 area (TauDEM's aread8) of the DEM as 16-bit integers (R/upslope_area.R:64-96)
+    ri <- .Call("C_splash_static_rasters", round(z), as.numeric(raster::ymax(elev)), as.numeric(raster::yres(elev)),
+                as.numeric(raster::xres(elev)), as.numeric(degree))
+    r$areacatch <- ri$areacatch_d8
+    r$ncellin <- ri$ncellin
+    r$ncellout <- ri$ncellout
+  }
   if (terrain == "gdal") {
     g <- .Call("C_splash_terrain_gdal", z, as.numeric(raster::xres(elev)), as.numeric(raster::yres(elev)), 111120, 1L)
     r$slope <- g$slope
