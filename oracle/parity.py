@@ -411,6 +411,30 @@ def reference_variants():
     return _VARIANTS
 
 
+def input_ulp_variants(st1):
+    """The statics of ONE cell with one input moved by one unit in the last place, up or down: the six soil inputs and
+    the elevation (14 variants).  The synthetic generator itself exists in two builds whose doubles differ in the last
+    place on one cell in 1e4 (host C and device, SURVEY.md 8d: 'agree to <= 1 ulp'), and no measured soil or DEM is
+    known to an ulp: a cell whose reference result leaves the tolerance under such a step -- a drainage time that
+    reaches 0 by a hair (`td <= 0`, src/SPLASH.cpp:1367-1371, after the cancelling `td -= 1`, :1468), a bucket that
+    lands on its bound -- has no reference value to be compared with (class 4).  Found in round 6: cell
+    (1924, 254) of the benchmark grid, where one ulp of the bulk density moves the oracle's aridity index by 1.7e-4
+    (profiles/r06_spinup_parity_sweep2.txt, tools/debug/r06_cell_1924_254.py)."""
+    for key, idx in [("soil", k) for k in range(6)] + [("elev", None)]:
+        for direction in (-np.inf, np.inf):
+            v = {k: np.array(x, dtype=np.float64, copy=True) for k, x in st1.items()}
+            a = v[key]
+            if idx is None:
+                if not np.isfinite(a).all():
+                    continue
+                a[...] = np.nextafter(a, direction)
+            else:
+                if not np.isfinite(a[idx]).all():
+                    continue
+                a[idx] = np.nextafter(a[idx], direction)
+            yield v
+
+
 def reference_disagrees_with_itself(cells, ref, aux, statics, forcing, names):
     """For each of `cells` (whole-pipeline inputs: statics dict, forcing = (doy, year, month, mid, nm,
     sw, tc, pn)): does another legal build of the reference's statements (B or C) leave the tolerance
@@ -430,6 +454,19 @@ def reference_disagrees_with_itself(cells, ref, aux, statics, forcing, names):
             differs = any(_bad(r2[k][:, 0], ref[k][:, c]).any() for k in names)
             differs |= int(a2["passes1"][0]) != int(aux["passes1"][c]) or int(a2["passes2"][0]) != int(aux["passes2"][c])
             res[n_] |= bool(differs)
+        if not res[n_]:   # ... or the PINNED build with one input moved by one ulp (input_ulp_variants)
+            from .binding import Oracle
+            pinned = Oracle()
+            for v in input_ulp_variants(st1):
+                r2, a2 = pinned.grid(doy, year, month, mid, nm, np.ascontiguousarray(sw[:, sl]),
+                                     np.ascontiguousarray(tc[:, sl]), np.ascontiguousarray(pn[:, sl]), v["lat"],
+                                     v["elev"], v["slop"], v["asp"], v["soil"], v["au"], v["resolution"],
+                                     monthly_out=(ref[names[0]].shape[0] != len(doy)), n_threads=1)
+                differs = any(_bad(r2[k][:, 0], ref[k][:, c]).any() for k in names)
+                differs |= int(a2["passes1"][0]) != int(aux["passes1"][c]) or int(a2["passes2"][0]) != int(aux["passes2"][c])
+                if differs:
+                    res[n_] = True
+                    break
     return res
 
 
@@ -601,6 +638,20 @@ def spinup_summary(oracle, state0, ai, passes2, aux, statics=None, forcing=None,
                         not (r2[4] == ref[4, c] or (r2[4] != r2[4] and ref[4, c] != ref[4, c])) or \
                         int(a2["passes2"][0]) != int(aux["passes2"][c])
                     ex[i] |= bool(differs)
+                if not ex[i]:   # ... or the pinned build with one input moved by one ulp (input_ulp_variants)
+                    for v in input_ulp_variants(st1):
+                        _, a2 = oracle.grid(doy, year, month, mid, nm, np.ascontiguousarray(sw[:, sl]),
+                                            np.ascontiguousarray(tc[:, sl]), np.ascontiguousarray(pn[:, sl]), v["lat"],
+                                            v["elev"], v["slop"], v["asp"], v["soil"], v["au"], v["resolution"], n_threads=1)
+                        r2 = np.asarray(a2["state0"][0])
+                        ai2 = float(a2["AI"][0])
+                        differs = abs(ai2 - ai_ref[c]) > rtol_ai * abs(ai_ref[c]) or _bad(r2[:3], ref[:3, c]).any() or \
+                            (not fragile[c] and _bad(r2[3:4], ref[3:4, c]).any()) or \
+                            not (r2[4] == ref[4, c] or (r2[4] != r2[4] and ref[4, c] != ref[4, c])) or \
+                            int(a2["passes2"][0]) != int(aux["passes2"][c])
+                        if differs:
+                            ex[i] = True
+                            break
             stray[cells[ex]] = False
             excused = int(ex.sum())
         if stray.any():

@@ -1,0 +1,67 @@
+"""A cell whose REFERENCE result is not defined to the tolerance: one unit in the last place of an input flips a branch.
+
+Cell (1924, 254) of the 4096 x 4096 benchmark grid, inputs as the DEVICE generator makes them (tests/golden/
+cell_1924_254_device_inputs.npz, written by tools/debug/r06_chunk_1923.py on an MI355X box; the host generator's bulk
+density, depth and organic matter differ from these in the last place -- SURVEY.md 8d: the two generators 'agree to <= 1
+ulp').  In the first pass of the first spin-up the drainage time counts down 2.99984.. -> 0.99992.. -> 0 with one
+input and 3.00024.. -> 1.00012.. -> 6e-5 with the other (`td -= 1`, src/SPLASH.cpp:1468, after a chain of halvings: a
+cancellation), so `td <= 0` (:1367-1371) resets the lateral inflow on day 184 in one and not in the other: the aridity
+index -- and with it the whole run -- differs by 1.7e-4.  The product gives the same answer for both inputs.  Found by
+tools/spinup_parity_sweep.py (profiles/r06_spinup_parity_sweep2.txt: the one stray cell of 1 048 576); since then the
+checker asks, for a stray cell, whether the pinned reference build itself leaves the tolerance when ONE input moves by
+one ulp (oracle/parity.py::input_ulp_variants) -- as it already asked of two other legal builds of the reference."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def api():
+    import rsplash_amd
+    rsplash_amd.build_library()
+    from rsplash_amd import api as a
+    return a
+
+
+def _inputs():
+    z = np.load(os.path.join(GOLD, "cell_1924_254_device_inputs.npz"))
+    st = dict(lat=np.array([float(z["lat"])]), elev=np.array([float(z["elev"])]), slop=np.array([float(z["slop"])]),
+              asp=np.array([float(z["asp"])]), resolution=np.array([float(z["resolution"])]),
+              soil=z["soil"].reshape(6, 1).copy(), au=z["au"].reshape(3, 1).copy())
+    return z, st, tuple(z[k].reshape(-1, 1).copy() for k in ("sw", "tc", "pn"))
+
+
+def test_one_ulp_of_an_input_moves_the_reference_not_the_product(api, oracle):
+    from oracle.parity import input_ulp_variants, spinup_summary
+    z, st, (sw, tc, pn) = _inputs()
+    doy, year, month, mid, nm = oracle.calendar(2001, 365)
+    dates = np.datetime64("2001-01-01") + np.arange(365)
+    run_o = lambda s: oracle.grid(doy, year, month, mid, nm, sw, tc, pn, s["lat"], s["elev"], s["slop"], s["asp"], s["soil"],
+                                  s["au"], s["resolution"])[1]
+    run_p = lambda s: api.splash_grid(sw, tc, pn, s["elev"], s["soil"], s["lat"], s["slop"], s["asp"], s["au"], s["resolution"],
+                                      time_index=dates, sim_control=dict(monthly_out=False), want_aux=True, backend="host")["aux"]
+    down = {k: v.copy() for k, v in st.items()}
+    down["soil"][4:6] = np.nextafter(down["soil"][4:6], -np.inf)          # bulk density and depth one ulp down: the host generator's values
+    a, b = run_o(st), run_o(down)
+    assert abs(a["AI"][0] - b["AI"][0]) > 1e-4 * b["AI"][0]               # the reference: 1.72482 against 1.72452
+    moved = [abs(run_o(v)["AI"][0] - a["AI"][0]) > 1e-6 * a["AI"][0] for v in input_ulp_variants(st)]
+    print("single-ulp steps that move the reference's aridity index by more than 1e-6:", int(sum(moved)), "of", len(moved))
+    assert any(moved)                                                     # ONE ulp of ONE input is enough
+    assert a["critical"][0] == 0 and a["fragile"][0] > 100                # ... with no critical event on record, only noise denominators
+    pa, pb = run_p(st), run_p(down)
+    assert abs(pa["AI"][0] - pb["AI"][0]) < 1e-12 * pb["AI"][0]           # the product: the same for both
+    assert abs(pa["AI"][0] - b["AI"][0]) < 1e-12 * b["AI"][0]             # = the reference's value for the OTHER input
+    variants = list(input_ulp_variants(st))
+    assert len(variants) == 14 and all(sum(int((v[k] != st[k]).sum()) for k in st) == 1 for v in variants)
+    # the checker: this cell breaks the aridity-index rule against the pinned build, and is excused by the ulp step
+    si, _ = oracle.soil_info(st["soil"][:, 0], st["au"][:, 0], st["resolution"][0])
+    si[11] = pa["AI"][0]
+    Tt, rain, snowf = oracle.snow_partition(tc[:, 0], pn[:, 0], month, st["lat"][0], st["elev"][0])
+    sp = api.SPLASH(st["lat"][0], st["elev"][0], backend="host").spin_up(365, 2001, sw[:, 0], tc[:, 0], rain, st["slop"][0],
+                                                                         st["asp"][0] - 180, snowf, si)
+    state0 = np.array([[sp[k][-1]] for k in ("sm", "snow", "qin", "tdrain", "snwage")])
+    rs = spinup_summary(oracle, state0, pa["AI"], np.array([sp["passes"]]), a, st, (doy, year, month, mid, nm, sw, tc, pn))
+    assert rs["violations"] == [] and rs["excused"] == 1, rs

@@ -4,7 +4,7 @@ eight latitude bands of the 4096 x 4096 benchmark grid, each side from its OWN s
 with exact-cycle detection, the oracle's 1000-pass loop (src/SPLASH.cpp:1594-1749 x 2, R/splash.point.R:141-152).
 oracle/parity.py::spinup_summary per chunk of 4 rows: state handed to run_all (wn, snow, qin, td within 1e-5; nd exactly),
 aridity index, pass counts.
-    python tools/spinup_parity_sweep.py [rows_per_band=16]"""
+    python tools/spinup_parity_sweep.py [rows_per_band=16] [row_offset=0]   (row_offset: other rows of every band)"""
 import json
 import os
 import sys
@@ -20,6 +20,7 @@ from oracle.parity import spinup_summary
 from gpu_pipeline import device_pipeline
 
 rows_per_band = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+row_offset = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 Htot = W = 4096
 chunk = 4
 o = Oracle()
@@ -30,6 +31,7 @@ worst_state, worst_capped, worst_ai = 0.0, 0.0, 0.0
 t_all = time.time()
 for b in range(8):
     r_band = int(round(b * (Htot - rows_per_band) / 7))
+    r_band = r_band + row_offset if r_band + row_offset + rows_per_band <= Htot else r_band - row_offset
     for r0 in range(r_band, r_band + rows_per_band, chunk):
         t0 = time.time()
         p = device_pipeline(api, 20221130, Htot, W, r0 * W, chunk * W, 365, 1, want_passes=True)
