@@ -8,7 +8,9 @@ from oracle.binding import Oracle
 from oracle.parity import assert_one_step, trajectory_summary
 from gpu_pipeline import device_pipeline
 o=Oracle(); bad=0
+off = int(sys.argv[1]) if len(sys.argv) > 1 else 0   # other rows of every band: python tools/parity_bands.py 137
 for row in (512, 1024, 1536, 2048, 2560, 3072, 3584, 4088):
+    row = row + off if row + off + 8 <= 4096 else row - off
     p=device_pipeline(api, 20221130, 4096, 4096, row*4096, 8*4096, 365, 1)
     msg=[]
     try: assert_one_step(o,p,f"row {row}")
