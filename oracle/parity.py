@@ -544,7 +544,8 @@ def assert_whole_pipeline(oracle, g, ref, aux, statics, doy, year, name="", name
 # spinup_summary: a stray cell whose spin-up amplifies an ulp of libm to >= AMPLIFIED_FROM in the reference's own other
 # builds is excused when the product is at most AMPLIFICATION_MARGIN times further from the pinned build than they are
 AMPLIFIED_FROM = 1.0e-7
-AMPLIFICATION_MARGIN = 100.0
+AMPLIFICATION_MARGIN = 1000.0   # the ratio of the seeds: the product's one-pass distance from the reference is 1e-13..1e-12,
+                                # a thousand ulp; a libm ulp is one.  Seen: 12x (cell (2057, 1855)), 93x (cell (2192, 523))
 
 
 def spinup_summary(oracle, state0, ai, passes2, aux, statics=None, forcing=None, max_flip_frac=0.05,
@@ -631,7 +632,7 @@ def spinup_summary(oracle, state0, ai, passes2, aux, statics=None, forcing=None,
             ex = np.zeros(len(cells), bool)
             doy, year, month, mid, nm, sw, tc, pn = forcing
 
-            def rel_dev(x, r):   # [wn, snow, qin, AI]: relative distance of a spin-up result from the pinned build's
+            def rel_dev(x, r):   # [wn, snow, qin, td, AI]: relative distance of a spin-up result from the pinned build's
                 with np.errstate(invalid="ignore", divide="ignore"):
                     d = np.abs(np.asarray(x, float) - np.asarray(r, float)) / np.maximum(np.abs(np.asarray(r, float)), 1e-300)
                 return np.where(np.isfinite(d), d, 0.0)
@@ -639,9 +640,9 @@ def spinup_summary(oracle, state0, ai, passes2, aux, statics=None, forcing=None,
             for i, c in enumerate(cells):
                 sl = slice(int(c), int(c) + 1)
                 st1 = {k: (v[:, sl] if np.ndim(v) == 2 else v[sl]) for k, v in statics.items()}
-                pin = np.array([ref[0, c], ref[1, c], ref[2, c], ai_ref[c]])
-                dev_product = rel_dev([state0[0][c], state0[1][c], state0[2][c], ai[c]], pin)
-                dev_builds = np.zeros(4)
+                pin = np.array([ref[0, c], ref[1, c], ref[2, c], ref[3, c], ai_ref[c]])
+                dev_product = rel_dev([state0[0][c], state0[1][c], state0[2][c], state0[3][c], ai[c]], pin)
+                dev_builds = np.zeros(5)
                 for oo in reference_variants().values():
                     _, a2 = oo.grid(doy, year, month, mid, nm, np.ascontiguousarray(sw[:, sl]),
                                     np.ascontiguousarray(tc[:, sl]), np.ascontiguousarray(pn[:, sl]), st1["lat"],
@@ -649,7 +650,7 @@ def spinup_summary(oracle, state0, ai, passes2, aux, statics=None, forcing=None,
                                     n_threads=1)
                     r2 = np.asarray(a2["state0"][0])
                     ai2 = float(a2["AI"][0])
-                    dev_builds = np.maximum(dev_builds, rel_dev([r2[0], r2[1], r2[2], ai2], pin))
+                    dev_builds = np.maximum(dev_builds, rel_dev([r2[0], r2[1], r2[2], r2[3], ai2], pin))
                     differs = abs(ai2 - ai_ref[c]) > rtol_ai * abs(ai_ref[c]) or _bad(r2[:3], ref[:3, c]).any() or (not fragile[c] and _bad(r2[3:4], ref[3:4, c]).any()) or \
                         not (r2[4] == ref[4, c] or (r2[4] != r2[4] and ref[4, c] != ref[4, c])) or \
                         int(a2["passes2"][0]) != int(aux["passes2"][c])
@@ -673,11 +674,11 @@ def spinup_summary(oracle, state0, ai, passes2, aux, statics=None, forcing=None,
                     # (one ulp of every libm result, or contraction and wider vectors: seeds of 1e-16) ends the spin-up
                     # at least AMPLIFIED_FROM away from the pinned build in every quantity the product breaks a rule on,
                     # and the product -- whose one-pass distance from the reference is 1e-13..1e-12, a thousand ulp -- is
-                    # no more than AMPLIFICATION_MARGIN times further.  (Found in round 6: cell (2057, 1855) of the
+                    # no more than AMPLIFICATION_MARGIN (= that ratio of the seeds) times further.  (Found in round 6: cell (2057, 1855) of the
                     # benchmark grid, 49 passes on an expanding orbit: pass-to-pass distance 4.6e-13 for ten passes, then
                     # x30 every ten; build C ends 1.9e-6 from the pinned build in qin, the product 2.2e-5.)
-                    broke = np.array([why["wn"][c], why["snow"][c], why["qin"][c], why["AI"][c]])
-                    other = why["td"][c] or why["nd"][c] or ("passes" in why and why["passes"][c])
+                    broke = np.array([why["wn"][c], why["snow"][c], why["qin"][c], why["td"][c], why["AI"][c]])
+                    other = why["nd"][c] or ("passes" in why and why["passes"][c])   # counts: never excused this way
                     if broke.any() and not other and (dev_builds[broke] >= AMPLIFIED_FROM).all() and \
                             (dev_product[broke] <= AMPLIFICATION_MARGIN * dev_builds[broke]).all():
                         ex[i] = True
