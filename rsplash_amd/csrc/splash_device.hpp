@@ -1188,15 +1188,30 @@ SPL_DEV void day_update(const CellConst& c, const DayTerms& K, const ViscTerms& 
     td -= 1.0;
     if ((R > 0.0) && (sm > c.Wmax)) {
         SPL_SITE();
-        // log(Kb) with Kb = exp(lkb_arg) (:1326, :1470): the round trip returns lkb_arg up to the
-        // rounding of Kb, an ABSOLUTE 1e-16, i.e. relative 1e-16/|lkb_arg|.  Above 1e-7 that is
-        // < 1e-9 and the argument itself is used (one log, and the exp when Kb was not needed for
-        // the upslope inflow, saved per cell-day); exactly 0 (flat terrain: Kb = 1, log = 0, the
-        // sticky-NaN drainage time of SURVEY trap 3) is exact either way; the sliver in between,
-        // and an underflowing Kb, go the reference's way.
+        // log(Kb) with Kb = exp(lkb_arg) (:1326, :1470): the round trip returns lkb_arg PLUS the rounding of Kb, a
+        // relative rho = (fl(e^x) - e^x)/e^x, |rho| <= 1.1e-16 -- relative to log(Kb) that is 1e-16/|x|, 1e-11 for the
+        // recession constants of slopes.  Rounds 1-5 dropped it above |x| = 1e-7 ("< 1e-9"): a spin-up on an expanding
+        // orbit amplified that 4.6e-13 of the lateral inflow to 2e-5 .. 9e-5 in one cell per million (round 6: cells
+        // (2057, 1855), (2192, 523), tests/test_conditioning.py); with the plain round trip the same cells end 2e-8 ..
+        // 3e-7 from the reference -- at 1.8 % of k_run_all.  So the rounding is REPRODUCED instead, for |x| < 2^-10
+        // (three cells in four of the benchmark grid: the median |x| is 2e-4, the stray cells' 6e-5 .. 1e-4):
+        // u = expm1(x) by its series to 1e-21, Kb = fl(1 + u) IS the correctly rounded exponential (glibc's is within
+        // 0.51 ulp of it), Kb - 1 is exact, and log(Kb) = x + log1p(rho) = x + ((Kb - 1) - u)/Kb to 1e-16 of itself; ten
+        // instructions instead of an exp and a log.  Kb = 1 exactly (x = 0: flat terrain, or |x| < 1e-16) gives
+        // log(Kb) = 0 exactly, the sticky-NaN drainage time of SURVEY trap 3, as the round trip does.  From 2^-10 on the
+        // rounding is < 1.2e-13 of log(Kb) and the argument itself stands, as before; an underflowing Kb and a NaN go
+        // the reference's way.
         const double ax = fabs(lkb_arg);
         double lkb = lkb_arg;
-        if (!(ax == 0.0 || (ax >= 1.0e-7 && ax <= 700.0))) {
+        if (ax < 0.0009765625) {
+            const double x = lkb_arg;
+            double pk = fma(x, 1.0 / 120.0, 1.0 / 24.0);
+            pk = fma(x, pk, 1.0 / 6.0);
+            pk = fma(x, pk, 0.5);
+            const double u = fma(x * x, pk, x);  // expm1(x) to 1e-21
+            const double v = (1.0 + u) - 1.0;    // fl(exp(x)) - 1, exact
+            lkb = (v == 0.0) ? 0.0 : fma(v - u, 1.0 - u, x); // x + ((Kb - 1) - expm1(x)) / Kb, 1/Kb = 1 - u to 1e-6
+        } else if (!(ax <= 700.0)) {
             if (!have_kb) Kb = fexp(lkb_arg);
             lkb = flog(Kb);
         }
